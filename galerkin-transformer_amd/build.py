@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Build libgt_hip.so (the C-ABI HIP library) in-tree for gfx950 with hipcc.
+
+    python galerkin-transformer_amd/build.py            # release library
+    python galerkin-transformer_amd/build.py --emu      # + debug twin with shuffle-emulated MFMA
+
+hipcc cross-compiles without a GPU.  Objects are cached by source mtime under csrc/.obj/.
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INC = os.path.join(os.path.dirname(HERE), "include")
+OUT_DIR = os.path.join(HERE, "galerkin_transformer", "_lib")
+SOURCES = ["gt_gemm.hip", "gt_ops.hip"]
+HEADERS = [os.path.join(CSRC, "gt_common.h"), os.path.join(INC, "gt_hip.h")]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(emu=False, verbose=False, force=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    tag = "_emu" if emu else ""
+    objdir = os.path.join(CSRC, ".obj" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC]
+    if emu:
+        flags.append("-DGT_EMULATE_MFMA=1")
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + HEADERS):
+            cmd = [_hipcc()] + flags + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    lib = os.path.join(OUT_DIR, f"libgt_hip{tag}.so")
+    if force or _stale(lib, objs):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", lib]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return lib
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--emu", action="store_true")
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("-v", "--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(False, a.verbose, a.force))
+    if a.emu:
+        print(build(True, a.verbose, a.force))

@@ -1,0 +1,80 @@
+// Shared device helpers for libgt_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gt_hip.h"
+
+namespace gt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------------------------------
+// Stateless dropout RNG.  key = mix(seed, salt) is wave-uniform (computed once per kernel),
+// the per-element part is a murmur3 finaliser over (idx * golden + key).
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ inline uint32_t drop_key(uint64_t seed, uint32_t salt) {
+    uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    return fmix32(lo ^ fmix32(hi + 0x9e3779b9u * (salt + 1u)));
+}
+__host__ __device__ inline uint32_t drop_hash(uint32_t key, uint32_t idx) {
+    return fmix32(idx * 0x9e3779b1u + key);
+}
+// p in (0,1): threshold such that keep <=> hash >= thresh
+__host__ inline uint32_t drop_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0) t = 0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+struct DropDev {          // device-side view of gt_dropout
+    uint32_t thresh;      // 0 => disabled
+    uint32_t salt;
+    float scale;          // 1/(1-p) (possibly signed)
+    const uint64_t* seed;
+};
+inline DropDev make_drop(const gt_dropout* d, float sign = 1.f) {
+    DropDev r{0u, 0u, sign, nullptr};
+    if (d && d->p > 0.f) {
+        r.thresh = drop_thresh(d->p);
+        r.salt = d->salt;
+        r.scale = sign / (1.f - d->p);
+        r.seed = d->seed;
+    }
+    return r;
+}
+__device__ inline uint32_t drop_key_dev(const DropDev& d) {
+    return d.thresh ? drop_key(*d.seed, d.salt) : 0u;
+}
+__device__ inline float drop_mul(const DropDev& d, uint32_t key, uint32_t idx) {
+    return (drop_hash(key, idx) >= d.thresh) ? d.scale : 0.f;
+}
+
+__device__ inline float silu_f(float x) { return x / (1.f + expf(-x)); }
+__device__ inline float dsilu_f(float x) {
+    float s = 1.f / (1.f + expf(-x));
+    return s * (1.f + x * (1.f - s));
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+#define GT_LAUNCH_CHECK()                         \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+}  // namespace gt

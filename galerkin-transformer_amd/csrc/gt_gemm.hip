@@ -1,0 +1,498 @@
+// Batched fp32 GEMM on the CDNA4 matrix pipe (v_mfma_f32_16x16x4_f32) with fused
+// prologue (stateless dropout mask on A) and epilogue (bias, rank-p update, activation,
+// aux-multiply, dropout, residual).  One kernel template serves every contraction of the
+// encoder layer and the spectral decoder, forward and backward (see include/gt_hip.h).
+//
+// Tiling (gfx950): block = WM x WN waves of 64 lanes; each wave owns a (16*MT) x (16*NT)
+// output tile as MT x NT MFMA 16x16 accumulators.  K is consumed in steps of 16 through a
+// double-buffered LDS stage.  LDS images are k-major ([16][BM], [16][BN]) so that a lane's
+// MT (NT) operands for one k are contiguous: one ds_read_b128 feeds 4 MFMAs.  Because the
+// lane->row map of the MFMA is free, lane i takes rows {MT*i .. MT*i+MT-1}: the accumulator
+// of a lane then holds NT consecutive output columns -> 16-byte global stores.
+// An XOR swizzle on the column index (bits 3-4, keyed by k>>2) makes both the transposing
+// ds_write_b32 of k-contiguous operands and the ds_read_b128 of the MFMA loop conflict-free.
+#include "gt_common.h"
+#include <algorithm>
+#include <cstring>
+
+namespace gt {
+
+struct GemmP {
+    int M, N, K;
+    int tiles_n, batch1, k_chunk;
+    const float* A; int64_t lda, a_bs0, a_bs1;
+    const float* B; int64_t ldb, b_bs0, b_bs1;
+    float* C; int64_t ldc, c_bs0, c_bs1, c_split;
+    int a_vec, b_vec, c_vec, raw;
+    DropDev a_drop; int64_t a_drop_ld, a_drop_bstride;
+    float alpha; const float* bias;
+    int rp; const float* rp_a; int64_t rp_lda, rp_a_bs0; const float* rp_b; int64_t rp_ldb;
+    float* pre; int64_t ldpre;
+    int act, aux_op; const float* aux; int64_t ldaux, aux_bs0, aux_bs1; float aux_scale;
+    DropDev drop;
+    const float* res; int64_t ldr, r_bs0, r_bs1;
+    float out_scale;
+};
+
+// ---- global -> registers: 4 consecutive elements of the operand tile -----------------------
+// L == 0: operand(x,k) = base[x*ld + k]  (k contiguous)  idx -> x = idx>>2, k = 4*(idx&3)
+// L == 1: operand(x,k) = base[k*ld + x]  (x contiguous)  idx -> k = idx/(BX/4), x = 4*(idx%(BX/4))
+template <int L, int BX>
+__device__ __forceinline__ f32x4 gload(const float* __restrict__ base, int64_t ld, int x0, int X,
+                                       int k0, int kend, int idx, int vec, const DropDev& dd,
+                                       uint32_t dkey, int64_t dld, int64_t dboff) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (L == 0) {
+        const int x = x0 + (idx >> 2), k = k0 + ((idx & 3) << 2);
+        if (x < X && k < kend) {
+            const float* ptr = base + (int64_t)x * ld + k;
+            if (vec && k + 3 < kend) {
+                v = *reinterpret_cast<const f32x4*>(ptr);
+            } else {
+                v[0] = ptr[0];
+                if (k + 1 < kend) v[1] = ptr[1];
+                if (k + 2 < kend) v[2] = ptr[2];
+                if (k + 3 < kend) v[3] = ptr[3];
+            }
+            if (dd.thresh) {
+                const uint32_t di = (uint32_t)(dboff + (int64_t)x * dld + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= drop_mul(dd, dkey, di + j);
+            }
+        }
+    } else {
+        constexpr int Q = BX / 4;
+        const int k = k0 + idx / Q, x = x0 + ((idx % Q) << 2);
+        if (k < kend && x < X) {
+            const float* ptr = base + (int64_t)k * ld + x;
+            if (vec && x + 3 < X) {
+                v = *reinterpret_cast<const f32x4*>(ptr);
+            } else {
+                v[0] = ptr[0];
+                if (x + 1 < X) v[1] = ptr[1];
+                if (x + 2 < X) v[2] = ptr[2];
+                if (x + 3 < X) v[3] = ptr[3];
+            }
+            if (dd.thresh) {
+                const uint32_t di = (uint32_t)(dboff + (int64_t)k * dld + x);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= drop_mul(dd, dkey, di + j);
+            }
+        }
+    }
+    return v;
+}
+
+// ---- registers -> LDS image s[16][BX], column swizzled by ((k>>2)&3)<<3 ---------------------
+template <int L, int BX>
+__device__ __forceinline__ void sstore(float* __restrict__ s, int idx, f32x4 v) {
+    if (L == 0) {
+        const int x = idx >> 2, c = idx & 3;
+        const int col = x ^ ((c << 3) & (BX - 1));
+        s[(4 * c + 0) * BX + col] = v[0];
+        s[(4 * c + 1) * BX + col] = v[1];
+        s[(4 * c + 2) * BX + col] = v[2];
+        s[(4 * c + 3) * BX + col] = v[3];
+    } else {
+        constexpr int Q = BX / 4;
+        const int k = idx / Q, x = (idx % Q) << 2;
+        const int col = x ^ ((((k >> 2) & 3) << 3) & (BX - 1));
+        *reinterpret_cast<f32x4*>(&s[k * BX + col]) = v;
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void lds_frag(const float* __restrict__ s, float (&f)[NV]) {
+    if (NV == 4) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(s);
+        f[0] = t[0]; f[1] = t[1]; f[2] = t[2]; f[3] = t[3];
+    } else if (NV == 2) {
+        f32x2 t = *reinterpret_cast<const f32x2*>(s);
+        f[0] = t[0]; f[1] = t[1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) f[j] = s[j];
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+#ifdef GT_EMULATE_MFMA
+    // Debug build: the same distributed-operand semantics with shuffles (documents the layout the
+    // kernel assumes: A[row=lane&15][k=lane>>4], B[k=lane>>4][col=lane&15], D[row=4*(lane>>4)+r][col=lane&15]).
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float av = __shfl(a, ((lane >> 4) * 4 + r) + 16 * k, 64);
+            float bv = __shfl(b, (lane & 15) + 16 * k, 64);
+            c[r] = fmaf(av, bv, c[r]);
+        }
+    }
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+template <int LA, int LB, int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
+    constexpr int BM = WM * 16 * MT, BN = WN * 16 * NT, BK = 16, T = WM * WN * 64;
+    constexpr int NVA = (BM * 4 + T - 1) / T, NVB = (BN * 4 + T - 1) / T;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * BM + 2 * BK * BN];
+    float* sA = smem;
+    float* sB = smem + 2 * BK * BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, kq = lane >> 4;
+    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z, b0 = z / p.batch1, b1 = z % p.batch1;
+    const int kbeg = blockIdx.y * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
+
+    const float* __restrict__ A = p.A + b0 * p.a_bs0 + b1 * p.a_bs1;
+    const float* __restrict__ Bm = p.B + b0 * p.b_bs0 + b1 * p.b_bs1;
+    const uint32_t akey = drop_key_dev(p.a_drop);
+    const int64_t adoff = (int64_t)z * p.a_drop_bstride;
+    const DropDev nodrop{0u, 0u, 1.f, nullptr};
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int s = 0; s < MT; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[NVA], rb[NVB];
+    auto g2r = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int idx = tid + i * T;
+            if ((BM * 4) % T == 0 || idx < BM * 4)
+                ra[i] = gload<LA, BM>(A, p.lda, m0, p.M, k0, kend, idx, p.a_vec, p.a_drop, akey,
+                                      p.a_drop_ld, adoff);
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int idx = tid + i * T;
+            if ((BN * 4) % T == 0 || idx < BN * 4)
+                rb[i] = gload<LB, BN>(Bm, p.ldb, n0, p.N, k0, kend, idx, p.b_vec, nodrop, 0u, 0, 0);
+        }
+    };
+    auto r2s = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int idx = tid + i * T;
+            if ((BM * 4) % T == 0 || idx < BM * 4) sstore<LA, BM>(sA + buf * BK * BM, idx, ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int idx = tid + i * T;
+            if ((BN * 4) % T == 0 || idx < BN * 4) sstore<LB, BN>(sB + buf * BK * BN, idx, rb[i]);
+        }
+    };
+
+    const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    if (nk > 0) {
+        g2r(kbeg);
+        r2s(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) g2r(kbeg + (kt + 1) * BK);
+        const float* __restrict__ cA = sA + buf * BK * BM;
+        const float* __restrict__ cB = sB + buf * BK * BN;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 4 * ks + kq;
+            const int swa = (ks << 3) & (BM - 1), swb = (ks << 3) & (BN - 1);
+            float a[MT], b[NT];
+            lds_frag<MT>(cA + k * BM + ((wm * 16 * MT + MT * li) ^ swa), a);
+            lds_frag<NT>(cB + k * BN + ((wn * 16 * NT + NT * li) ^ swb), b);
+#pragma unroll
+            for (int s = 0; s < MT; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[s][t] = mfma16(a[s], b[t], acc[s][t]);
+        }
+        if (kt + 1 < nk) r2s(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------- epilogue -------------------------------------------------
+    const int nb = n0 + wn * 16 * NT + NT * li;        // first of this lane's NT columns
+    if (nb >= p.N) return;
+    const bool full = (nb + NT <= p.N);
+    const int64_t coff = b0 * p.c_bs0 + b1 * p.c_bs1 + (int64_t)blockIdx.y * p.c_split;
+    float* __restrict__ C = p.C + coff;
+
+    float biasv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
+    const uint32_t dkey = drop_key_dev(p.drop);
+
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 16 * MT + MT * (4 * kq + r) + s;
+            if (m >= p.M) continue;
+            float v[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = acc[s][t][r];
+            float* cp = C + (int64_t)m * p.ldc + nb;
+            if (p.raw) {
+                if (full && p.c_vec && NT == 4) {
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (nb + t < p.N) cp[t] = v[t];
+                }
+                continue;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = p.alpha * v[t] + biasv[t];
+            if (p.rp) {
+                const float* ra_ = p.rp_a + b0 * p.rp_a_bs0 + (int64_t)m * p.rp_lda;
+                for (int j = 0; j < p.rp; ++j) {
+                    const float aj = ra_[j];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (nb + t < p.N) v[t] += aj * p.rp_b[(int64_t)(nb + t) * p.rp_ldb + j];
+                }
+            }
+            if (p.pre) {
+                float* pp = p.pre + ((int64_t)z * p.M + m) * p.ldpre + nb;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (nb + t < p.N) pp[t] = v[t];
+            }
+            if (p.act == GT_ACT_RELU) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = fmaxf(v[t], 0.f);
+            } else if (p.act == GT_ACT_SILU) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = silu_f(v[t]);
+            }
+            if (p.aux_op) {
+                const float* ap = p.aux + b0 * p.aux_bs0 + b1 * p.aux_bs1 + (int64_t)m * p.ldaux + nb;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (nb + t < p.N) {
+                        const float a = ap[t];
+                        v[t] *= (p.aux_op == GT_AUX_GT0)   ? (a > 0.f ? p.aux_scale : 0.f)
+                                : (p.aux_op == GT_AUX_DSILU) ? dsilu_f(a)
+                                                             : a * p.aux_scale;
+                    }
+                }
+            }
+            if (p.drop.thresh) {
+                const uint32_t di = (uint32_t)(((int64_t)z * p.M + m) * p.N + nb);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] *= drop_mul(p.drop, dkey, di + t);
+            }
+            if (p.res) {
+                const float* rp_ = p.res + b0 * p.r_bs0 + b1 * p.r_bs1 + (int64_t)m * p.ldr + nb;
+                if (full && p.c_vec && NT == 4) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(rp_);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) v[t] = rv[t] + p.out_scale * v[t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (nb + t < p.N) v[t] = rp_[t] + p.out_scale * v[t];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] *= p.out_scale;
+            }
+            if (full && p.c_vec && NT == 4) {
+                *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            } else if (full && p.c_vec && NT == 2) {
+                *reinterpret_cast<f32x2*>(cp) = f32x2{v[0], v[1]};
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (nb + t < p.N) cp[t] = v[t];
+            }
+        }
+    }
+}
+
+// out_z[m][n] = alpha * sum_s slab[s][z][m][n]
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit, int64_t slab_stride,
+                                     int M, int N, int batch1, float alpha, float* __restrict__ C,
+                                     int64_t ldc, int64_t c_bs0, int64_t c_bs1, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += slabs[k * slab_stride + i];
+        const int n = (int)(i % N);
+        const int64_t r = i / N;
+        const int m = (int)(r % M);
+        const int z = (int)(r / M);
+        C[(z / batch1) * c_bs0 + (z % batch1) * c_bs1 + (int64_t)m * ldc + n] = alpha * s;
+    }
+}
+
+struct Cfg { int mt, nt, wm, wn; };
+static const Cfg kCfgs[] = {{4, 4, 2, 2}, {2, 4, 2, 2}, {2, 2, 2, 2}, {2, 2, 4, 1}, {2, 1, 4, 1}};
+constexpr int kNumCfg = 5;
+
+template <int LA, int LB>
+static void launch_cfg(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
+    switch (cfg) {
+        case 0: hipLaunchKernelGGL((gemm_kernel<LA, LB, 4, 4, 2, 2>), grid, dim3(256), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 4, 2, 2>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 2, 2, 2>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 2, 4, 1>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 1, 4, 1>), grid, dim3(256), 0, st, p); break;
+    }
+}
+
+struct Plan { int cfg, bm, bn, tiles_m, tiles_n, split, k_chunk; };
+
+static bool has_epilogue(const gt_gemm_desc* d) {
+    return d->bias || d->rp || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res ||
+           d->out_scale != 1.f;
+}
+
+static int make_plan(const gt_gemm_desc* d, Plan* pl) {
+    if (d->M <= 0 || d->N <= 0 || d->K < 0 || d->batch0 <= 0 || d->batch1 <= 0) return GT_EINVAL;
+    const int64_t batch = (int64_t)d->batch0 * d->batch1;
+    if (batch > 65535) return GT_EINVAL;
+    int c;
+    if (d->N <= 16) c = 4;
+    else if (d->N <= 32) c = 3;
+    else if (d->N <= 64) c = 2;
+    else {
+        const int64_t blocks0 = (int64_t)ceil_div(d->M, 128) * ceil_div(d->N, 128) * batch;
+        if (d->M > 64 && blocks0 >= 384) c = 0;
+        else c = (d->N > 64) ? 1 : 2;
+    }
+    pl->cfg = c;
+    pl->bm = kCfgs[c].wm * 16 * kCfgs[c].mt;
+    pl->bn = kCfgs[c].wn * 16 * kCfgs[c].nt;
+    pl->tiles_m = ceil_div(d->M, pl->bm);
+    pl->tiles_n = ceil_div(d->N, pl->bn);
+    const int64_t blocks = (int64_t)pl->tiles_m * pl->tiles_n * batch;
+    int split = d->split_k;
+    if (split == 0) {
+        split = 1;
+        if (!has_epilogue(d) && blocks < 256 && d->K >= 1024) {
+            split = (int)std::min<int64_t>((768 + blocks - 1) / blocks, d->K / 256);
+            if (split < 1) split = 1;
+        }
+    }
+    if (split > 1 && has_epilogue(d)) return GT_ENOTSUP;
+    if (split > 1024) split = 1024;
+    int chunk = ceil_div(std::max(d->K, 1), split);
+    chunk = ((chunk + 15) / 16) * 16;
+    split = std::max(1, ceil_div(std::max(d->K, 1), chunk));
+    pl->split = split;
+    pl->k_chunk = chunk;
+    return 0;
+}
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline bool m4(int64_t v) { return (v & 3) == 0; }
+
+}  // namespace gt
+
+using namespace gt;
+
+extern "C" void gt_gemm_desc_init(gt_gemm_desc* d) {
+    memset(d, 0, sizeof(*d));
+    d->alpha = 1.f;
+    d->out_scale = 1.f;
+    d->a_drop_sign = 1.f;
+    d->aux_scale = 1.f;
+    d->batch0 = d->batch1 = 1;
+    d->split_k = 1;
+}
+
+extern "C" int gt_gemm_plan(const gt_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* split) {
+    Plan pl;
+    int rc = make_plan(d, &pl);
+    if (rc) return rc;
+    if (bm) *bm = pl.bm;
+    if (bn) *bn = pl.bn;
+    if (split) *split = pl.split;
+    return 0;
+}
+
+extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
+    Plan pl;
+    if (make_plan(d, &pl)) return 0;
+    if (pl.split <= 1) return 0;
+    return (int64_t)pl.split * d->batch0 * d->batch1 * d->M * d->N * (int64_t)sizeof(float);
+}
+
+extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream) {
+    if (!d || !d->A || !d->B || !d->C) return GT_EINVAL;
+    if ((d->layout_a | d->layout_b) & ~1) return GT_EINVAL;
+    if (d->rp < 0 || d->rp > 8) return GT_EINVAL;
+    if ((d->a_drop.p > 0.f && !d->a_drop.seed) || (d->drop.p > 0.f && !d->drop.seed)) return GT_EINVAL;
+    if (d->a_drop.p >= 1.f || d->drop.p >= 1.f || d->a_drop.p < 0.f || d->drop.p < 0.f) return GT_EINVAL;
+    Plan pl;
+    int rc = make_plan(d, &pl);
+    if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t batch = (int64_t)d->batch0 * d->batch1;
+
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.tiles_n = pl.tiles_n; p.batch1 = d->batch1; p.k_chunk = pl.k_chunk;
+    p.A = d->A; p.lda = d->lda; p.a_bs0 = d->a_bs0; p.a_bs1 = d->a_bs1;
+    p.B = d->B; p.ldb = d->ldb; p.b_bs0 = d->b_bs0; p.b_bs1 = d->b_bs1;
+    p.a_vec = al16(d->A) && m4(d->lda) && m4(d->a_bs0) && m4(d->a_bs1);
+    p.b_vec = al16(d->B) && m4(d->ldb) && m4(d->b_bs0) && m4(d->b_bs1);
+    p.a_drop = make_drop(&d->a_drop, d->a_drop_sign);
+    p.a_drop_ld = d->a_drop_ld; p.a_drop_bstride = d->a_drop_bstride;
+
+    const int64_t mn = (int64_t)d->M * d->N;
+    if (pl.split > 1) {
+        const int64_t need = (int64_t)pl.split * batch * mn * (int64_t)sizeof(float);
+        if (!ws || ws_bytes < need) return GT_EWS;
+        p.C = reinterpret_cast<float*>(ws);
+        p.ldc = d->N; p.c_bs0 = (int64_t)d->batch1 * mn; p.c_bs1 = mn; p.c_split = batch * mn;
+        p.c_vec = al16(ws) && m4(d->N) && m4(mn);
+        p.raw = 1;
+        p.alpha = 1.f; p.out_scale = 1.f;
+    } else {
+        p.C = d->C; p.ldc = d->ldc; p.c_bs0 = d->c_bs0; p.c_bs1 = d->c_bs1; p.c_split = 0;
+        p.c_vec = al16(d->C) && m4(d->ldc) && m4(d->c_bs0) && m4(d->c_bs1);
+        if (d->res) p.c_vec = p.c_vec && al16(d->res) && m4(d->ldr) && m4(d->r_bs0) && m4(d->r_bs1);
+        p.alpha = d->alpha; p.bias = d->bias;
+        p.rp = d->rp; p.rp_a = d->rp_a; p.rp_lda = d->rp_lda; p.rp_a_bs0 = d->rp_a_bs0;
+        p.rp_b = d->rp_b; p.rp_ldb = d->rp_ldb;
+        if (p.rp && (!p.rp_a || !p.rp_b)) return GT_EINVAL;
+        p.pre = d->pre; p.ldpre = d->ldpre;
+        p.act = d->act; p.aux_op = d->aux_op; p.aux = d->aux; p.ldaux = d->ldaux;
+        p.aux_bs0 = d->aux_bs0; p.aux_bs1 = d->aux_bs1; p.aux_scale = d->aux_scale;
+        if (p.aux_op && !p.aux) return GT_EINVAL;
+        p.drop = make_drop(&d->drop);
+        p.res = d->res; p.ldr = d->ldr; p.r_bs0 = d->r_bs0; p.r_bs1 = d->r_bs1;
+        p.out_scale = d->out_scale;
+    }
+
+    dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split, (unsigned)batch);
+    if (d->layout_a == 0 && d->layout_b == 0) launch_cfg<0, 0>(pl.cfg, grid, st, p);
+    else if (d->layout_a == 0 && d->layout_b == 1) launch_cfg<0, 1>(pl.cfg, grid, st, p);
+    else if (d->layout_a == 1 && d->layout_b == 0) launch_cfg<1, 0>(pl.cfg, grid, st, p);
+    else launch_cfg<1, 1>(pl.cfg, grid, st, p);
+    GT_LAUNCH_CHECK();
+
+    if (pl.split > 1) {
+        const int64_t total = batch * mn;
+        const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(ws), pl.split, batch * mn, d->M, d->N,
+                           d->batch1, d->alpha, d->C, d->ldc, d->c_bs0, d->c_bs1, total);
+        GT_LAUNCH_CHECK();
+    }
+    return 0;
+}

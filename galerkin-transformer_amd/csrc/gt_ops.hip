@@ -1,0 +1,676 @@
+// Memory-bound and small-matrix kernels of the encoder / spectral hot path (gfx950).
+//   - stateless dropout helpers, column sums, slab reductions (deterministic two-pass)
+//   - per-head LayerNorm + position concat (fwd/bwd)
+//   - Galerkin small-matrix stage: M = mask .* (K'^T V')/n, P = M Wfc_h^T (fwd/bwd)
+//   - row LayerNorm (fwd/bwd), activation backward
+//   - spectral complex mode mixing (fwd/bwd)
+// All launches go to the caller's stream; no allocation, no synchronisation.
+#include "gt_common.h"
+#include <algorithm>
+#include <cstring>
+
+namespace gt {
+
+// ------------------------------------------------------------------------------------------ misc
+__global__ void seed_advance_kernel(uint64_t* s, uint64_t inc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *s += inc;
+}
+
+__global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
+                                     DropDev d) {
+    const uint32_t key = drop_key_dev(d);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = x[i] * (d.thresh ? drop_mul(d, key, (uint32_t)i) : d.scale);
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int64_t stride, int n_slabs,
+                                   int64_t n, float alpha, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < n_slabs; ++k) s += slabs[k * stride + i];
+        out[i] = alpha * s;
+    }
+}
+
+// partial[chunk][n] = sum over the chunk's rows of A[m][n]*keep(m,n); 64 columns per block.x
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t lda, int M,
+                                                     int N, DropDev d, float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    const uint32_t key = drop_key_dev(d);
+    float s = 0.f;
+    if (n < N) {
+        for (int m = r0 + w; m < r1; m += 4) {
+            float v = A[(int64_t)m * lda + n];
+            if (d.thresh) v *= drop_mul(d, key, (uint32_t)((int64_t)m * N + n));
+            else v *= d.scale;
+            s += v;
+        }
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && n < N)
+        partial[(int64_t)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pre,
+                               float* __restrict__ dpre, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = pre[i], g = dout[i];
+        dpre[i] = (act == GT_ACT_SILU) ? g * dsilu_f(x) : (act == GT_ACT_RELU ? (x > 0.f ? g : 0.f) : g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ head norm
+// One block handles HN_TOK tokens.  LDS image: seg[tok][3h][dk+1] (pad 1 -> a thread walking its own
+// segment is conflict-free against its neighbours).
+constexpr int HN_TOK_MAX = 16;
+// tokens per block such that the LDS image stays <= ~48 KiB
+static inline int hn_tok(int per_token_floats) {
+    int t = 12000 / std::max(per_token_floats, 1);
+    return std::max(1, std::min(t, HN_TOK_MAX));
+}
+
+__global__ __launch_bounds__(256) void headnorm_fwd_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ pos, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int T, int h, int dk, int p, int DP, int norm_mask, float eps,
+    float* __restrict__ out, float* __restrict__ stats, int HN_TOK) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int d3 = 3 * h * dk, S = 3 * h, pitch = dk + 1;
+    const int t0 = blockIdx.x * HN_TOK, nt = min(HN_TOK, T - t0);
+    for (int e = threadIdx.x; e < nt * d3; e += blockDim.x) {
+        const int tok = e / d3, f = e % d3;
+        lds[(tok * S + f / dk) * pitch + (f % dk)] = qkv[(int64_t)(t0 + tok) * d3 + f];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < nt * S; it += blockDim.x) {
+        const int tok = it / S, s = it % S, stream = s / h, head = s % h;
+        if (!((norm_mask >> stream) & 1)) continue;
+        int ni = 0;
+        for (int q = 0; q < stream; ++q) ni += (norm_mask >> q) & 1;
+        float* v = lds + it * pitch;
+        float mu = 0.f;
+        for (int j = 0; j < dk; ++j) mu += v[j];
+        mu /= dk;
+        float var = 0.f;
+        for (int j = 0; j < dk; ++j) { const float c = v[j] - mu; var += c * c; }
+        var /= dk;
+        const float rstd = 1.f / sqrtf(var + eps);
+        const float* g = gamma + (ni * h + head) * dk;
+        const float* b = beta + (ni * h + head) * dk;
+        for (int j = 0; j < dk; ++j) v[j] = (v[j] - mu) * rstd * g[j] + b[j];
+        float* st = stats + (((int64_t)ni * T + t0 + tok) * h + head) * 2;
+        st[0] = mu;
+        st[1] = rstd;
+    }
+    __syncthreads();
+    const int per_stream = nt * h * DP;
+    for (int e = threadIdx.x; e < 3 * per_stream; e += blockDim.x) {
+        const int stream = e / per_stream, r = e % per_stream;
+        const int tok = r / (h * DP), head = (r / DP) % h, c = r % DP;
+        float val = 0.f;
+        if (c < p) val = pos[(int64_t)(t0 + tok) * p + c];
+        else if (c < p + dk) val = lds[(tok * S + stream * h + head) * pitch + (c - p)];
+        out[((int64_t)stream * T + t0) * h * DP + r] = val;
+    }
+}
+
+__global__ __launch_bounds__(256) void headnorm_bwd_kernel(
+    const float* __restrict__ d_out, const float* __restrict__ qkv, const float* __restrict__ gamma,
+    const float* __restrict__ stats, int T, int h, int dk, int p, int DP, int norm_mask,
+    float* __restrict__ d_qkv, float* __restrict__ partial /* [nblk][2(dg,db)][2][h][dk] */, int HN_TOK) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int d3 = 3 * h * dk, S = 3 * h, pitch = dk + 1;
+    float* xs = lds;                              // raw -> xhat   [HN_TOK][S][pitch]
+    float* dy = lds + HN_TOK * S * pitch;         // upstream grad [HN_TOK][S][pitch]
+    float* m1 = dy + HN_TOK * S * pitch;          // [HN_TOK*S]
+    float* m2 = m1 + HN_TOK * S;
+    float* rs = m2 + HN_TOK * S;
+    const int t0 = blockIdx.x * HN_TOK, nt = min(HN_TOK, T - t0);
+    for (int e = threadIdx.x; e < nt * d3; e += blockDim.x) {
+        const int tok = e / d3, f = e % d3, s = f / dk, j = f % dk;
+        xs[(tok * S + s) * pitch + j] = qkv[(int64_t)(t0 + tok) * d3 + f];
+        const int stream = s / h, head = s % h;
+        dy[(tok * S + s) * pitch + j] =
+            d_out[(((int64_t)stream * T + t0 + tok) * h + head) * DP + p + j];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < nt * S; it += blockDim.x) {
+        const int tok = it / S, s = it % S, stream = s / h, head = s % h;
+        if (!((norm_mask >> stream) & 1)) continue;
+        int ni = 0;
+        for (int q = 0; q < stream; ++q) ni += (norm_mask >> q) & 1;
+        const float* st = stats + (((int64_t)ni * T + t0 + tok) * h + head) * 2;
+        const float mu = st[0], rstd = st[1];
+        const float* g = gamma + (ni * h + head) * dk;
+        float* x = xs + it * pitch;
+        const float* gy = dy + it * pitch;
+        float a1 = 0.f, a2 = 0.f;
+        for (int j = 0; j < dk; ++j) {
+            const float xh = (x[j] - mu) * rstd;
+            x[j] = xh;
+            const float gg = gy[j] * g[j];
+            a1 += gg;
+            a2 += gg * xh;
+        }
+        m1[it] = a1 / dk;
+        m2[it] = a2 / dk;
+        rs[it] = rstd;
+    }
+    __syncthreads();
+    // dgamma/dbeta partial sums over this block's tokens: one thread per (ni, head, j)
+    const int nn = ((norm_mask & 1) + ((norm_mask >> 1) & 1) + ((norm_mask >> 2) & 1));
+    const int hd = h * dk;
+    float* pg = partial + (int64_t)blockIdx.x * 2 * 2 * hd;
+    for (int e = threadIdx.x; e < 2 * hd; e += blockDim.x) {
+        const int ni = e / hd, head = (e % hd) / dk, j = e % dk;
+        float sg = 0.f, sb = 0.f;
+        if (ni < nn) {
+            int stream = -1, cnt = -1;
+            for (int q = 0; q < 3; ++q)
+                if ((norm_mask >> q) & 1) { if (++cnt == ni) { stream = q; break; } }
+            const int s = stream * h + head;
+            for (int tok = 0; tok < nt; ++tok) {
+                const float gyv = dy[(tok * S + s) * pitch + j];
+                sg += gyv * xs[(tok * S + s) * pitch + j];
+                sb += gyv;
+            }
+        }
+        pg[e] = sg;
+        pg[2 * hd + e] = sb;
+    }
+    for (int e = threadIdx.x; e < nt * d3; e += blockDim.x) {
+        const int tok = e / d3, f = e % d3, s = f / dk, j = f % dk, stream = s / h, head = s % h;
+        const int it = tok * S + s;
+        float g = dy[it * pitch + j];
+        if ((norm_mask >> stream) & 1) {
+            int ni = 0;
+            for (int q = 0; q < stream; ++q) ni += (norm_mask >> q) & 1;
+            const float gm = gamma[(ni * h + head) * dk + j];
+            g = rs[it] * (g * gm - m1[it] - xs[it * pitch + j] * m2[it]);
+        }
+        d_qkv[(int64_t)(t0 + tok) * d3 + f] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ galerkin finalize
+__global__ __launch_bounds__(256) void galerkin_fin_fwd_kernel(
+    const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int h, int DP, int Dr, int d,
+    float inv_n, const float* __restrict__ mask, DropDev drop, const float* __restrict__ Wfc,
+    float* __restrict__ Mt, float* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sM = lds;               // [DP][DP]
+    float* sW = lds + DP * DP;     // [d][Dr]
+    const int bh = blockIdx.x, b = bh / h, hh = bh % h;
+    const uint32_t key = drop_key_dev(drop);
+    const int64_t mo = (int64_t)bh * DP * DP;
+    for (int e = threadIdx.x; e < DP * DP; e += blockDim.x) {
+        const int j = e / DP, c = e % DP;
+        float s = 0.f;
+        for (int k = 0; k < n_slabs; ++k) s += slabs[k * slab_stride + mo + e];
+        float mul = inv_n;
+        if (mask) mul *= mask[mo + e];
+        else if (drop.thresh) mul *= drop_mul(drop, key, (uint32_t)(mo + e));
+        const float v = (j < Dr && c < Dr) ? s * mul : 0.f;
+        sM[e] = v;
+        Mt[mo + e] = v;
+    }
+    for (int e = threadIdx.x; e < d * Dr; e += blockDim.x) {
+        const int c = e / Dr, ee = e % Dr;
+        sW[e] = Wfc[(int64_t)c * (h * Dr) + hh * Dr + ee];
+    }
+    __syncthreads();
+    float* Pb = P + ((int64_t)b * h * DP + (int64_t)hh * DP) * d;
+    for (int e = threadIdx.x; e < DP * d; e += blockDim.x) {
+        const int j = e / d, c = e % d;
+        float acc = 0.f;
+        if (j < Dr) {
+            const float* mr = sM + j * DP;
+            const float* wr = sW + c * Dr;
+            for (int ee = 0; ee < Dr; ++ee) acc = fmaf(mr[ee], wr[ee], acc);
+        }
+        Pb[e] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void galerkin_fin_bwd_kernel(
+    const float* __restrict__ dPt, const float* __restrict__ Mt, const float* __restrict__ mask,
+    DropDev drop, const float* __restrict__ Wfc, int h, int DP, int Dr, int d, float inv_n,
+    float* __restrict__ dM, float* __restrict__ dWfc_slabs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int dpitch = d + 1;
+    float* sdp = lds;                       // [DP][d+1]   dP_h[j][c]
+    float* sW = sdp + DP * dpitch;          // [d][Dr]
+    float* sM = sW + d * Dr;                // [DP][DP]
+    const int bh = blockIdx.x, b = bh / h, hh = bh % h;
+    const uint32_t key = drop_key_dev(drop);
+    const int64_t mo = (int64_t)bh * DP * DP;
+    const float* src = dPt + (int64_t)b * d * (h * DP) + hh * DP;
+    for (int e = threadIdx.x; e < d * DP; e += blockDim.x) {
+        const int c = e / DP, j = e % DP;
+        sdp[j * dpitch + c] = src[(int64_t)c * (h * DP) + j];
+    }
+    for (int e = threadIdx.x; e < d * Dr; e += blockDim.x) {
+        const int c = e / Dr, ee = e % Dr;
+        sW[e] = Wfc[(int64_t)c * (h * Dr) + hh * Dr + ee];
+    }
+    for (int e = threadIdx.x; e < DP * DP; e += blockDim.x) sM[e] = Mt[mo + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < DP * DP; e += blockDim.x) {
+        const int j = e / DP, ee = e % DP;
+        float acc = 0.f;
+        if (j < Dr && ee < Dr) {
+            const float* dp = sdp + j * dpitch;
+            for (int c = 0; c < d; ++c) acc = fmaf(dp[c], sW[c * Dr + ee], acc);
+            float mul = inv_n;
+            if (mask) mul *= mask[mo + e];
+            else if (drop.thresh) mul *= drop_mul(drop, key, (uint32_t)(mo + e));
+            acc *= mul;
+        }
+        dM[mo + e] = acc;
+    }
+    float* dst = dWfc_slabs + (int64_t)b * d * (h * Dr) + hh * Dr;
+    for (int e = threadIdx.x; e < d * Dr; e += blockDim.x) {
+        const int c = e / Dr, ee = e % Dr;
+        float acc = 0.f;
+        for (int j = 0; j < Dr; ++j) acc = fmaf(sdp[j * dpitch + c], sM[j * DP + ee], acc);
+        dst[(int64_t)c * (h * Dr) + ee] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ row layernorm
+// one wave per row, 4 rows per block
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int T, int d,
+                                                            float eps, float* __restrict__ y,
+                                                            float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= T) return;
+    const float* xr = x + (int64_t)row * d;
+    float s = 0.f;
+    for (int j = lane; j < d; j += 64) s += xr[j];
+    const float mu = wave_sum(s) / d;
+    float v = 0.f;
+    for (int j = lane; j < d; j += 64) { const float c = xr[j] - mu; v += c * c; }
+    const float rstd = 1.f / sqrtf(wave_sum(v) / d + eps);
+    float* yr = y + (int64_t)row * d;
+    for (int j = lane; j < d; j += 64) yr[j] = (xr[j] - mu) * rstd * gamma[j] + beta[j];
+    if (lane == 0) { stats[2 * (int64_t)row] = mu; stats[2 * (int64_t)row + 1] = rstd; }
+}
+
+constexpr int LN_ROWS = 64;   // rows per block in backward (partial dgamma/dbeta per block)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ stats, int T, int d, float* __restrict__ dx,
+    float* __restrict__ partial /* [nblk][2][d] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][2][d]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* mg = lds + (w * 2) * d;
+    float* mb = mg + d;
+    for (int j = lane; j < d; j += 64) { mg[j] = 0.f; mb[j] = 0.f; }
+    const int r0 = blockIdx.x * LN_ROWS, r1 = min(T, r0 + LN_ROWS);
+    for (int row = r0 + w; row < r1; row += 4) {
+        const float mu = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
+        const float* xr = x + (int64_t)row * d;
+        const float* gr = dy + (int64_t)row * d;
+        float a1 = 0.f, a2 = 0.f;
+        for (int j = lane; j < d; j += 64) {
+            const float xh = (xr[j] - mu) * rstd, gg = gr[j] * gamma[j];
+            a1 += gg;
+            a2 += gg * xh;
+            mg[j] += gr[j] * xh;
+            mb[j] += gr[j];
+        }
+        a1 = wave_sum(a1) / d;
+        a2 = wave_sum(a2) / d;
+        float* dr = dx + (int64_t)row * d;
+        for (int j = lane; j < d; j += 64) {
+            const float xh = (xr[j] - mu) * rstd;
+            dr[j] = rstd * (gr[j] * gamma[j] - a1 - xh * a2);
+        }
+    }
+    __syncthreads();
+    float* pg = partial + (int64_t)blockIdx.x * 2 * d;
+    for (int j = threadIdx.x; j < 2 * d; j += blockDim.x)
+        pg[j] = lds[j] + lds[2 * d + j] + lds[4 * d + j] + lds[6 * d + j];
+}
+
+// ------------------------------------------------------------------------------------------ mode mixing
+// One block per retained mode q.  X: [B][2][Qx][Cin], Y: [B][2][Qy][Cout] (re plane, im plane),
+// W: [Cin][Cout][Q][2].  Complex product, no conjugate (layers.py:1143-1151).
+constexpr int MM_BCH = 8;   // batch entries staged per pass
+__global__ __launch_bounds__(256) void modemix_fwd_kernel(const float* __restrict__ X,
+                                                          const float* __restrict__ W, int B, int Q,
+                                                          int Cin, int Cout, int64_t xbs, int64_t ybs,
+                                                          int Qx, int Qy, int qoff,
+                                                          float* __restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sWr = lds;                       // [Cin][Cout]
+    float* sWi = sWr + Cin * Cout;          // [Cin][Cout]
+    float* sX = sWi + Cin * Cout;           // [MM_BCH][2][Cin]
+    const int q = blockIdx.x;
+    for (int e = threadIdx.x; e < Cin * Cout; e += blockDim.x) {
+        const float2 w = *reinterpret_cast<const float2*>(W + ((int64_t)e * Q + q) * 2);
+        sWr[e] = w.x;
+        sWi[e] = w.y;
+    }
+    for (int bb = 0; bb < B; bb += MM_BCH) {
+        const int nb = min(MM_BCH, B - bb);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nb * 2 * Cin; e += blockDim.x) {
+            const int b = e / (2 * Cin), ri = (e / Cin) & 1, i = e % Cin;
+            sX[e] = X[(int64_t)(bb + b) * xbs + ((int64_t)ri * Qx + qoff + q) * Cin + i];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nb * Cout; e += blockDim.x) {
+            const int b = e / Cout, o = e % Cout;
+            const float* xr = sX + b * 2 * Cin;
+            const float* xi = xr + Cin;
+            float yr = 0.f, yi = 0.f;
+            for (int i = 0; i < Cin; ++i) {
+                const float wr = sWr[i * Cout + o], wi = sWi[i * Cout + o];
+                yr = fmaf(xr[i], wr, yr); yr = fmaf(-xi[i], wi, yr);
+                yi = fmaf(xi[i], wr, yi); yi = fmaf(xr[i], wi, yi);
+            }
+            float* yp = Y + (int64_t)(bb + b) * ybs + ((int64_t)qoff + q) * Cout + o;
+            yp[0] = yr;
+            yp[(int64_t)Qy * Cout] = yi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void modemix_bwd_kernel(
+    const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ dY, int B, int Q,
+    int Cin, int Cout, int64_t xbs, int64_t ybs, int Qx, int Qy, int qoff, float* __restrict__ dX,
+    float* __restrict__ dW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sWr = lds;                       // [Cin][Cout]
+    float* sWi = sWr + Cin * Cout;
+    float* sX = sWi + Cin * Cout;           // [MM_BCH][2][Cin]
+    float* sG = sX + MM_BCH * 2 * Cin;      // [MM_BCH][2][Cout]
+    const int q = blockIdx.x;
+    for (int e = threadIdx.x; e < Cin * Cout; e += blockDim.x) {
+        const float2 w = *reinterpret_cast<const float2*>(W + ((int64_t)e * Q + q) * 2);
+        sWr[e] = w.x;
+        sWi[e] = w.y;
+    }
+    // each thread owns up to 4 (i,o) pairs of dW, accumulated over the whole batch in registers
+    constexpr int MAXP = 8;
+    float gr[MAXP], gi[MAXP];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) gr[k] = gi[k] = 0.f;
+    for (int bb = 0; bb < B; bb += MM_BCH) {
+        const int nb = min(MM_BCH, B - bb);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nb * 2 * Cin; e += blockDim.x) {
+            const int b = e / (2 * Cin), ri = (e / Cin) & 1, i = e % Cin;
+            sX[e] = X[(int64_t)(bb + b) * xbs + ((int64_t)ri * Qx + qoff + q) * Cin + i];
+        }
+        for (int e = threadIdx.x; e < nb * 2 * Cout; e += blockDim.x) {
+            const int b = e / (2 * Cout), ri = (e / Cout) & 1, o = e % Cout;
+            sG[e] = dY[(int64_t)(bb + b) * ybs + ((int64_t)ri * Qy + qoff + q) * Cout + o];
+        }
+        __syncthreads();
+        // dX[b][.][q][i] = sum_o dY (x) conj(W)
+        for (int e = threadIdx.x; e < nb * Cin; e += blockDim.x) {
+            const int b = e / Cin, i = e % Cin;
+            const float* g_r = sG + b * 2 * Cout;
+            const float* g_i = g_r + Cout;
+            float xr = 0.f, xi = 0.f;
+            for (int o = 0; o < Cout; ++o) {
+                const float wr = sWr[i * Cout + o], wi = sWi[i * Cout + o];
+                xr = fmaf(g_r[o], wr, xr); xr = fmaf(g_i[o], wi, xr);
+                xi = fmaf(g_i[o], wr, xi); xi = fmaf(-g_r[o], wi, xi);
+            }
+            float* xp = dX + (int64_t)(bb + b) * xbs + ((int64_t)qoff + q) * Cin + i;
+            xp[0] = xr;
+            xp[(int64_t)Qx * Cin] = xi;
+        }
+        // dW[i][o] += sum_b conj(X) (x) dY
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int e = threadIdx.x + k * 256;
+            if (e < Cin * Cout) {
+                const int i = e / Cout, o = e % Cout;
+                for (int b = 0; b < nb; ++b) {
+                    const float xr = sX[b * 2 * Cin + i], xi = sX[b * 2 * Cin + Cin + i];
+                    const float g_r = sG[b * 2 * Cout + o], g_i = sG[b * 2 * Cout + Cout + o];
+                    gr[k] = fmaf(xr, g_r, gr[k]); gr[k] = fmaf(xi, g_i, gr[k]);
+                    gi[k] = fmaf(xr, g_i, gi[k]); gi[k] = fmaf(-xi, g_r, gi[k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int e = threadIdx.x + k * 256;
+        if (e < Cin * Cout)
+            *reinterpret_cast<float2*>(dW + ((int64_t)e * Q + q) * 2) = make_float2(gr[k], gi[k]);
+    }
+}
+
+// kernels whose dynamic LDS may exceed 64 KiB opt in once (host-side attribute, not a stream op)
+template <typename K>
+static int allow_big_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    if (bytes > 160 * 1024) return GT_ENOTSUP;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+static inline int grid_for(int64_t n, int block = 256, int cap = 4096) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>((n + block - 1) / block, cap));
+}
+
+}  // namespace gt
+
+using namespace gt;
+
+extern "C" int gt_abi_version(void) { return GT_ABI_VERSION; }
+extern "C" const char* gt_target_arch(void) { return "gfx950"; }
+
+extern "C" int gt_seed_advance(uint64_t* seed, uint64_t inc, void* stream) {
+    if (!seed) return GT_EINVAL;
+    hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seed, inc);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_dropout_apply(const float* x, float* out, int64_t n, const gt_dropout* d, void* stream) {
+    if (!x || !out || n < 0) return GT_EINVAL;
+    if (d && d->p > 0.f && !d->seed) return GT_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, out,
+                       n, make_drop(d));
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_slab_reduce(const float* slabs, int64_t stride, int32_t n_slabs, int64_t n, float alpha,
+                              float* out, void* stream) {
+    if (!slabs || !out || n_slabs <= 0 || n <= 0) return GT_EINVAL;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, slabs,
+                       stride, n_slabs, n, alpha, out);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_colsum(const float* A, int64_t lda, int32_t M, int32_t N, const gt_dropout* a_drop,
+                         float a_sign, float* out, void* ws, int64_t ws_bytes, void* stream) {
+    if (!A || !out || M <= 0 || N <= 0) return GT_EINVAL;
+    if (a_drop && a_drop->p > 0.f && !a_drop->seed) return GT_EINVAL;
+    const int chunks = ceil_div(M, CS_ROWS);
+    if (!ws || ws_bytes < (int64_t)chunks * N * (int64_t)sizeof(float)) return GT_EWS;
+    float* partial = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), chunks), dim3(256), 0, (hipStream_t)stream, A,
+                       lda, M, N, make_drop(a_drop, a_sign), partial);
+    GT_LAUNCH_CHECK();
+    return gt_slab_reduce(partial, N, chunks, N, 1.f, out, stream);
+}
+
+extern "C" int gt_act_bwd(const float* dout, const float* pre, float* dpre, int64_t n, int32_t act,
+                          void* stream) {
+    if (!dout || !pre || !dpre || n <= 0) return GT_EINVAL;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dout, pre,
+                       dpre, n, act);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline int round4(int v) { return (v + 3) & ~3; }
+
+extern "C" int gt_headnorm_fwd(const float* qkv, const float* pos, const float* gamma, const float* beta,
+                               int32_t T, int32_t h, int32_t dk, int32_t p, int32_t norm_mask, float eps,
+                               float* out, float* stats, void* stream) {
+    if (!qkv || !out || T <= 0 || h <= 0 || dk <= 0 || p < 0) return GT_EINVAL;
+    if (p > 0 && !pos) return GT_EINVAL;
+    if (norm_mask & ~7) return GT_EINVAL;
+    if (norm_mask && (!gamma || !beta || !stats)) return GT_EINVAL;
+    const int DP = round4(dk + p);
+    const int tok = hn_tok(3 * h * (dk + 1));
+    const size_t lds = (size_t)tok * 3 * h * (dk + 1) * sizeof(float);
+    if (lds > 64 * 1024) return GT_ENOTSUP;
+    hipLaunchKernelGGL(headnorm_fwd_kernel, dim3(ceil_div(T, tok)), dim3(256), lds, (hipStream_t)stream,
+                       qkv, pos, gamma, beta, T, h, dk, p, DP, norm_mask, eps, out, stats, tok);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline int hn_tok_bwd(int h, int dk) { return hn_tok(2 * 3 * h * (dk + 1) + 9 * h); }
+extern "C" int64_t gt_headnorm_bwd_ws_bytes(int32_t T, int32_t h, int32_t dk) {
+    return (int64_t)ceil_div(T, hn_tok_bwd(h, dk)) * 4 * h * dk * (int64_t)sizeof(float);
+}
+
+extern "C" int gt_headnorm_bwd(const float* d_out, const float* qkv, const float* gamma, const float* stats,
+                               int32_t T, int32_t h, int32_t dk, int32_t p, int32_t norm_mask, float* d_qkv,
+                               float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, void* stream) {
+    if (!d_out || !qkv || !d_qkv || T <= 0 || h <= 0 || dk <= 0 || p < 0) return GT_EINVAL;
+    if (norm_mask & ~7) return GT_EINVAL;
+    if (norm_mask && (!gamma || !stats || !dgamma || !dbeta)) return GT_EINVAL;
+    if (!ws || ws_bytes < gt_headnorm_bwd_ws_bytes(T, h, dk)) return GT_EWS;
+    const int DP = round4(dk + p);
+    const int S = 3 * h;
+    const int tok = hn_tok_bwd(h, dk);
+    const size_t lds = ((size_t)2 * tok * S * (dk + 1) + 3 * tok * S) * sizeof(float);
+    if (lds > 64 * 1024) return GT_ENOTSUP;
+    const int nblk = ceil_div(T, tok);
+    float* partial = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(headnorm_bwd_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, d_out, qkv,
+                       gamma, stats, T, h, dk, p, DP, norm_mask, d_qkv, partial, tok);
+    GT_LAUNCH_CHECK();
+    if (norm_mask) {
+        const int hd = h * dk;
+        // partial: [nblk][ (dg: 2*hd) | (db: 2*hd) ]
+        int rc = gt_slab_reduce(partial, 4 * hd, nblk, 2 * hd, 1.f, dgamma, stream);
+        if (rc) return rc;
+        rc = gt_slab_reduce(partial + 2 * hd, 4 * hd, nblk, 2 * hd, 1.f, dbeta, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int gt_galerkin_finalize_fwd(const float* slabs, int32_t n_slabs, int64_t slab_stride, int32_t B,
+                                        int32_t h, int32_t DP, int32_t Dr, int32_t d, int32_t n_tokens,
+                                        const float* mask, const gt_dropout* drop, const float* Wfc,
+                                        float* Mt, float* P, void* stream) {
+    if (!slabs || !Wfc || !Mt || !P || n_slabs <= 0 || B <= 0 || h <= 0 || Dr <= 0 || DP < Dr || d <= 0 ||
+        n_tokens <= 0)
+        return GT_EINVAL;
+    if (drop && drop->p > 0.f && !drop->seed) return GT_EINVAL;
+    const size_t lds = ((size_t)DP * DP + (size_t)d * Dr) * sizeof(float);
+    if (int rc = allow_big_lds(galerkin_fin_fwd_kernel, lds)) return rc;
+    hipLaunchKernelGGL(galerkin_fin_fwd_kernel, dim3(B * h), dim3(256), lds, (hipStream_t)stream, slabs,
+                       n_slabs, slab_stride, h, DP, Dr, d, 1.f / (float)n_tokens, mask,
+                       make_drop(mask ? nullptr : drop), Wfc, Mt, P);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_galerkin_finalize_bwd(const float* dPt, const float* Mt, const float* mask,
+                                        const gt_dropout* drop, const float* Wfc, int32_t B, int32_t h,
+                                        int32_t DP, int32_t Dr, int32_t d, int32_t n_tokens, float* dM,
+                                        float* dWfc_slabs, void* stream) {
+    if (!dPt || !Mt || !Wfc || !dM || !dWfc_slabs || B <= 0 || h <= 0 || Dr <= 0 || DP < Dr || d <= 0 ||
+        n_tokens <= 0)
+        return GT_EINVAL;
+    if (drop && drop->p > 0.f && !drop->seed) return GT_EINVAL;
+    const size_t lds = ((size_t)DP * (d + 1) + (size_t)d * Dr + (size_t)DP * DP) * sizeof(float);
+    if (int rc = allow_big_lds(galerkin_fin_bwd_kernel, lds)) return rc;
+    hipLaunchKernelGGL(galerkin_fin_bwd_kernel, dim3(B * h), dim3(256), lds, (hipStream_t)stream, dPt, Mt,
+                       mask, make_drop(mask ? nullptr : drop), Wfc, h, DP, Dr, d, 1.f / (float)n_tokens, dM,
+                       dWfc_slabs);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_layernorm_fwd(const float* x, const float* gamma, const float* beta, int32_t T, int32_t d,
+                                float eps, float* y, float* stats, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats || T <= 0 || d <= 0) return GT_EINVAL;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(T, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       gamma, beta, T, d, eps, y, stats);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t gt_layernorm_bwd_ws_bytes(int32_t T, int32_t d) {
+    return (int64_t)ceil_div(T, LN_ROWS) * 2 * d * (int64_t)sizeof(float);
+}
+
+extern "C" int gt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats,
+                                int32_t T, int32_t d, float* dx, float* dgamma, float* dbeta, void* ws,
+                                int64_t ws_bytes, void* stream) {
+    if (!dy || !x || !gamma || !stats || !dx || !dgamma || !dbeta || T <= 0 || d <= 0) return GT_EINVAL;
+    if (!ws || ws_bytes < gt_layernorm_bwd_ws_bytes(T, d)) return GT_EWS;
+    const int nblk = ceil_div(T, LN_ROWS);
+    const size_t lds = (size_t)8 * d * sizeof(float);
+    if (lds > 64 * 1024) return GT_ENOTSUP;
+    float* partial = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, dy, x, gamma,
+                       stats, T, d, dx, partial);
+    GT_LAUNCH_CHECK();
+    int rc = gt_slab_reduce(partial, 2 * d, nblk, d, 1.f, dgamma, stream);
+    if (rc) return rc;
+    return gt_slab_reduce(partial + d, 2 * d, nblk, d, 1.f, dbeta, stream);
+}
+
+extern "C" int gt_modemix_fwd(const float* X, const float* W, int32_t B, int32_t Q, int32_t Cin, int32_t Cout,
+                              int64_t x_bstride, int64_t y_bstride, int32_t q_total_x, int32_t q_total_y,
+                              int32_t q_off, float* Y, void* stream) {
+    if (!X || !W || !Y || B <= 0 || Q <= 0 || Cin <= 0 || Cout <= 0 || q_off < 0 ||
+        q_off + Q > q_total_x || q_off + Q > q_total_y)
+        return GT_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(W) & 7) != 0) return GT_EALIGN;
+    const size_t lds = ((size_t)2 * Cin * Cout + (size_t)MM_BCH * 2 * Cin) * sizeof(float);
+    if (int rc = allow_big_lds(modemix_fwd_kernel, lds)) return rc;
+    hipLaunchKernelGGL(modemix_fwd_kernel, dim3(Q), dim3(256), lds, (hipStream_t)stream, X, W, B, Q, Cin,
+                       Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, Y);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_modemix_bwd(const float* X, const float* W, const float* dY, int32_t B, int32_t Q,
+                              int32_t Cin, int32_t Cout, int64_t x_bstride, int64_t y_bstride,
+                              int32_t q_total_x, int32_t q_total_y, int32_t q_off, float* dX, float* dW,
+                              void* stream) {
+    if (!X || !W || !dY || !dX || !dW || B <= 0 || Q <= 0 || Cin <= 0 || Cout <= 0 || q_off < 0 ||
+        q_off + Q > q_total_x || q_off + Q > q_total_y)
+        return GT_EINVAL;
+    if (((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(dW)) & 7) != 0) return GT_EALIGN;
+    if (Cin * Cout > 8 * 256) return GT_ENOTSUP;
+    const size_t lds =
+        ((size_t)2 * Cin * Cout + (size_t)MM_BCH * 2 * Cin + (size_t)MM_BCH * 2 * Cout) * sizeof(float);
+    if (int rc = allow_big_lds(modemix_bwd_kernel, lds)) return rc;
+    hipLaunchKernelGGL(modemix_bwd_kernel, dim3(Q), dim3(256), lds, (hipStream_t)stream, X, W, dY, B, Q, Cin,
+                       Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, dX, dW);
+    GT_LAUNCH_CHECK();
+    return 0;
+}

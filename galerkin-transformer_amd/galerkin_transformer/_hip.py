@@ -1,0 +1,403 @@
+"""ctypes binding of libgt_hip.so (the C ABI declared in include/gt_hip.h).
+
+This module is the only place that touches the shared library.  It fails loudly when the
+library is missing or cannot be loaded: there is no CPU / eager fallback for the hot path.
+PyTorch is used for device memory, streams and autograd plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import torch
+
+_LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
+_LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
+
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
+ACT_CODE = {None: ACT_NONE, "none": ACT_NONE, "identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
+
+
+class GtDropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("salt", C.c_uint32), ("seed", C.c_void_p)]
+
+
+class GtGemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("layout_a", C.c_int32), ("layout_b", C.c_int32),
+        ("batch0", C.c_int32), ("batch1", C.c_int32), ("split_k", C.c_int32),
+        ("A", C.c_void_p), ("lda", C.c_int64), ("a_bs0", C.c_int64), ("a_bs1", C.c_int64),
+        ("B", C.c_void_p), ("ldb", C.c_int64), ("b_bs0", C.c_int64), ("b_bs1", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64), ("c_bs0", C.c_int64), ("c_bs1", C.c_int64),
+        ("a_drop", GtDropout), ("a_drop_sign", C.c_float),
+        ("a_drop_ld", C.c_int64), ("a_drop_bstride", C.c_int64),
+        ("alpha", C.c_float), ("bias", C.c_void_p),
+        ("rp", C.c_int32), ("rp_a", C.c_void_p), ("rp_lda", C.c_int64), ("rp_a_bs0", C.c_int64),
+        ("rp_b", C.c_void_p), ("rp_ldb", C.c_int64),
+        ("pre", C.c_void_p), ("ldpre", C.c_int64),
+        ("act", C.c_int32), ("aux_op", C.c_int32), ("aux", C.c_void_p), ("ldaux", C.c_int64),
+        ("aux_bs0", C.c_int64), ("aux_bs1", C.c_int64), ("aux_scale", C.c_float),
+        ("drop", GtDropout),
+        ("res", C.c_void_p), ("ldr", C.c_int64), ("r_bs0", C.c_int64), ("r_bs1", C.c_int64),
+        ("out_scale", C.c_float),
+    ]
+
+
+_lib = None
+
+_PROTOS = {
+    "gt_abi_version": (C.c_int, []),
+    "gt_target_arch": (C.c_char_p, []),
+    "gt_seed_advance": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "gt_dropout_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(GtDropout), C.c_void_p]),
+    "gt_gemm_desc_init": (None, [C.POINTER(GtGemmDesc)]),
+    "gt_gemm_ws_bytes": (C.c_int64, [C.POINTER(GtGemmDesc)]),
+    "gt_gemm": (C.c_int, [C.POINTER(GtGemmDesc), C.c_void_p, C.c_int64, C.c_void_p]),
+    "gt_gemm_plan": (C.c_int, [C.POINTER(GtGemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                               C.POINTER(C.c_int32)]),
+    "gt_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GtDropout), C.c_float,
+                            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gt_act_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "gt_slab_reduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p,
+                                 C.c_void_p]),
+    "gt_headnorm_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_float, C.c_void_p, C.c_void_p,
+                                                                     C.c_void_p]),
+    "gt_headnorm_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p] * 4 + [C.c_int64,
+                                                                                        C.c_void_p]),
+    "gt_headnorm_bwd_ws_bytes": (C.c_int64, [C.c_int32] * 3),
+    "gt_galerkin_finalize_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64] + [C.c_int32] * 6 +
+                                 [C.c_void_p, C.POINTER(GtDropout), C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "gt_galerkin_finalize_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GtDropout),
+                                           C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p,
+                                                                            C.c_void_p]),
+    "gt_layernorm_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p]),
+    "gt_layernorm_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_int32] + [C.c_void_p] * 4 +
+                         [C.c_int64, C.c_void_p]),
+    "gt_layernorm_bwd_ws_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "gt_modemix_fwd": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_int64, C.c_int64] +
+                       [C.c_int32] * 3 + [C.c_void_p, C.c_void_p]),
+    "gt_modemix_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_int64, C.c_int64] +
+                       [C.c_int32] * 3 + [C.c_void_p] * 3),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+def lib_path() -> str:
+    return os.path.join(_LIB_DIR, _LIB_NAME)
+
+
+def lib():
+    """Load (once) and return the shared library.  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: the HIP hot path is not built (run "
+                f"`python galerkin-transformer_amd/build.py` or __graft_entry__.build()). "
+                f"There is no CPU fallback for these operators.")
+        try:
+            handle = C.CDLL(path)      # torch is already imported: its libamdhip64.so.7 is reused
+        except OSError as e:
+            raise RuntimeError(f"cannot load {path}: {e}") from e
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.gt_abi_version() != 1:
+            raise RuntimeError("libgt_hip ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+class GtError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "GT_EINVAL (bad shape/flags)", -2: "GT_EALIGN (misaligned pointer/ld)",
+        -3: "GT_EWS (scratch too small)", -4: "GT_ENOTSUP (not implemented)"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise GtError(f"{what} failed: {_ERR.get(rc, 'hipError ' + str(rc))}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def need_f32_cuda(*ts: torch.Tensor):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("galerkin_transformer HIP operators need tensors on a ROCm device "
+                               "(got a CPU tensor); there is no CPU fallback for the hot path")
+        if t.dtype != torch.float32:
+            raise TypeError(f"galerkin_transformer HIP operators are fp32 (got {t.dtype})")
+
+
+# ----------------------------------------------------------------------------------- scratch / rng state
+_ws_cache = {}
+_WS_MIN = 64 << 20
+
+
+def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Per-device scratch buffer (stream-ordered reuse: every consumer runs on the current stream)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        size = max(_WS_MIN, int(nbytes * 1.25))
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+_seed_cache = {}
+
+
+def seed_state(device: torch.device) -> torch.Tensor:
+    """Device-resident uint64 dropout seed (as int64 tensor of one element)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    s = _seed_cache.get(key)
+    if s is None:
+        s = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
+        _seed_cache[key] = s
+    return s
+
+
+def set_seed(seed: int, device: Optional[torch.device] = None):
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    seed_state(device).fill_(seed & 0x7FFFFFFFFFFFFFFF)
+
+
+def advance_seed(device: Optional[torch.device] = None, inc: int = 1):
+    """Bump the dropout seed (captured into graphs: every replay draws fresh masks)."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    s = seed_state(device)
+    check(lib().gt_seed_advance(s.data_ptr(), inc, stream_ptr()), "gt_seed_advance")
+
+
+def dropout_desc(p: float, salt: int, device: torch.device) -> GtDropout:
+    d = GtDropout()
+    d.p = float(p) if p else 0.0
+    d.salt = int(salt) & 0xFFFFFFFF
+    d.seed = seed_state(device).data_ptr() if d.p > 0 else None
+    return d
+
+
+# ----------------------------------------------------------------------------------- GEMM
+def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K: int, *,
+         layout_a: int = 0, layout_b: int = 0, lda: int, ldb: int, ldc: int,
+         batch: Tuple[int, int] = (1, 1), a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), split_k: int = 1,
+         alpha: float = 1.0, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+         a_drop: Optional[GtDropout] = None, a_drop_sign: float = 1.0, a_drop_ld: int = 0,
+         a_drop_bstride: int = 0,
+         rp: int = 0, rp_a: Optional[torch.Tensor] = None, rp_lda: int = 0, rp_a_bs0: int = 0,
+         rp_b: Optional[torch.Tensor] = None, rp_ldb: int = 0,
+         pre: Optional[torch.Tensor] = None, ldpre: int = 0,
+         aux_op: int = AUX_NONE, aux: Optional[torch.Tensor] = None, ldaux: int = 0, aux_bs=(0, 0),
+         aux_scale: float = 1.0, drop: Optional[GtDropout] = None,
+         res: Optional[torch.Tensor] = None, ldr: int = 0, r_bs=(0, 0), out_scale: float = 1.0):
+    """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics)."""
+    need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, pre, aux, res)
+    L = lib()
+    d = GtGemmDesc()
+    L.gt_gemm_desc_init(C.byref(d))
+    d.M, d.N, d.K = M, N, K
+    d.layout_a, d.layout_b = layout_a, layout_b
+    d.batch0, d.batch1 = batch
+    d.split_k = split_k
+    d.A, d.lda, d.a_bs0, d.a_bs1 = A.data_ptr(), lda, a_bs[0], a_bs[1]
+    d.B, d.ldb, d.b_bs0, d.b_bs1 = B.data_ptr(), ldb, b_bs[0], b_bs[1]
+    d.C, d.ldc, d.c_bs0, d.c_bs1 = Cout.data_ptr(), ldc, c_bs[0], c_bs[1]
+    if a_drop is not None and a_drop.p > 0:
+        d.a_drop = a_drop
+        d.a_drop_ld, d.a_drop_bstride = a_drop_ld, a_drop_bstride
+    d.a_drop_sign = a_drop_sign
+    d.alpha = alpha
+    d.bias = ptr(bias)
+    if rp:
+        d.rp, d.rp_a, d.rp_lda, d.rp_a_bs0 = rp, rp_a.data_ptr(), rp_lda, rp_a_bs0
+        d.rp_b, d.rp_ldb = rp_b.data_ptr(), rp_ldb
+    if pre is not None:
+        d.pre, d.ldpre = pre.data_ptr(), ldpre
+    d.act = act
+    if aux_op:
+        d.aux_op, d.aux, d.ldaux = aux_op, aux.data_ptr(), ldaux
+        d.aux_bs0, d.aux_bs1, d.aux_scale = aux_bs[0], aux_bs[1], aux_scale
+    if drop is not None and drop.p > 0:
+        d.drop = drop
+    if res is not None:
+        d.res, d.ldr, d.r_bs0, d.r_bs1 = res.data_ptr(), ldr, r_bs[0], r_bs[1]
+    d.out_scale = out_scale
+    need = L.gt_gemm_ws_bytes(C.byref(d))
+    wsp, wsn = None, 0
+    if need > 0:
+        ws = workspace(A.device, need)
+        wsp, wsn = ws.data_ptr(), ws.numel()
+    check(L.gt_gemm(C.byref(d), wsp, wsn, stream_ptr()), "gt_gemm")
+    return Cout
+
+
+def gemm_plan(M, N, K, batch=(1, 1), split_k=1):
+    d = GtGemmDesc()
+    lib().gt_gemm_desc_init(C.byref(d))
+    d.M, d.N, d.K = M, N, K
+    d.batch0, d.batch1 = batch
+    d.split_k = split_k
+    bm, bn, sp = C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib().gt_gemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(sp)), "gt_gemm_plan")
+    return bm.value, bn.value, sp.value
+
+
+# ----------------------------------------------------------------------------------- small wrappers
+def colsum(A: torch.Tensor, M: int, N: int, lda: int, a_drop: Optional[GtDropout] = None,
+           sign: float = 1.0) -> torch.Tensor:
+    need_f32_cuda(A)
+    out = torch.empty(N, dtype=torch.float32, device=A.device)
+    chunks = (M + 255) // 256
+    ws = workspace(A.device, chunks * N * 4)
+    dp = C.byref(a_drop) if (a_drop is not None and a_drop.p > 0) else None
+    check(lib().gt_colsum(A.data_ptr(), lda, M, N, dp, sign, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                          stream_ptr()), "gt_colsum")
+    return out
+
+
+def slab_reduce(slabs: torch.Tensor, n_slabs: int, stride: int, n: int, out: torch.Tensor,
+                alpha: float = 1.0):
+    need_f32_cuda(slabs, out)
+    check(lib().gt_slab_reduce(slabs.data_ptr(), stride, n_slabs, n, alpha, out.data_ptr(), stream_ptr()),
+          "gt_slab_reduce")
+    return out
+
+
+def act_bwd(dout: torch.Tensor, pre: torch.Tensor, act: int) -> torch.Tensor:
+    need_f32_cuda(dout, pre)
+    dout = dout.contiguous()
+    out = torch.empty_like(pre)
+    check(lib().gt_act_bwd(dout.data_ptr(), pre.data_ptr(), out.data_ptr(), pre.numel(), act, stream_ptr()),
+          "gt_act_bwd")
+    return out
+
+
+def dropout_apply(x: torch.Tensor, d: GtDropout) -> torch.Tensor:
+    need_f32_cuda(x)
+    out = torch.empty_like(x)
+    check(lib().gt_dropout_apply(x.data_ptr(), out.data_ptr(), x.numel(), C.byref(d), stream_ptr()),
+          "gt_dropout_apply")
+    return out
+
+
+def round4(v: int) -> int:
+    return (v + 3) & ~3
+
+
+def headnorm_fwd(qkv: torch.Tensor, pos: Optional[torch.Tensor], gamma: Optional[torch.Tensor],
+                 beta: Optional[torch.Tensor], T: int, h: int, dk: int, p: int, norm_mask: int, eps: float):
+    """qkv [T,3*h*dk] -> out [3,T,h,DP], stats [2,T,h,2]."""
+    need_f32_cuda(qkv, pos, gamma, beta)
+    DP = round4(dk + p)
+    out = torch.empty(3, T, h, DP, dtype=torch.float32, device=qkv.device)
+    stats = torch.empty(2, T, h, 2, dtype=torch.float32, device=qkv.device)
+    check(lib().gt_headnorm_fwd(qkv.data_ptr(), ptr(pos), ptr(gamma), ptr(beta), T, h, dk, p, norm_mask,
+                                eps, out.data_ptr(), stats.data_ptr(), stream_ptr()), "gt_headnorm_fwd")
+    return out, stats
+
+
+def headnorm_bwd(d_out: torch.Tensor, qkv: torch.Tensor, gamma: Optional[torch.Tensor], stats: torch.Tensor,
+                 T: int, h: int, dk: int, p: int, norm_mask: int):
+    need_f32_cuda(d_out, qkv, gamma, stats)
+    dev = qkv.device
+    d_qkv = torch.empty(T, 3 * h * dk, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(2, h, dk, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(2, h, dk, dtype=torch.float32, device=dev)
+    need = lib().gt_headnorm_bwd_ws_bytes(T, h, dk)
+    ws = workspace(dev, need)
+    check(lib().gt_headnorm_bwd(d_out.data_ptr(), qkv.data_ptr(), ptr(gamma), stats.data_ptr(), T, h, dk, p,
+                                norm_mask, d_qkv.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                ws.data_ptr(), ws.numel(), stream_ptr()), "gt_headnorm_bwd")
+    return d_qkv, dgamma, dbeta
+
+
+def galerkin_finalize_fwd(slabs: torch.Tensor, n_slabs: int, slab_stride: int, B: int, h: int, DP: int,
+                          Dr: int, d: int, n_tokens: int, mask: Optional[torch.Tensor],
+                          drop: Optional[GtDropout], Wfc: torch.Tensor):
+    need_f32_cuda(slabs, mask, Wfc)
+    dev = slabs.device
+    Mt = torch.empty(B, h, DP, DP, dtype=torch.float32, device=dev)
+    P = torch.empty(B, h * DP, d, dtype=torch.float32, device=dev)
+    dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
+    check(lib().gt_galerkin_finalize_fwd(slabs.data_ptr(), n_slabs, slab_stride, B, h, DP, Dr, d, n_tokens,
+                                         ptr(mask), dp, Wfc.data_ptr(), Mt.data_ptr(), P.data_ptr(),
+                                         stream_ptr()), "gt_galerkin_finalize_fwd")
+    return Mt, P
+
+
+def galerkin_finalize_bwd(dPt: torch.Tensor, Mt: torch.Tensor, mask: Optional[torch.Tensor],
+                          drop: Optional[GtDropout], Wfc: torch.Tensor, B: int, h: int, DP: int, Dr: int,
+                          d: int, n_tokens: int):
+    need_f32_cuda(dPt, Mt, mask, Wfc)
+    dev = dPt.device
+    dM = torch.empty(B, h, DP, DP, dtype=torch.float32, device=dev)
+    dW_slabs = torch.empty(B, d, h * Dr, dtype=torch.float32, device=dev)
+    dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
+    check(lib().gt_galerkin_finalize_bwd(dPt.data_ptr(), Mt.data_ptr(), ptr(mask), dp, Wfc.data_ptr(), B, h,
+                                         DP, Dr, d, n_tokens, dM.data_ptr(), dW_slabs.data_ptr(),
+                                         stream_ptr()), "gt_galerkin_finalize_bwd")
+    return dM, dW_slabs
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    need_f32_cuda(x, gamma, beta)
+    d = x.shape[-1]
+    T = x.numel() // d
+    y = torch.empty_like(x)
+    stats = torch.empty(T, 2, dtype=torch.float32, device=x.device)
+    check(lib().gt_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), T, d, eps, y.data_ptr(),
+                                 stats.data_ptr(), stream_ptr()), "gt_layernorm_fwd")
+    return y, stats
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats: torch.Tensor):
+    need_f32_cuda(dy, x, gamma, stats)
+    d = x.shape[-1]
+    T = x.numel() // d
+    dx = torch.empty_like(x)
+    dg = torch.empty(d, dtype=torch.float32, device=x.device)
+    db = torch.empty(d, dtype=torch.float32, device=x.device)
+    ws = workspace(x.device, lib().gt_layernorm_bwd_ws_bytes(T, d))
+    check(lib().gt_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), T, d,
+                                 dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 stream_ptr()), "gt_layernorm_bwd")
+    return dx, dg, db
+
+
+def modemix_fwd(X: torch.Tensor, W: torch.Tensor, Y: torch.Tensor, B: int, Q: int, Cin: int, Cout: int,
+                q_total: int, q_off: int):
+    """X [B,2,q_total,Cin], W [Cin,Cout,Q,2], Y [B,2,q_total,Cout] (written for q in [q_off,q_off+Q))."""
+    need_f32_cuda(X, W, Y)
+    check(lib().gt_modemix_fwd(X.data_ptr(), W.data_ptr(), B, Q, Cin, Cout, 2 * q_total * Cin,
+                               2 * q_total * Cout, q_total, q_total, q_off, Y.data_ptr(), stream_ptr()),
+          "gt_modemix_fwd")
+    return Y
+
+
+def modemix_bwd(X: torch.Tensor, W: torch.Tensor, dY: torch.Tensor, dX: torch.Tensor, dW: torch.Tensor,
+                B: int, Q: int, Cin: int, Cout: int, q_total: int, q_off: int):
+    need_f32_cuda(X, W, dY, dX, dW)
+    check(lib().gt_modemix_bwd(X.data_ptr(), W.data_ptr(), dY.data_ptr(), B, Q, Cin, Cout, 2 * q_total * Cin,
+                               2 * q_total * Cout, q_total, q_total, q_off, dX.data_ptr(), dW.data_ptr(),
+                               stream_ptr()), "gt_modemix_bwd")
+    return dX, dW

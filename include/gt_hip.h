@@ -1,0 +1,202 @@
+/*
+ * gt_hip.h -- C ABI of libgt_hip.so: the MI355X (gfx950) device path for the Galerkin /
+ * Fourier simple-attention encoder layer and the spectral-convolution decoder.
+ *
+ * Boundary contract
+ *   - plain C: device pointers, sizes, POD descriptors; no torch / C++ types.
+ *   - every entry point enqueues work on `stream` (a hipStream_t passed as void*) and
+ *     returns immediately; no hidden synchronisation, no allocation (graph-capturable).
+ *     Scratch memory is supplied by the caller (`ws`, `ws_bytes`).
+ *   - all tensors are fp32, row-major, device-resident.
+ *   - return value: 0 = success, >0 = hipError_t from the launch, <0 = GT_E* argument error.
+ *
+ * The reference (scaomath/galerkin-transformer) has no FFI of its own: its hot path is a chain
+ * of ATen calls issued from Python.  Each entry point below names the reference call site(s)
+ * (file:line under /root/reference) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ */
+#ifndef GT_HIP_H
+#define GT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GT_ABI_VERSION 1
+
+/* argument errors */
+#define GT_EINVAL   (-1)   /* bad shape / flag combination            */
+#define GT_EALIGN   (-2)   /* pointer or leading dimension misaligned */
+#define GT_EWS      (-3)   /* scratch buffer too small                */
+#define GT_ENOTSUP  (-4)   /* combination not implemented             */
+
+/* activations */
+#define GT_ACT_NONE 0
+#define GT_ACT_RELU 1
+#define GT_ACT_SILU 2
+
+/* gt_gemm_desc.aux_op: multiply the result by a function of aux[m][n] */
+#define GT_AUX_NONE      0
+#define GT_AUX_GT0       1   /* v *= (aux > 0) ? aux_scale : 0      (ReLU' with the dropout scale folded in) */
+#define GT_AUX_DSILU     2   /* v *= d/dx silu(aux)                 (aux = saved pre-activation)             */
+#define GT_AUX_MUL       3   /* v *= aux * aux_scale                (explicit multiplicative mask replay)    */
+
+int gt_abi_version(void);
+/* Name of the code object's target ("gfx950").  Does not touch the device. */
+const char* gt_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stateless dropout.  keep(idx) = hash(seed[0], salt, idx) >= p*2^32, scale 1/(1-p).  `seed`
+ * is a DEVICE pointer to one uint64 so a captured graph replays with fresh masks after the
+ * host bumps it (gt_seed_advance).  The same (seed, salt, idx) regenerates the mask in backward.
+ * Replaces F.dropout / nn.Dropout at layers.py:701,731,981 and model.py:125,132.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gt_dropout {
+    float p;                    /* 0 => disabled                                   */
+    uint32_t salt;              /* distinguishes call sites                        */
+    const uint64_t* seed;       /* device pointer, may be NULL iff p == 0          */
+} gt_dropout;
+
+/* seed[0] += inc  (one tiny kernel; capturable) */
+int gt_seed_advance(uint64_t* seed, uint64_t inc, void* stream);
+/* out[i] = x[i] * keepscale(i)   -- standalone elementwise dropout, n elements, used by tests */
+int gt_dropout_apply(const float* x, float* out, int64_t n, const gt_dropout* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched fp32 GEMM on the MFMA pipe (v_mfma_f32_16x16x4_f32) with fused prologue/epilogue.
+ *
+ *   for z = (b0, b1) in [0,batch0) x [0,batch1):
+ *     acc[m][n] = sum_k  A_z(m,k) * keepA(m,k) * B_z(k,n)
+ *     v   = alpha*acc + bias[n] + sum_{j<rp} rp_a[m][j]*rp_b[n][j]
+ *     pre[m][n] = v                                  (optional)
+ *     v   = act(v) ;  v *= f(aux[m][n]) ;  v = dropout(v)
+ *     C_z[m][n] = res_z[m][n] + out_scale*v          (res optional)
+ *
+ *   layout_a = 0 : A(m,k) = A[m*lda + k]     (k contiguous; activations [tokens, features])
+ *   layout_a = 1 : A(m,k) = A[k*lda + m]     (m contiguous; transposed use, reduction over rows)
+ *   layout_b = 0 : B(k,n) = B[n*ldb + k]     (nn.Linear weight [out, in])
+ *   layout_b = 1 : B(k,n) = B[k*ldb + n]
+ *
+ * Replaces every nn.Linear / torch.matmul / einsum contraction on the path:
+ *   layers.py:837-839 (QKV), :723,:733 (K^T V, Q M), :687,:703 (Q K^T, S V), :897 (fc),
+ *   :979-987 (FFN), :1087-1098 / :1172-1189 (truncated DFT stages), model.py:615-629, and the
+ *   autograd backward of each (addmm / bmm backward = the transposed layouts).
+ *
+ * split_k: 0 = let the library decide, 1 = never split, >1 = that many K-slices (reduced in a
+ * second deterministic pass; only alpha is allowed as epilogue then).  ws/ws_bytes: scratch for
+ * the slabs (gt_gemm_ws_bytes gives an upper bound).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gt_gemm_desc {
+    int32_t M, N, K;
+    int32_t layout_a, layout_b;
+    int32_t batch0, batch1;
+    int32_t split_k;
+
+    const float* A; int64_t lda, a_bs0, a_bs1;
+    const float* B; int64_t ldb, b_bs0, b_bs1;
+    float*       C; int64_t ldc, c_bs0, c_bs1;
+
+    /* prologue: stateless dropout mask on A.  The mask index of A's element (outer, inner) is
+       z*a_drop_bstride + outer*a_drop_ld + inner  (outer = the lda-strided index).          */
+    gt_dropout a_drop; float a_drop_sign; int64_t a_drop_ld, a_drop_bstride;
+
+    /* epilogue */
+    float alpha;
+    const float* bias;
+    int32_t rp; const float* rp_a; int64_t rp_lda, rp_a_bs0; const float* rp_b; int64_t rp_ldb;
+    float* pre; int64_t ldpre;                  /* batch strides = c_bs0/c_bs1 scaled by ldpre/ldc is NOT assumed: dense [batch][M][ldpre] */
+    int32_t act;
+    int32_t aux_op; const float* aux; int64_t ldaux, aux_bs0, aux_bs1; float aux_scale;
+    gt_dropout drop;                            /* mask index = (z*M + m)*N + n */
+    const float* res; int64_t ldr, r_bs0, r_bs1;
+    float out_scale;
+} gt_gemm_desc;
+
+void    gt_gemm_desc_init(gt_gemm_desc* d);            /* zero + alpha=1, out_scale=1, batch=1 */
+int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d);
+int     gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream);
+/* debugging/tests: which tile configuration and split the library picks */
+int     gt_gemm_plan(const gt_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* split);
+
+/* ---------------------------------------------------------------------------------------------
+ * out[n] (+)= sum_m A[m*lda + n] * keepA(m,n)  -- bias gradients.  Two deterministic passes.
+ * ------------------------------------------------------------------------------------------- */
+int gt_colsum(const float* A, int64_t lda, int32_t M, int32_t N, const gt_dropout* a_drop,
+              float a_sign, float* out, void* ws, int64_t ws_bytes, void* stream);
+/* dpre[i] = dout[i] * act'(pre[i])   (GT_ACT_*), n elements */
+int gt_act_bwd(const float* dout, const float* pre, float* dpre, int64_t n, int32_t act, void* stream);
+/* out[i] = alpha * sum_s slabs[s*stride + i], i < n */
+int gt_slab_reduce(const float* slabs, int64_t stride, int32_t n_slabs, int64_t n, float alpha,
+                   float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-head LayerNorm + position concat (layers.py:841-874).
+ *   qkv   [T, 3*d]   raw projections (T = B*n tokens), d = h*dk
+ *   pos   [T, p]     coordinates (p may be 0 -> pos may be NULL)
+ *   gamma/beta [2][h][dk]: affine of the two normalised streams, in stream order
+ *   norm_mask: bit s set => stream s (0=Q,1=K,2=V) is normalised (galerkin: K,V = 6; fourier:
+ *              Q,K = 3; no attn norm: 0)
+ *   out   [3][T][h][DP]  with DP = round_up(dk+p, 4); columns [0,p) = pos, [p,p+dk) = values,
+ *                        rest zero.  stats [2][T][h][2] = (mean, rstd) of the normalised streams.
+ * Backward: d_out -> d_qkv [T,3d], dgamma/dbeta [2][h][dk] (deterministic two-pass).
+ * ------------------------------------------------------------------------------------------- */
+int gt_headnorm_fwd(const float* qkv, const float* pos, const float* gamma, const float* beta,
+                    int32_t T, int32_t h, int32_t dk, int32_t p, int32_t norm_mask, float eps,
+                    float* out, float* stats, void* stream);
+int gt_headnorm_bwd(const float* d_out, const float* qkv, const float* gamma, const float* stats,
+                    int32_t T, int32_t h, int32_t dk, int32_t p, int32_t norm_mask,
+                    float* d_qkv, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
+                    void* stream);
+int64_t gt_headnorm_bwd_ws_bytes(int32_t T, int32_t h, int32_t dk);
+
+/* ---------------------------------------------------------------------------------------------
+ * Galerkin attention core, small-matrix stage (layers.py:723-733 + :897 folded):
+ *   Mt[b,h]   = mask .* ( sum_s slabs[s][b,h] ) / n          (DPxDP, the "attn_weight")
+ *   P[b][h*DP + j][c] = sum_e Mt[b,h][j][e] * Wfc[c][h*Dr + e]    (Dr = dk+p unpadded)
+ * so that   attn_out[b] = [Q'](n x h*DP) @ P[b]  is one GEMM.  mask: explicit tensor
+ * [B,h,DP,DP] of multipliers (replay mode), or NULL with drop.p (0.5 in the reference) for the
+ * stateless RNG, or both NULL/0 for identity.
+ * Backward: from dPt[b][c][h*DP+j] (= d attn_out^T Q') produce
+ *   dM[b,h]  = mask .* (dP_h Wfc_h) / n        and      dWfc slabs [B][d][h*Dr].
+ * ------------------------------------------------------------------------------------------- */
+int gt_galerkin_finalize_fwd(const float* slabs, int32_t n_slabs, int64_t slab_stride,
+                             int32_t B, int32_t h, int32_t DP, int32_t Dr, int32_t d, int32_t n_tokens,
+                             const float* mask, const gt_dropout* drop, const float* Wfc,
+                             float* Mt, float* P, void* stream);
+int gt_galerkin_finalize_bwd(const float* dPt, const float* Mt, const float* mask,
+                             const gt_dropout* drop, const float* Wfc,
+                             int32_t B, int32_t h, int32_t DP, int32_t Dr, int32_t d, int32_t n_tokens,
+                             float* dM, float* dWfc_slabs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row LayerNorm over the feature axis (model.py:128-129,134-135 when layer_norm=True).
+ * ------------------------------------------------------------------------------------------- */
+int gt_layernorm_fwd(const float* x, const float* gamma, const float* beta, int32_t T, int32_t d,
+                     float eps, float* y, float* stats /* [T][2] mean,rstd */, void* stream);
+int gt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats,
+                     int32_t T, int32_t d, float* dx, float* dgamma, float* dbeta,
+                     void* ws, int64_t ws_bytes, void* stream);
+int64_t gt_layernorm_bwd_ws_bytes(int32_t T, int32_t d);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spectral mode mixing (layers.py:1066-1075, 1143-1151): per retained mode q, complex
+ *   Y[b][ri][q][o] = sum_i X[b][ri'][q][i] (x) W[i][o][q]      (complex product, real-pair weights)
+ * X, Y layout: [B][2][Q][C] (re plane, im plane), Q = number of retained modes, C channels.
+ * W layout:    [Cin][Cout][Q][2]  (the reference's parameter layout; for 2-D the two corner
+ *              blocks are passed as two calls or as Q = modes*modes each via `w_qstride`).
+ * Backward: dX from dY and W ;  dW from X and dY (summed over the batch).
+ * ------------------------------------------------------------------------------------------- */
+int gt_modemix_fwd(const float* X, const float* W, int32_t B, int32_t Q, int32_t Cin, int32_t Cout,
+                   int64_t x_bstride, int64_t y_bstride, int32_t q_total_x, int32_t q_total_y,
+                   int32_t q_off, float* Y, void* stream);
+int gt_modemix_bwd(const float* X, const float* W, const float* dY, int32_t B, int32_t Q,
+                   int32_t Cin, int32_t Cout, int64_t x_bstride, int64_t y_bstride,
+                   int32_t q_total_x, int32_t q_total_y, int32_t q_off,
+                   float* dX, float* dW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GT_HIP_H */

@@ -1,0 +1,328 @@
+"""Kernel-level parity: every C-ABI entry point of libgt_hip.so against a plain torch fp64
+restatement of the same op, on the GPU box.  (-m gpu)"""
+import ctypes
+import math
+
+import pytest
+import torch
+
+from _util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+KTOL = 2e-6   # fp32 accumulation-order noise
+
+
+@pytest.fixture(scope="module")
+def H(gpu_device):
+    from galerkin_transformer import _hip
+    _hip.lib()
+    return _hip
+
+
+def rnd(*shape, dev, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def ref_mm(A, B, la, lb):
+    a = A.double() if la == 0 else A.double().transpose(-1, -2)      # -> [..., M, K]
+    b = B.double().transpose(-1, -2) if lb == 0 else B.double()      # -> [..., K, N]
+    return a @ b
+
+
+@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (130, 36, 150), (64, 128, 16), (141, 32, 24),
+                                   (200, 1, 128), (48, 384, 282), (1000, 256, 130), (33, 130, 7)])
+def test_gemm_layouts(H, gpu_device, la, lb, M, N, K):
+    dev = gpu_device
+    A = rnd(M, K, dev=dev, seed=1) if la == 0 else rnd(K, M, dev=dev, seed=1)
+    B = rnd(N, K, dev=dev, seed=2) if lb == 0 else rnd(K, N, dev=dev, seed=2)
+    Cc = torch.full((M, N), float("nan"), device=dev)
+    H.gemm(A, B, Cc, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1], ldb=B.shape[1], ldc=N)
+    torch.cuda.synchronize()
+    assert rel_l2(Cc, ref_mm(A, B, la, lb)) < KTOL
+
+
+def test_gemm_asymmetric_identity(H, gpu_device):
+    """A = I with an asymmetric B catches a transposed accumulator layout."""
+    dev = gpu_device
+    n = 96
+    A = torch.eye(n, device=dev)
+    B = (torch.arange(n * n, device=dev, dtype=torch.float32).reshape(n, n) % 97) / 7.0   # B[n][k]
+    Cc = torch.empty(n, n, device=dev)
+    H.gemm(A, B, Cc, n, n, n, lda=n, ldb=n, ldc=n)
+    torch.cuda.synchronize()
+    assert torch.equal(Cc, B.t().contiguous())
+
+
+@pytest.mark.parametrize("la,lb", [(0, 0), (1, 1)])
+def test_gemm_batched_strided(H, gpu_device, la, lb):
+    """Two-level batch (b, head) on strided head-interleaved operands, as used by K^T V / Q M."""
+    dev = gpu_device
+    Bn, h, n, DP = 3, 4, 257, 36
+    X = rnd(Bn, n, h, DP, dev=dev, seed=3)
+    Y = rnd(Bn, n, h, DP, dev=dev, seed=4)
+    if la == 1:      # M = X^T Y per (b,h): reduction over tokens
+        out = torch.empty(Bn, h, DP, DP, device=dev)
+        H.gemm(X, Y, out, DP, DP, n, layout_a=1, layout_b=1, lda=h * DP, ldb=h * DP, ldc=DP,
+               batch=(Bn, h), a_bs=(n * h * DP, DP), b_bs=(n * h * DP, DP), c_bs=(h * DP * DP, DP * DP),
+               split_k=0)
+        ref = torch.einsum("bnhd,bnhe->bhde", X.double(), Y.double())
+    else:            # out = X W^T per (b,h) with W [DP,DP]
+        W = rnd(Bn, h, DP, DP, dev=dev, seed=5)
+        out = torch.empty(Bn, n, h, DP, device=dev)
+        H.gemm(X, W, out, n, DP, DP, layout_a=0, layout_b=0, lda=h * DP, ldb=DP, ldc=h * DP,
+               batch=(Bn, h), a_bs=(n * h * DP, DP), b_bs=(h * DP * DP, DP * DP), c_bs=(n * h * DP, DP))
+        ref = torch.einsum("bnhd,bhed->bnhe", X.double(), W.double())
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < KTOL
+
+
+@pytest.mark.parametrize("split", [0, 3, 16])
+def test_gemm_split_k(H, gpu_device, split):
+    dev = gpu_device
+    M, N, K = 256, 128, 5000
+    A = rnd(K, M, dev=dev, seed=6)
+    B = rnd(K, N, dev=dev, seed=7)
+    Cc = torch.empty(M, N, device=dev)
+    H.gemm(A, B, Cc, M, N, K, layout_a=1, layout_b=1, lda=M, ldb=N, ldc=N, split_k=split, alpha=0.5)
+    torch.cuda.synchronize()
+    assert rel_l2(Cc, 0.5 * (A.double().t() @ B.double())) < KTOL
+
+
+def test_gemm_epilogue_bias_act_res(H, gpu_device):
+    dev = gpu_device
+    M, N, K = 333, 256, 128
+    A, W, b = rnd(M, K, dev=dev, seed=8), rnd(N, K, dev=dev, seed=9, scale=0.2), rnd(N, dev=dev, seed=10)
+    R = rnd(M, N, dev=dev, seed=11)
+    for act, fn in ((H.ACT_RELU, torch.relu), (H.ACT_SILU, torch.nn.functional.silu)):
+        Cc = torch.empty(M, N, device=dev)
+        pre = torch.empty(M, N, device=dev)
+        H.gemm(A, W, Cc, M, N, K, lda=K, ldb=K, ldc=N, bias=b, act=act, res=R, ldr=N, out_scale=-1.0,
+               pre=pre, ldpre=N, alpha=2.0)
+        torch.cuda.synchronize()
+        p64 = 2.0 * (A.double() @ W.double().t()) + b.double()
+        assert rel_l2(pre, p64) < KTOL
+        assert rel_l2(Cc, R.double() - fn(p64)) < KTOL
+
+
+def test_gemm_rank_update_and_unaligned_b(H, gpu_device):
+    """fc(cat[x, grid]) as x W[:, :K]^T + grid W[:, K:]^T (regressor fc, model.py:615-617)."""
+    dev = gpu_device
+    M, N, K, p = 500, 32, 128, 2
+    x, grid = rnd(M, K, dev=dev, seed=12), rnd(M, p, dev=dev, seed=13)
+    W, b = rnd(N, K + p, dev=dev, seed=14, scale=0.2), rnd(N, dev=dev, seed=15)
+    Cc = torch.empty(M, N, device=dev)
+    H.gemm(x, W, Cc, M, N, K, lda=K, ldb=K + p, ldc=N, bias=b, rp=p, rp_a=grid, rp_lda=p,
+           rp_b=W[:, K:], rp_ldb=K + p)
+    torch.cuda.synchronize()
+    ref = torch.cat([x, grid], -1).double() @ W.double().t() + b.double()
+    assert rel_l2(Cc, ref) < KTOL
+
+
+def test_gemm_aux_ops(H, gpu_device):
+    dev = gpu_device
+    M, N, K = 200, 96, 64
+    A, W = rnd(M, K, dev=dev, seed=16), rnd(N, K, dev=dev, seed=17)
+    aux = rnd(M, N, dev=dev, seed=18)
+    ref = A.double() @ W.double().t()
+    Cc = torch.empty(M, N, device=dev)
+    H.gemm(A, W, Cc, M, N, K, lda=K, ldb=K, ldc=N, aux_op=H.AUX_GT0, aux=aux, ldaux=N, aux_scale=1.25)
+    torch.cuda.synchronize()
+    assert rel_l2(Cc, ref * (aux.double() > 0) * 1.25) < KTOL
+    H.gemm(A, W, Cc, M, N, K, lda=K, ldb=K, ldc=N, aux_op=H.AUX_DSILU, aux=aux, ldaux=N)
+    torch.cuda.synchronize()
+    a = aux.double().requires_grad_(True)
+    ds, = torch.autograd.grad(torch.nn.functional.silu(a).sum(), a)
+    assert rel_l2(Cc, ref * ds) < KTOL
+    H.gemm(A, W, Cc, M, N, K, lda=K, ldb=K, ldc=N, aux_op=H.AUX_MUL, aux=aux, ldaux=N, aux_scale=2.0)
+    torch.cuda.synchronize()
+    assert rel_l2(Cc, ref * aux.double() * 2.0) < KTOL
+
+
+def test_dropout_consistency_and_rate(H, gpu_device):
+    """Epilogue dropout, A-prologue dropout and gt_dropout_apply draw the same mask per index."""
+    dev = gpu_device
+    H.set_seed(1234, dev)
+    M, N, K = 256, 128, 64
+    d = H.dropout_desc(0.3, salt=77, device=dev)
+    ones = torch.ones(M * N, device=dev)
+    mask = H.dropout_apply(ones, d).reshape(M, N)
+    torch.cuda.synchronize()
+    keep = (mask > 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01
+    assert torch.allclose(mask[mask > 0], torch.tensor(1 / 0.7, device=dev))
+    # epilogue
+    A, W = rnd(M, K, dev=dev, seed=19), rnd(N, K, dev=dev, seed=20)
+    Cc = torch.empty(M, N, device=dev)
+    H.gemm(A, W, Cc, M, N, K, lda=K, ldb=K, ldc=N, drop=d)
+    torch.cuda.synchronize()
+    assert rel_l2(Cc, (A.double() @ W.double().t()) * mask.double()) < KTOL
+    # prologue on A = G [M, N] (mask index space of the [M,N] tensor): C2 = (G*mask) @ W2^T
+    G, W2 = rnd(M, N, dev=dev, seed=21), rnd(48, N, dev=dev, seed=22)
+    C2 = torch.empty(M, 48, device=dev)
+    H.gemm(G, W2, C2, M, 48, N, lda=N, ldb=N, ldc=48, a_drop=d, a_drop_ld=N, a_drop_sign=-1.0)
+    torch.cuda.synchronize()
+    assert rel_l2(C2, -(G.double() * mask.double()) @ W2.double().t()) < KTOL
+    # transposed use: C3 = (G*mask)^T X   (weight-gradient form)
+    X = rnd(M, 40, dev=dev, seed=23)
+    C3 = torch.empty(N, 40, device=dev)
+    H.gemm(G, X, C3, N, 40, M, layout_a=1, layout_b=1, lda=N, ldb=40, ldc=40, a_drop=d, a_drop_ld=N)
+    torch.cuda.synchronize()
+    assert rel_l2(C3, (G.double() * mask.double()).t() @ X.double()) < KTOL
+    # colsum with the same mask
+    cs = H.colsum(G, M, N, N, a_drop=d)
+    torch.cuda.synchronize()
+    assert rel_l2(cs, (G.double() * mask.double()).sum(0)) < KTOL
+    # a different seed gives a different mask; advancing is deterministic
+    H.advance_seed(dev)
+    mask2 = H.dropout_apply(ones, d).reshape(M, N)
+    torch.cuda.synchronize()
+    assert (mask2 != mask).float().mean().item() > 0.2
+
+
+def _headnorm_ref(qkv, pos, gamma, beta, h, dk, p, norm_mask, eps):
+    T = qkv.shape[0]
+    DP = (dk + p + 3) // 4 * 4
+    s = qkv.reshape(T, 3, h, dk)
+    outs, ni = [], 0
+    for st in range(3):
+        v = s[:, st]
+        if (norm_mask >> st) & 1:
+            mu = v.mean(-1, keepdim=True)
+            var = ((v - mu) ** 2).mean(-1, keepdim=True)
+            v = (v - mu) / torch.sqrt(var + eps) * gamma[ni] + beta[ni]
+            ni += 1
+        parts = []
+        if p:
+            parts.append(pos[:, None, :].expand(T, h, p))
+        parts.append(v)
+        if DP - dk - p:
+            parts.append(torch.zeros(T, h, DP - dk - p, dtype=v.dtype, device=v.device))
+        outs.append(torch.cat(parts, -1))
+    return torch.stack(outs)
+
+
+@pytest.mark.parametrize("h,dk,p,mask", [(4, 32, 2, 6), (4, 16, 1, 3), (1, 96, 1, 6), (2, 48, 2, 6),
+                                         (1, 48, 2, 0)])
+def test_headnorm_fwd_bwd(H, gpu_device, h, dk, p, mask):
+    dev = gpu_device
+    T, eps = 1003, 1e-7
+    qkv = rnd(T, 3 * h * dk, dev=dev, seed=24)
+    pos = torch.rand(T, p, device=dev)
+    gamma = 1 + 0.1 * rnd(2, h, dk, dev=dev, seed=25)
+    beta = 0.1 * rnd(2, h, dk, dev=dev, seed=26)
+    out, stats = H.headnorm_fwd(qkv, pos, gamma, beta, T, h, dk, p, mask, eps)
+    q64 = qkv.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = _headnorm_ref(q64, pos.double(), g64, b64, h, dk, p, mask, eps)
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < KTOL
+    cot = rnd(*out.shape, dev=dev, seed=27)
+    dq, dg, db = H.headnorm_bwd(cot, qkv, gamma, stats, T, h, dk, p, mask)
+    torch.cuda.synchronize()
+    grads = torch.autograd.grad(ref, [q64, g64, b64], cot.double(), allow_unused=True)
+    assert rel_l2(dq, grads[0]) < 5 * KTOL
+    if mask:
+        nn_ = bin(mask).count("1")
+        assert rel_l2(dg[:nn_], grads[1][:nn_]) < 5 * KTOL
+        assert rel_l2(db[:nn_], grads[2][:nn_]) < 5 * KTOL
+
+
+@pytest.mark.parametrize("B,h,dk,p,d", [(2, 4, 32, 2, 128), (1, 1, 96, 1, 96), (3, 2, 48, 2, 96)])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_galerkin_finalize(H, gpu_device, B, h, dk, p, d, use_mask):
+    dev = gpu_device
+    Dr, n = dk + p, 777
+    DP = (Dr + 3) // 4 * 4
+    S = 3
+    slabs = rnd(S, B, h, DP, DP, dev=dev, seed=28)
+    Wfc = rnd(d, h * Dr, dev=dev, seed=29, scale=0.3)
+    mask = ((torch.rand(B, h, DP, DP, device=dev) > 0.5).float() * 2.0) if use_mask else None
+    Mt, P = H.galerkin_finalize_fwd(slabs, S, B * h * DP * DP, B, h, DP, Dr, d, n, mask, None, Wfc)
+    torch.cuda.synchronize()
+    s64 = slabs.double().requires_grad_(True)
+    w64 = Wfc.double().requires_grad_(True)
+    M64 = s64.sum(0)[..., :Dr, :Dr] / n
+    if use_mask:
+        M64 = M64 * mask.double()[..., :Dr, :Dr]
+    P64 = torch.einsum("bhje,che->bhjc", M64, w64.reshape(d, h, Dr))
+    assert rel_l2(Mt[..., :Dr, :Dr], M64) < KTOL
+    assert float(Mt[..., Dr:, :].abs().max()) == 0 and float(Mt[..., :, Dr:].abs().max()) == 0
+    Pv = P.reshape(B, h, DP, d)
+    assert rel_l2(Pv[:, :, :Dr], P64) < KTOL
+    assert float(Pv[:, :, Dr:].abs().max()) == 0 if DP > Dr else True
+    # backward: cotangent on P, given as dPt[b][c][h*DP + j]
+    cot = rnd(B, h, DP, d, dev=dev, seed=30)
+    dPt = cot.permute(0, 3, 1, 2).reshape(B, d, h * DP).contiguous()
+    dM, dWs = H.galerkin_finalize_bwd(dPt, Mt, mask, None, Wfc, B, h, DP, Dr, d, n)
+    torch.cuda.synchronize()
+    gs, gw = torch.autograd.grad(P64, [s64, w64], cot.double()[:, :, :Dr])
+    # dM is the gradient w.r.t. the un-normalised K'^T V' sum (every slab sees the same gradient)
+    assert rel_l2(dM[..., :Dr, :Dr], gs[0][..., :Dr, :Dr]) < 5 * KTOL
+    assert rel_l2(dWs.sum(0), gw) < 5 * KTOL
+
+
+def test_layernorm(H, gpu_device):
+    dev = gpu_device
+    for T, d in ((1000, 48), (517, 128), (64, 200)):
+        x = rnd(T, d, dev=dev, seed=31)
+        g, b = 1 + 0.1 * rnd(d, dev=dev, seed=32), 0.1 * rnd(d, dev=dev, seed=33)
+        y, st = H.layernorm_fwd(x, g, b, 1e-5)
+        x64, g64, b64 = (t.double().requires_grad_(True) for t in (x, g, b))
+        ref = torch.nn.functional.layer_norm(x64, (d,), g64, b64, 1e-5)
+        torch.cuda.synchronize()
+        assert rel_l2(y, ref) < KTOL
+        cot = rnd(T, d, dev=dev, seed=34)
+        dx, dg, db = H.layernorm_bwd(cot, x, g, st)
+        torch.cuda.synchronize()
+        gx, gg, gb = torch.autograd.grad(ref, [x64, g64, b64], cot.double())
+        assert rel_l2(dx, gx) < 5 * KTOL and rel_l2(dg, gg) < 5 * KTOL and rel_l2(db, gb) < 5 * KTOL
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Q,qtot,qoff", [(4, 32, 32, 144, 288, 144), (3, 8, 16, 16, 16, 0),
+                                                    (20, 20, 12, 36, 72, 0)])
+def test_modemix(H, gpu_device, B, Cin, Cout, Q, qtot, qoff):
+    dev = gpu_device
+    X = rnd(B, 2, qtot, Cin, dev=dev, seed=35)
+    W = rnd(Cin, Cout, Q, 2, dev=dev, seed=36, scale=0.3)
+    Y = torch.zeros(B, 2, qtot, Cout, device=dev)
+    H.modemix_fwd(X, W, Y, B, Q, Cin, Cout, qtot, qoff)
+    torch.cuda.synchronize()
+    x64 = X.double().requires_grad_(True)
+    w64 = W.double().requires_grad_(True)
+    xc = torch.complex(x64[:, 0, qoff:qoff + Q], x64[:, 1, qoff:qoff + Q])       # [B,Q,Cin]
+    wc = torch.complex(w64[..., 0], w64[..., 1])                                  # [Cin,Cout,Q]
+    yc = torch.einsum("bqi,ioq->bqo", xc, wc)
+    ref = torch.stack([yc.real, yc.imag], 1)
+    assert rel_l2(Y[:, :, qoff:qoff + Q], ref) < KTOL
+    cot = rnd(B, 2, qtot, Cout, dev=dev, seed=37)
+    dX = torch.zeros_like(X)
+    dW = torch.empty_like(W)
+    H.modemix_bwd(X, W, cot, dX, dW, B, Q, Cin, Cout, qtot, qoff)
+    torch.cuda.synchronize()
+    gx, gw = torch.autograd.grad(ref, [x64, w64], cot.double()[:, :, qoff:qoff + Q])
+    assert rel_l2(dX, gx) < 5 * KTOL
+    assert rel_l2(dW, gw) < 5 * KTOL
+
+
+def test_misc_reductions(H, gpu_device):
+    dev = gpu_device
+    A = rnd(5000, 130, dev=dev, seed=38)
+    cs = H.colsum(A, 5000, 130, 130)
+    torch.cuda.synchronize()
+    assert rel_l2(cs, A.double().sum(0)) < KTOL
+    pre, g = rnd(1000, 33, dev=dev, seed=39), rnd(1000, 33, dev=dev, seed=40)
+    out = H.act_bwd(g, pre, H.ACT_SILU)
+    p64 = pre.double().requires_grad_(True)
+    ref, = torch.autograd.grad(torch.nn.functional.silu(p64), p64, g.double())
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < KTOL
+
+
+def test_ops_refuse_cpu_tensors(H):
+    """No silent CPU fallback: the product path must fail loudly off-device."""
+    a = torch.zeros(4, 4)
+    with pytest.raises(RuntimeError):
+        H.gemm(a, a, a, 4, 4, 4, lda=4, ldb=4, ldc=4)
