@@ -27,6 +27,7 @@ struct GemmP {
     DropDev a_drop; int64_t a_drop_ld, a_drop_bstride;
     float alpha; const float* bias;
     int rp; const float* rp_a; int64_t rp_lda, rp_a_bs0; const float* rp_b; int64_t rp_ldb;
+    const float* add; int64_t ldadd, add_bs0, add_bs1;
     float* pre; int64_t ldpre;
     int act, aux_op; const float* aux; int64_t ldaux, aux_bs0, aux_bs1; float aux_scale;
     DropDev drop;
@@ -263,6 +264,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
                         if (nb + t < p.N) v[t] += aj * p.rp_b[(int64_t)(nb + t) * p.rp_ldb + j];
                 }
             }
+            if (p.add) {
+                const float* ad = p.add + b0 * p.add_bs0 + b1 * p.add_bs1 + (int64_t)m * p.ldadd + nb;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (nb + t < p.N) v[t] += ad[t];
+            }
             if (p.pre) {
                 float* pp = p.pre + ((int64_t)z * p.M + m) * p.ldpre + nb;
 #pragma unroll
@@ -355,7 +362,7 @@ static void launch_cfg(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
 struct Plan { int cfg, bm, bn, tiles_m, tiles_n, split, k_chunk; };
 
 static bool has_epilogue(const gt_gemm_desc* d) {
-    return d->bias || d->rp || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res ||
+    return d->bias || d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res ||
            d->out_scale != 1.f;
 }
 
@@ -470,6 +477,7 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
         p.rp = d->rp; p.rp_a = d->rp_a; p.rp_lda = d->rp_lda; p.rp_a_bs0 = d->rp_a_bs0;
         p.rp_b = d->rp_b; p.rp_ldb = d->rp_ldb;
         if (p.rp && (!p.rp_a || !p.rp_b)) return GT_EINVAL;
+        p.add = d->add; p.ldadd = d->ldadd; p.add_bs0 = d->add_bs0; p.add_bs1 = d->add_bs1;
         p.pre = d->pre; p.ldpre = d->ldpre;
         p.act = d->act; p.aux_op = d->aux_op; p.aux = d->aux; p.ldaux = d->ldaux;
         p.aux_bs0 = d->aux_bs0; p.aux_bs1 = d->aux_bs1; p.aux_scale = d->aux_scale;

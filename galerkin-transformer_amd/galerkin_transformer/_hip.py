@@ -37,6 +37,7 @@ class GtGemmDesc(C.Structure):
         ("alpha", C.c_float), ("bias", C.c_void_p),
         ("rp", C.c_int32), ("rp_a", C.c_void_p), ("rp_lda", C.c_int64), ("rp_a_bs0", C.c_int64),
         ("rp_b", C.c_void_p), ("rp_ldb", C.c_int64),
+        ("add", C.c_void_p), ("ldadd", C.c_int64), ("add_bs0", C.c_int64), ("add_bs1", C.c_int64),
         ("pre", C.c_void_p), ("ldpre", C.c_int64),
         ("act", C.c_int32), ("aux_op", C.c_int32), ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("aux_bs0", C.c_int64), ("aux_bs1", C.c_int64), ("aux_scale", C.c_float),
@@ -206,12 +207,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          a_drop_bstride: int = 0,
          rp: int = 0, rp_a: Optional[torch.Tensor] = None, rp_lda: int = 0, rp_a_bs0: int = 0,
          rp_b: Optional[torch.Tensor] = None, rp_ldb: int = 0,
+         add: Optional[torch.Tensor] = None, ldadd: int = 0, add_bs=(0, 0),
          pre: Optional[torch.Tensor] = None, ldpre: int = 0,
          aux_op: int = AUX_NONE, aux: Optional[torch.Tensor] = None, ldaux: int = 0, aux_bs=(0, 0),
          aux_scale: float = 1.0, drop: Optional[GtDropout] = None,
          res: Optional[torch.Tensor] = None, ldr: int = 0, r_bs=(0, 0), out_scale: float = 1.0):
     """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics)."""
-    need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, pre, aux, res)
+    need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res)
     L = lib()
     d = GtGemmDesc()
     L.gt_gemm_desc_init(C.byref(d))
@@ -231,6 +233,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if rp:
         d.rp, d.rp_a, d.rp_lda, d.rp_a_bs0 = rp, rp_a.data_ptr(), rp_lda, rp_a_bs0
         d.rp_b, d.rp_ldb = rp_b.data_ptr(), rp_ldb
+    if add is not None:
+        d.add, d.ldadd, d.add_bs0, d.add_bs1 = add.data_ptr(), ldadd, add_bs[0], add_bs[1]
     if pre is not None:
         d.pre, d.ldpre = pre.data_ptr(), ldpre
     d.act = act

@@ -1,0 +1,388 @@
+"""Layer modules with the reference's names, constructor arguments, forward signatures and
+state_dict keys (reference: libs/layers.py), whose hot-path arithmetic runs in libgt_hip.so.
+
+Hot path (HIP):  SimpleAttention (:764), FeedForward (:954), SpectralConv1d (:1040),
+SpectralConv2d (:1109).  Not on the hot path (plain PyTorch-ROCm / MIOpen, as SURVEY.md section 8
+scopes them): the conv + bilinear-interpolation scalers (:88-150, :431-512, :624-670).
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, xavier_normal_, xavier_uniform_
+from torch.nn.parameter import Parameter
+
+from . import ops, spectral
+from .ops import get_attention_dropout, push_attention_masks, set_attention_dropout  # noqa: F401
+
+
+def default(value, d):
+    return d if value is None else value
+
+
+_LINEAR_FAMILY = ("linear", "galerkin", "global")
+_HIP_ATTENTION = ("galerkin", "fourier", "integral", "local")
+
+
+def _act_module(name, fallback="silu"):
+    return nn.SiLU() if default(name, fallback) == "silu" else nn.ReLU()
+
+
+def _act_name(module) -> str:
+    if isinstance(module, nn.SiLU):
+        return "silu"
+    if isinstance(module, nn.ReLU):
+        return "relu"
+    if isinstance(module, (nn.Identity, Identity)):
+        return "none"
+    raise NotImplementedError(f"activation {type(module).__name__} has no HIP path")
+
+
+# --------------------------------------------------------------------------------------- small helpers
+class Identity(nn.Module):
+    """Pass-through, or a Linear when both feature sizes are given (layers.py:21-41)."""
+
+    def __init__(self, in_features=None, out_features=None, *args, **kwargs):
+        super().__init__()
+        if in_features is not None and out_features is not None:
+            self.id = nn.Linear(in_features, out_features)
+        else:
+            self.id = nn.Identity()
+
+    def forward(self, x, edge=None, grid=None):
+        if isinstance(self.id, nn.Linear):
+            return ops.linear(x, self.id.weight, self.id.bias)
+        return x
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoidal table added to (B, n, d) inputs (layers.py:60-85); unused by the shipped configs."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=2 ** 13):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout)
+        position = torch.arange(max_len, dtype=torch.float).unsqueeze(1)
+        freq = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(2 ** 13) / d_model))
+        pe = torch.zeros(max_len, d_model)
+        pe[:, 0::2] = torch.sin(position * freq)
+        pe[:, 1::2] = torch.cos(position * freq)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def forward(self, x):
+        return self.dropout(x + self.pe[:, :x.size(1), :])
+
+
+# --------------------------------------------------------------------------------------- CNN scalers (torch/MIOpen)
+class Conv2dResBlock(nn.Module):
+    """conv (no bias) -> dropout [-> act -> conv -> dropout] -> (+ shortcut) -> act (layers.py:88-150)."""
+
+    def __init__(self, in_dim, out_dim, kernel_size=3, padding=1, dilation=1, dropout=0.1, stride=1,
+                 bias=False, residual=False, basic_block=False, activation_type="silu"):
+        super().__init__()
+        self.activation = _act_module(activation_type)
+        self.add_res = residual
+        self.conv = nn.Sequential(
+            nn.Conv2d(in_dim, out_dim, kernel_size=kernel_size, padding=padding, dilation=dilation,
+                      stride=stride, bias=bias),
+            nn.Dropout(dropout))
+        self.basic_block = basic_block
+        if basic_block:
+            self.conv1 = nn.Sequential(
+                self.activation,
+                nn.Conv2d(out_dim, out_dim, kernel_size=kernel_size, padding=padding, bias=bias),
+                nn.Dropout(dropout))
+        self.apply_shortcut = in_dim != out_dim
+        if residual:
+            self.res = _Shortcut2d(in_dim, out_dim) if self.apply_shortcut else Identity()
+
+    def forward(self, x):
+        h = self.res(x) if self.add_res else None
+        x = self.conv(x)
+        if self.basic_block:
+            x = self.conv1(x)
+        return self.activation(x + h) if self.add_res else self.activation(x)
+
+
+class _Shortcut2d(nn.Module):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.shortcut = nn.Linear(in_features, out_features)
+
+    def forward(self, x, edge=None, grid=None):
+        return self.shortcut(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+
+
+Shortcut2d = _Shortcut2d
+
+
+def _resize(x, size):
+    if isinstance(size, float):
+        return F.interpolate(x, scale_factor=size, mode="bilinear", recompute_scale_factor=True,
+                             align_corners=True)
+    return F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=True)
+
+
+class Interp2dEncoder(nn.Module):
+    """conv0 -> resize -> act -> conv1 -> conv2 -> conv3 -> cat -> resize -> act (layers.py:431-512)."""
+
+    def __init__(self, in_dim, out_dim, kernel_size=3, stride=1, padding=1, dilation=1, interp_size=None,
+                 residual=False, activation_type="silu", dropout=0.1, debug=False):
+        super().__init__()
+        c0 = out_dim // 3
+        c1 = out_dim // 3
+        c2 = int(out_dim - c0 - c1)
+        pad1 = max(padding // 2, 1)
+        pad2 = max(padding // 4, 1)
+        activation_type = default(activation_type, "silu")
+        self.interp_size = interp_size
+        self.is_scale_factor = isinstance(interp_size[0], float) and isinstance(interp_size[1], float)
+        common = dict(kernel_size=kernel_size, residual=residual, dropout=dropout,
+                      activation_type=activation_type)
+        self.conv0 = Conv2dResBlock(in_dim, out_dim, padding=padding, **common)
+        self.conv1 = Conv2dResBlock(out_dim, c0, padding=pad1, stride=stride, **common)
+        self.conv2 = Conv2dResBlock(c0, c1, dilation=dilation, padding=pad2, **common)
+        self.conv3 = Conv2dResBlock(c1, c2, **common)
+        self.activation = _act_module(activation_type)
+        self.add_res = residual
+        self.debug = debug
+
+    def forward(self, x):
+        x = self.activation(_resize(self.conv0(x), self.interp_size[0]))
+        x1 = self.conv1(x)
+        x2 = self.conv2(x1)
+        x3 = self.conv3(x2)
+        out = torch.cat([x1, x2, x3], dim=1)
+        if self.add_res:
+            out = out + x
+        return self.activation(_resize(out, self.interp_size[1]))
+
+
+class Interp2dUpsample(nn.Module):
+    """resize -> conv block -> dropout -> act -> resize (layers.py:624-670)."""
+
+    def __init__(self, in_dim, out_dim, kernel_size=3, padding=1, residual=False, conv_block=True,
+                 interp_mode="bilinear", interp_size=None, activation_type="silu", dropout=0.1, debug=False):
+        super().__init__()
+        self.activation = _act_module(activation_type)
+        self.dropout = nn.Dropout(dropout)
+        if conv_block:
+            self.conv = nn.Sequential(
+                Conv2dResBlock(in_dim, out_dim, kernel_size=kernel_size, padding=padding, residual=residual,
+                               dropout=dropout, activation_type=default(activation_type, "silu")),
+                self.dropout, self.activation)
+        self.conv_block = conv_block
+        self.interp_size = interp_size
+        self.interp_mode = interp_mode
+        self.debug = debug
+
+    def forward(self, x):
+        x = F.interpolate(x, size=tuple(self.interp_size[0]), mode=self.interp_mode, align_corners=True)
+        if self.conv_block:
+            x = self.conv(x)
+        return F.interpolate(x, size=tuple(self.interp_size[1]), mode=self.interp_mode, align_corners=True)
+
+
+# --------------------------------------------------------------------------------------- attention (HIP)
+class SimpleAttention(nn.Module):
+    """Softmax-free attention with per-head LayerNorm and coordinate concatenation.
+
+    Same parameters / state_dict keys as the reference (layers.py:793-828): ``linears.{0,1,2}``,
+    ``norm_K.{i}``, ``norm_V.{i}`` (galerkin) or ``norm_Q.{i}`` (fourier), ``fc``.  The HIP path covers
+    self-attention (query is key is value) of the 'galerkin' and 'fourier' ('integral', 'local') types
+    with norm_type='layer'; other variants of the reference are baselines outside the hot path."""
+
+    def __init__(self, n_head, d_model, pos_dim: int = 1, attention_type="fourier", dropout=0.1,
+                 xavier_init=1e-4, diagonal_weight=1e-2, symmetric_init=False, norm=False,
+                 norm_type="layer", eps=1e-5, debug=False):
+        super().__init__()
+        assert d_model % n_head == 0
+        self.attention_type = attention_type
+        self.d_k = d_model // n_head
+        self.n_head = n_head
+        self.pos_dim = pos_dim
+        self.linears = nn.ModuleList([nn.Linear(d_model, d_model) for _ in range(3)])
+        self.xavier_init = xavier_init
+        self.diagonal_weight = diagonal_weight
+        self.symmetric_init = symmetric_init
+        if self.xavier_init > 0:
+            self._reset_parameters()
+        self.add_norm = norm
+        self.norm_type = norm_type
+        self.eps = eps
+        if norm:
+            self._get_norm(eps=eps)
+        if pos_dim > 0:
+            self.fc = nn.Linear(d_model + n_head * pos_dim, d_model)
+        self.attn_weight = None
+        self.dropout = nn.Dropout(dropout)
+        self.debug = debug
+
+    # -- init contract of the reference (layers.py:901-913)
+    def _reset_parameters(self):
+        for param in self.linears.parameters():
+            if param.ndim > 1:
+                xavier_uniform_(param, gain=self.xavier_init)
+                if self.diagonal_weight > 0.0:
+                    param.data += self.diagonal_weight * torch.eye(param.size(-1), dtype=torch.float)
+                if self.symmetric_init:
+                    param.data += param.data.T
+            else:
+                constant_(param, 0)
+
+    def _get_norm(self, eps):
+        if self.norm_type != "layer":
+            raise NotImplementedError("only norm_type='layer' has a HIP path (the reference's 'instance' "
+                                      "branch is unused by its configs)")
+        mk = lambda: nn.ModuleList([nn.LayerNorm(self.d_k, eps=eps) for _ in range(self.n_head)])
+        self.norm_K = mk()
+        if self.attention_type in _LINEAR_FAMILY:
+            self.norm_V = mk()
+        else:
+            self.norm_Q = mk()
+
+    def _packed(self):
+        wqkv = torch.cat([l.weight for l in self.linears], dim=0)
+        bqkv = torch.cat([l.bias for l in self.linears], dim=0)
+        gamma = beta = None
+        mask = 0
+        if self.add_norm:
+            if self.attention_type in _LINEAR_FAMILY:
+                first, second, mask = self.norm_K, self.norm_V, 0b110
+            else:
+                first, second, mask = self.norm_Q, self.norm_K, 0b011
+            gamma = torch.stack([m.weight for m in first] + [m.weight for m in second])
+            beta = torch.stack([m.bias for m in first] + [m.bias for m in second])
+            gamma = gamma.view(2, self.n_head, self.d_k)
+            beta = beta.view(2, self.n_head, self.d_k)
+        return wqkv, bqkv, gamma, beta, mask
+
+    def fused_forward(self, x, pos=None, residual=None, sign=1.0, p_out=0.0):
+        """res + sign*dropout(attention(x)); the encoder layer's entry point."""
+        if self.attention_type not in _HIP_ATTENTION:
+            raise NotImplementedError(f"attention_type={self.attention_type!r} is outside the HIP hot path "
+                                      "(galerkin / fourier only)")
+        use_pos = pos is not None and self.pos_dim > 0
+        if use_pos:
+            assert pos.size(-1) == self.pos_dim
+        else:
+            raise NotImplementedError("the HIP path folds fc into the attention product and needs pos "
+                                      "(every reference config passes it)")
+        wqkv, bqkv, gamma, beta, mask = self._packed()
+        kind = "galerkin" if self.attention_type == "galerkin" else "fourier"
+        out, w = ops.simple_attention(x, pos, wqkv, bqkv, gamma, beta, self.fc.weight, self.fc.bias,
+                                      kind=kind, n_head=self.n_head, norm_mask=mask, eps=self.eps,
+                                      res=residual, sign=sign, p_out=p_out)
+        self.attn_weight = w
+        return out, w
+
+    def forward(self, query, key, value, pos=None, mask=None, weight=None):
+        if mask is not None:
+            if self.attention_type in _LINEAR_FAMILY:
+                raise RuntimeError("linear attention does not support casual mask.")
+            raise NotImplementedError("attention masks are outside the HIP hot path")
+        if weight is not None:
+            raise NotImplementedError("weighted attention is outside the HIP hot path")
+        if not (query is key and key is value):
+            raise NotImplementedError("the HIP path implements self-attention (query is key is value)")
+        return self.fused_forward(query, pos)
+
+
+class FeedForward(nn.Module):
+    """lr1 -> act -> dropout -> lr2 (layers.py:954-987); one fused HIP operator."""
+
+    def __init__(self, in_dim=256, dim_feedforward: int = 1024, out_dim=None, batch_norm=False,
+                 activation="relu", dropout=0.1):
+        super().__init__()
+        out_dim = default(out_dim, in_dim)
+        self.lr1 = nn.Linear(in_dim, dim_feedforward)
+        if activation == "silu":
+            self.activation = nn.SiLU()
+        elif activation == "gelu":
+            self.activation = nn.GELU()
+        else:
+            self.activation = nn.ReLU()
+        self.batch_norm = batch_norm
+        if batch_norm:
+            self.bn = nn.BatchNorm1d(dim_feedforward)
+        self.lr2 = nn.Linear(dim_feedforward, out_dim)
+        self.dropout = nn.Dropout(dropout)
+
+    def fused_forward(self, x, residual=None, p_out=0.0):
+        if self.batch_norm:
+            raise NotImplementedError("batch_norm=True is outside the HIP hot path (False in every config)")
+        p_h = self.dropout.p if self.training else 0.0
+        return ops.feed_forward(x, self.lr1.weight, self.lr1.bias, self.lr2.weight, self.lr2.bias,
+                                res=residual, act=_act_name(self.activation), p_h=p_h, p_out=p_out)
+
+    def forward(self, x):
+        return self.fused_forward(x)
+
+
+# --------------------------------------------------------------------------------------- spectral convs (HIP)
+class SpectralConv1d(nn.Module):
+    def __init__(self, in_dim, out_dim, modes: int, n_grid=None, dropout=0.1, return_freq=False,
+                 activation="silu", debug=False):
+        super().__init__()
+        self.linear = nn.Linear(in_dim, out_dim)
+        self.modes = modes
+        self.activation = _act_module(activation)
+        self.n_grid = n_grid
+        self.fourier_weight = Parameter(torch.empty(in_dim, out_dim, modes, 2))
+        xavier_normal_(self.fourier_weight, gain=1 / (in_dim * out_dim))
+        self.dropout = nn.Dropout(dropout)
+        self.return_freq = return_freq
+        self.debug = debug
+
+    def forward(self, x):
+        if self.return_freq:
+            raise NotImplementedError("return_freq is outside the HIP hot path")
+        if self.training and self.dropout.p > 0:
+            x = self.dropout(x)          # decoder_dropout is 0 in every shipped config
+        return spectral.spectral_conv1d(x, self.linear.weight, self.linear.bias, self.fourier_weight,
+                                        self.modes, _act_name(self.activation))
+
+
+class SpectralConv2d(nn.Module):
+    def __init__(self, in_dim, out_dim, modes: int, n_grid=None, dropout=0.1, norm="ortho",
+                 activation="silu", return_freq=False, debug=False):
+        super().__init__()
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.linear = nn.Linear(in_dim, out_dim)
+        self.modes = modes
+        self.activation = _act_module(activation)
+        self.n_grid = n_grid
+        self.fourier_weight = nn.ParameterList(
+            [Parameter(torch.empty(in_dim, out_dim, modes, modes, 2)) for _ in range(2)])
+        for param in self.fourier_weight:
+            xavier_normal_(param, gain=1 / (in_dim * out_dim) * np.sqrt(in_dim + out_dim))
+        self.dropout = nn.Dropout(dropout)
+        self.norm = norm
+        self.return_freq = return_freq
+        self.debug = debug
+
+    def forward(self, x):
+        if x.ndim == 4:
+            n = x.size(1)
+            assert x.size(1) == x.size(2)
+        elif x.ndim == 3:
+            n = int(x.size(1) ** 0.5)
+        else:
+            raise ValueError("Dimension not implemented")
+        if self.return_freq:
+            raise NotImplementedError("return_freq is outside the HIP hot path")
+        if self.norm != "ortho":
+            raise NotImplementedError("only norm='ortho' (the reference default) has a HIP path")
+        B, flat = x.size(0), x.ndim == 3
+        h = x.reshape(B, n, n, self.in_dim)
+        if self.training and self.dropout.p > 0:
+            # NB the reference drops the FFT branch input only (layers.py:1173); p is 0 in every config
+            raise NotImplementedError("decoder dropout > 0 inside SpectralConv2d has no HIP path")
+        y = spectral.spectral_conv2d(h, self.linear.weight, self.linear.bias, self.fourier_weight[0],
+                                     self.fourier_weight[1], self.modes, _act_name(self.activation))
+        return y.reshape(B, n * n, self.out_dim) if flat else y

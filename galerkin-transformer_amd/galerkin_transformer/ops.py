@@ -1,0 +1,375 @@
+"""Autograd operators of the hot path, built on the C ABI (``_hip``).
+
+Each ``torch.autograd.Function`` here enqueues hand-written HIP kernels for forward and
+backward; torch only owns the tensors and the autograd graph.  Reference call sites
+(under /root/reference/libs) are cited per operator.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import _hip as H
+
+# ----------------------------------------------------------------------------------- dropout bookkeeping
+# The reference applies F.dropout(p_attn) with the *default* p=0.5, training=True to the attention
+# matrix in train and eval alike (layers.py:700-701, 730-731).  Modes:
+#   "reference": stateless-RNG Bernoulli(0.5) mask, x2 rescale (default, reference-faithful)
+#   "off"      : identity (exact-math parity runs)
+#   "replay"   : multiply by explicit masks queued with push_attention_masks() (mask-replay parity)
+_attn_mode = "reference"
+_attn_masks = []
+_salt = [1]
+
+
+def set_attention_dropout(mode: str):
+    global _attn_mode
+    if mode not in ("reference", "off", "replay"):
+        raise ValueError(mode)
+    _attn_mode = mode
+    _attn_masks.clear()
+
+
+def get_attention_dropout() -> str:
+    return _attn_mode
+
+
+def push_attention_masks(masks):
+    """Queue explicit multiplicative masks (values 0 or 2), consumed one per attention call."""
+    _attn_masks.extend(masks)
+
+
+def _next_salt(k: int = 4) -> int:
+    s = _salt[0]
+    _salt[0] = (s + k) & 0x7FFFFFFF
+    return s
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------- Linear
+class LinearFn(Function):
+    """y = res + out_scale * dropout(act(x W^T + b + extra W_e^T)).
+
+    ``extra`` (optional, [.., p] with small p) folds ``torch.cat([x, extra], -1)`` followed by a Linear
+    over the concatenation into one GEMM + rank-p epilogue (model.py:615-617, 507-512); W then has
+    in_features = K + p.  Replaces nn.Linear (+ activation + nn.Dropout) at layers.py:964-987,
+    model.py:615-629.  Returns y (and keeps the pre-activation for SiLU backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, extra, act: int, p_drop: float):
+        H.need_f32_cuda(x, weight, bias, extra)
+        K = x.shape[-1]
+        N = weight.shape[0]
+        pe = 0 if extra is None else extra.shape[-1]
+        assert weight.shape[1] == K + pe
+        x2 = _c(x).reshape(-1, K)
+        T = x2.shape[0]
+        w = _c(weight)
+        y = torch.empty(T, N, dtype=torch.float32, device=x.device)
+        pre = torch.empty(T, N, dtype=torch.float32, device=x.device) if act == H.ACT_SILU else None
+        e2 = None if extra is None else _c(extra).reshape(T, pe)
+        salt = _next_salt()
+        drop = H.dropout_desc(p_drop, salt, x.device) if p_drop > 0 else None
+        H.gemm(x2, w, y, T, N, K, lda=K, ldb=K + pe, ldc=N, bias=bias, act=act,
+               rp=pe, rp_a=e2, rp_lda=pe, rp_b=(w[:, K:] if pe else None), rp_ldb=K + pe,
+               pre=pre, ldpre=N, drop=drop)
+        ctx.save_for_backward(x2, w, e2, pre if act == H.ACT_SILU else (y if act == H.ACT_RELU else None))
+        ctx.cfg = (act, p_drop, salt, K, N, pe, bias is not None, x.shape)
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, e2, saved = ctx.saved_tensors
+        act, p_drop, salt, K, N, pe, has_bias, xshape = ctx.cfg
+        dev = gy.device
+        T = x2.shape[0]
+        g = _c(gy).reshape(T, N)
+        # dpre = g * dropmask * act'(pre)
+        if act == H.ACT_NONE and p_drop == 0:
+            gp = g
+        else:
+            gp = torch.empty_like(g)
+            if act == H.ACT_SILU:
+                gp = H.act_bwd(g, saved, H.ACT_SILU)
+                if p_drop > 0:
+                    gp = H.dropout_apply(gp, H.dropout_desc(p_drop, salt, dev))
+            elif act == H.ACT_RELU:
+                # y = relu(pre)*mask*s : y>0 <=> kept and pre>0
+                gp = H.act_bwd(g, saved, H.ACT_RELU)
+                if p_drop > 0:
+                    gp = gp * (1.0 / (1.0 - p_drop))
+            else:
+                gp = H.dropout_apply(g, H.dropout_desc(p_drop, salt, dev))
+        dx = de = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(T, K, dtype=torch.float32, device=dev)
+            H.gemm(gp, w, dx, T, K, N, layout_b=1, lda=N, ldb=K + pe, ldc=K)
+            dx = dx.reshape(xshape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(N, K + pe, dtype=torch.float32, device=dev)
+            H.gemm(gp, x2, dw, N, K, T, layout_a=1, layout_b=1, lda=N, ldb=K, ldc=K + pe, split_k=0)
+            if pe:
+                H.gemm(gp, e2, dw[:, K:], N, pe, T, layout_a=1, layout_b=1, lda=N, ldb=pe, ldc=K + pe,
+                       split_k=0)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = H.colsum(gp, T, N, N)
+        return dx, dw, db, de, None, None
+
+
+def linear(x, weight, bias=None, extra=None, act: str = None, p_drop: float = 0.0):
+    return LinearFn.apply(x, weight, bias, extra, H.ACT_CODE[act], float(p_drop))
+
+
+# ----------------------------------------------------------------------------------- row LayerNorm
+class LayerNormFn(Function):
+    """nn.LayerNorm(d_model) of the encoder layer (model.py:84-85, 128-135)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float):
+        xc = _c(x)
+        y, stats = H.layernorm_fwd(xc, _c(weight), _c(bias), eps)
+        ctx.save_for_backward(xc, weight, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, weight, stats = ctx.saved_tensors
+        dx, dg, db = H.layernorm_bwd(_c(gy), xc, _c(weight), stats)
+        return dx, dg, db, None
+
+
+def layer_norm(x, weight, bias, eps):
+    return LayerNormFn.apply(x, weight, bias, float(eps))
+
+
+# ----------------------------------------------------------------------------------- FFN
+class FeedForwardFn(Function):
+    """out = res + dropout2(lr2(dropout_h(act(lr1(x)))))   (layers.py:979-987 + model.py:131-132).
+
+    res=None gives the bare FeedForward.forward."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res, act: int, p_h: float, p_out: float):
+        H.need_f32_cuda(x, w1, b1, w2, b2, res)
+        if act not in (H.ACT_RELU, H.ACT_SILU):
+            raise NotImplementedError("FeedForward HIP path implements relu and silu")
+        d, f, dout = x.shape[-1], w1.shape[0], w2.shape[0]
+        xc = _c(x).reshape(-1, d)
+        T = xc.shape[0]
+        dev = x.device
+        w1c, w2c = _c(w1), _c(w2)
+        salt = _next_salt()
+        hid = torch.empty(T, f, dtype=torch.float32, device=dev)
+        pre = torch.empty(T, f, dtype=torch.float32, device=dev) if act == H.ACT_SILU else None
+        H.gemm(xc, w1c, hid, T, f, d, lda=d, ldb=d, ldc=f, bias=b1, act=act, pre=pre, ldpre=f,
+               drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None)
+        out = torch.empty(T, dout, dtype=torch.float32, device=dev)
+        rc = None if res is None else _c(res).reshape(T, dout)
+        H.gemm(hid, w2c, out, T, dout, f, lda=f, ldb=f, ldc=dout, bias=b2,
+               drop=H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None, res=rc, ldr=dout)
+        ctx.save_for_backward(xc, w1c, w2c, hid, pre)
+        ctx.cfg = (act, p_h, p_out, salt, d, f, dout, b1 is not None, b2 is not None, res is not None,
+                   x.shape)
+        return out.reshape(*x.shape[:-1], dout)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, w1c, w2c, hid, pre = ctx.saved_tensors
+        act, p_h, p_out, salt, d, f, dout, hb1, hb2, has_res, xshape = ctx.cfg
+        dev = gy.device
+        T = xc.shape[0]
+        g = _c(gy).reshape(T, dout)
+        dro = H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None
+        # gh = ((g*mask_out) W2) * mask_h * act'(pre)
+        gh = torch.empty(T, f, dtype=torch.float32, device=dev)
+        if act == H.ACT_RELU:
+            H.gemm(g, w2c, gh, T, f, dout, layout_b=1, lda=dout, ldb=f, ldc=f, a_drop=dro, a_drop_ld=dout,
+                   aux_op=H.AUX_GT0, aux=hid, ldaux=f, aux_scale=1.0 / (1.0 - p_h))
+        else:
+            H.gemm(g, w2c, gh, T, f, dout, layout_b=1, lda=dout, ldb=f, ldc=f, a_drop=dro, a_drop_ld=dout,
+                   aux_op=H.AUX_DSILU, aux=pre, ldaux=f,
+                   drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None)
+        dw2 = torch.empty(dout, f, dtype=torch.float32, device=dev)
+        H.gemm(g, hid, dw2, dout, f, T, layout_a=1, layout_b=1, lda=dout, ldb=f, ldc=f, split_k=0,
+               a_drop=dro, a_drop_ld=dout)
+        db2 = H.colsum(g, T, dout, dout, a_drop=dro) if hb2 else None
+        dw1 = torch.empty(f, d, dtype=torch.float32, device=dev)
+        H.gemm(gh, xc, dw1, f, d, T, layout_a=1, layout_b=1, lda=f, ldb=d, ldc=d, split_k=0)
+        db1 = H.colsum(gh, T, f, f) if hb1 else None
+        dx = torch.empty(T, d, dtype=torch.float32, device=dev)
+        same = has_res and dout == d
+        H.gemm(gh, w1c, dx, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=g if same else None, ldr=d)
+        dx = dx.reshape(xshape)
+        dres = None
+        if has_res:
+            # the residual input is normally x itself: its gradient g is folded into dx above
+            dres = torch.zeros_like(gy) if same else gy
+        return dx, dw1, db1, dw2, db2, dres, None, None, None
+
+
+def feed_forward(x, w1, b1, w2, b2, res=None, act="relu", p_h=0.0, p_out=0.0):
+    """res must be x itself (or None): the fused backward folds d(res) into d(x)."""
+    return FeedForwardFn.apply(x, w1, b1, w2, b2, res, H.ACT_CODE[act], float(p_h), float(p_out))
+
+
+# ----------------------------------------------------------------------------------- attention
+class SimpleAttentionFn(Function):
+    """out = res + sign * dropout1( fc( merge_heads( attention(Q', K', V') ) ) ).
+
+    galerkin: per-head LN on K,V; M = mask .* (K'^T V')/n; heads: Q' M      (layers.py:708-734)
+    fourier : per-head LN on Q,K; S = mask .* (Q' K'^T)/sqrt(d_k')/n; heads: S V' (layers.py:672-705)
+    with X' = [pos, X] per head (layers.py:869-874) and fc over the merged heads (layers.py:894-897).
+    Also returns the attention matrix (``attn_weight``), detached."""
+
+    @staticmethod
+    def forward(ctx, x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, res, cfg, mask):
+        (kind, h, norm_mask, eps, sign, p_attn, p_out) = cfg
+        H.need_f32_cuda(x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, res, mask)
+        B, n, d = x.shape
+        dk = d // h
+        p = 0 if pos is None else pos.shape[-1]
+        Dr, DP = dk + p, H.round4(dk + p)
+        T = B * n
+        dev = x.device
+        xc = _c(x).reshape(T, d)
+        posc = None if pos is None else _c(pos).reshape(T, p)
+        wq, wf = _c(wqkv), _c(wfc)
+        salt = _next_salt(4)
+        qkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
+        H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
+        out3, stats = H.headnorm_fwd(qkv, posc, gamma, beta, T, h, dk, p, norm_mask, eps)
+        Qp, Kp, Vp = out3[0], out3[1], out3[2]
+        hD = h * DP
+        out = torch.empty(T, d, dtype=torch.float32, device=dev)
+        rc = None if res is None else _c(res).reshape(T, d)
+        d_attn = H.dropout_desc(p_attn, salt, dev) if (p_attn > 0 and mask is None) else None
+        d_out = H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None
+        if kind == "galerkin":
+            mraw = torch.empty(B, h, DP, DP, dtype=torch.float32, device=dev)
+            H.gemm(Kp, Vp, mraw, DP, DP, n, layout_a=1, layout_b=1, lda=hD, ldb=hD, ldc=DP, batch=(B, h),
+                   a_bs=(n * hD, DP), b_bs=(n * hD, DP), c_bs=(h * DP * DP, DP * DP), split_k=0)
+            Mt, P = H.galerkin_finalize_fwd(mraw, 1, B * h * DP * DP, B, h, DP, Dr, d, n, mask, d_attn, wf)
+            H.gemm(Qp, P, out, n, d, hD, layout_b=1, lda=hD, ldb=d, ldc=d, batch=(B, 1), a_bs=(n * hD, 0),
+                   b_bs=(hD * d, 0), c_bs=(n * d, 0), bias=bfc, drop=d_out, res=rc, ldr=d, r_bs=(n * d, 0),
+                   out_scale=sign)
+            ctx.save_for_backward(xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask)
+            attn_w = Mt[:, :, :Dr, :Dr]
+        else:
+            scale = 1.0 / math.sqrt(Dr) / n
+            S = torch.empty(B, h, n, n, dtype=torch.float32, device=dev)
+            H.gemm(Qp, Kp, S, n, n, DP, lda=hD, ldb=hD, ldc=n, batch=(B, h), a_bs=(n * hD, DP),
+                   b_bs=(n * hD, DP), c_bs=(h * n * n, n * n), alpha=scale, drop=d_attn,
+                   aux_op=H.AUX_MUL if mask is not None else H.AUX_NONE, aux=mask, ldaux=n,
+                   aux_bs=(h * n * n, n * n))
+            att = torch.empty(T, hD, dtype=torch.float32, device=dev)
+            H.gemm(S, Vp, att, n, DP, n, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
+                   a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
+            wpad = torch.zeros(d, h, DP, dtype=torch.float32, device=dev)
+            wpad[:, :, :Dr] = wf.reshape(d, h, Dr)
+            wpad = wpad.reshape(d, hD)
+            H.gemm(att, wpad, out, T, d, hD, lda=hD, ldb=hD, ldc=d, bias=bfc, drop=d_out, res=rc, ldr=d,
+                   out_scale=sign)
+            ctx.save_for_backward(xc, wq, gamma, wpad, qkv, stats, out3, S, att, mask)
+            attn_w = S
+        ctx.cfg = cfg
+        ctx.dims = (B, n, d, h, dk, p, Dr, DP, salt, bqkv is not None, bfc is not None, res is not None,
+                    x.shape)
+        attn_w = attn_w.detach()
+        ctx.mark_non_differentiable(attn_w)
+        return out.reshape(x.shape), attn_w
+
+    @staticmethod
+    def backward(ctx, gy, _gw):
+        (kind, h, norm_mask, eps, sign, p_attn, p_out) = ctx.cfg
+        B, n, d, h, dk, p, Dr, DP, salt, hbq, hbf, has_res, xshape = ctx.dims
+        T, hD = B * n, h * DP
+        dev = gy.device
+        g = _c(gy).reshape(T, d)
+        d_out = H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None
+        dO3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
+        dbfc = H.colsum(g, T, d, d, a_drop=d_out, sign=sign) if hbf else None
+        if kind == "galerkin":
+            xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask = ctx.saved_tensors
+            d_attn = H.dropout_desc(p_attn, salt, dev) if (p_attn > 0 and mask is None) else None
+            Qp, Kp, Vp = out3[0], out3[1], out3[2]
+            # dP^T[b] = (sign*g*mask1)^T[b] Q'[b]        [B, d, h*DP]
+            dPt = torch.empty(B, d, hD, dtype=torch.float32, device=dev)
+            H.gemm(g, Qp, dPt, d, hD, n, layout_a=1, layout_b=1, lda=d, ldb=hD, ldc=hD, batch=(B, 1),
+                   a_bs=(n * d, 0), b_bs=(n * hD, 0), c_bs=(d * hD, 0), split_k=0, a_drop=d_out,
+                   a_drop_sign=sign, a_drop_ld=d, a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0))
+            # dQ'[b] = (sign*g*mask1)[b] P[b]^T
+            H.gemm(g, P, dO3[0], n, hD, d, lda=d, ldb=d, ldc=hD, batch=(B, 1), a_bs=(n * d, 0),
+                   b_bs=(hD * d, 0), c_bs=(n * hD, 0), a_drop=d_out, a_drop_sign=sign, a_drop_ld=d,
+                   a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0))
+            dM, dWs = H.galerkin_finalize_bwd(dPt, Mt, mask, d_attn, wf, B, h, DP, Dr, d, n)
+            dwfc = torch.empty(d, h * Dr, dtype=torch.float32, device=dev)
+            H.slab_reduce(dWs, B, d * h * Dr, d * h * Dr, dwfc)
+            # dK' = V' dM^T ; dV' = K' dM          per (b, head)
+            H.gemm(Vp, dM, dO3[1], n, DP, DP, lda=hD, ldb=DP, ldc=hD, batch=(B, h), a_bs=(n * hD, DP),
+                   b_bs=(h * DP * DP, DP * DP), c_bs=(n * hD, DP))
+            H.gemm(Kp, dM, dO3[2], n, DP, DP, layout_b=1, lda=hD, ldb=DP, ldc=hD, batch=(B, h),
+                   a_bs=(n * hD, DP), b_bs=(h * DP * DP, DP * DP), c_bs=(n * hD, DP))
+        else:
+            xc, wq, gamma, wpad, qkv, stats, out3, S, att, mask = ctx.saved_tensors
+            d_attn = H.dropout_desc(p_attn, salt, dev) if (p_attn > 0 and mask is None) else None
+            Qp, Kp, Vp = out3[0], out3[1], out3[2]
+            scale = 1.0 / math.sqrt(Dr) / n
+            asc = sign if d_out is None else 1.0
+            dwpad = torch.empty(d, hD, dtype=torch.float32, device=dev)
+            H.gemm(g, att, dwpad, d, hD, T, layout_a=1, layout_b=1, lda=d, ldb=hD, ldc=hD, split_k=0,
+                   a_drop=d_out, a_drop_sign=sign, a_drop_ld=d, alpha=asc)
+            dwfc = dwpad.reshape(d, h, DP)[:, :, :Dr].reshape(d, h * Dr)
+            datt = torch.empty(T, hD, dtype=torch.float32, device=dev)
+            H.gemm(g, wpad, datt, T, hD, d, layout_b=1, lda=d, ldb=hD, ldc=hD, a_drop=d_out,
+                   a_drop_sign=sign, a_drop_ld=d, alpha=asc)
+            dS = torch.empty(B, h, n, n, dtype=torch.float32, device=dev)
+            H.gemm(datt, Vp, dS, n, n, DP, lda=hD, ldb=hD, ldc=n, batch=(B, h), a_bs=(n * hD, DP),
+                   b_bs=(n * hD, DP), c_bs=(h * n * n, n * n), alpha=scale, drop=d_attn,
+                   aux_op=H.AUX_MUL if mask is not None else H.AUX_NONE, aux=mask, ldaux=n,
+                   aux_bs=(h * n * n, n * n))
+            # dV' = S^T datt ; dQ' = dS K' ; dK' = dS^T Q'
+            H.gemm(S, datt, dO3[2], n, DP, n, layout_a=1, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
+                   a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
+            H.gemm(dS, Kp, dO3[0], n, DP, n, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
+                   a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
+            H.gemm(dS, Qp, dO3[1], n, DP, n, layout_a=1, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
+                   a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
+        dqkv, dgamma, dbeta = H.headnorm_bwd(dO3, qkv, gamma, stats, T, h, dk, p, norm_mask)
+        dwqkv = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
+        H.gemm(dqkv, xc, dwqkv, 3 * d, d, T, layout_a=1, layout_b=1, lda=3 * d, ldb=d, ldc=d, split_k=0)
+        dbqkv = H.colsum(dqkv, T, 3 * d, 3 * d) if hbq else None
+        dx = torch.empty(T, d, dtype=torch.float32, device=dev)
+        H.gemm(dqkv, wq, dx, T, d, 3 * d, layout_b=1, lda=3 * d, ldb=d, ldc=d, res=g if has_res else None,
+               ldr=d)
+        dres = torch.zeros_like(gy) if has_res else None     # folded into dx (res is x)
+        if not norm_mask:
+            dgamma = dbeta = None
+        return (dx.reshape(xshape), None, dwqkv, dbqkv, dgamma, dbeta, dwfc, dbfc, dres, None, None)
+
+
+def simple_attention(x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, *, kind: str, n_head: int, norm_mask: int,
+                     eps: float, res=None, sign: float = 1.0, p_out: float = 0.0):
+    """Self-attention block; ``res`` must be ``x`` (or None).  Returns (out, attn_weight)."""
+    mode = _attn_mode
+    mask, p_attn = None, 0.0
+    if mode == "reference":
+        p_attn = 0.5
+    elif mode == "replay":
+        if not _attn_masks:
+            raise RuntimeError("attention dropout mode 'replay' but no mask queued")
+        m = _attn_masks.pop(0).to(device=x.device, dtype=torch.float32)
+        if kind == "galerkin":
+            Dr = m.shape[-1]
+            DP = H.round4(Dr)
+            mask = torch.zeros(*m.shape[:2], DP, DP, dtype=torch.float32, device=x.device)
+            mask[..., :Dr, :Dr] = m
+        else:
+            mask = _c(m)
+    cfg = (kind, int(n_head), int(norm_mask), float(eps), float(sign), float(p_attn), float(p_out))
+    return SimpleAttentionFn.apply(x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, res, cfg, mask)

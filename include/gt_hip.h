@@ -69,7 +69,7 @@ int gt_dropout_apply(const float* x, float* out, int64_t n, const gt_dropout* d,
  *
  *   for z = (b0, b1) in [0,batch0) x [0,batch1):
  *     acc[m][n] = sum_k  A_z(m,k) * keepA(m,k) * B_z(k,n)
- *     v   = alpha*acc + bias[n] + sum_{j<rp} rp_a[m][j]*rp_b[n][j]
+ *     v   = alpha*acc + bias[n] + sum_{j<rp} rp_a[m][j]*rp_b[n][j] + add_z[m][n]
  *     pre[m][n] = v                                  (optional)
  *     v   = act(v) ;  v *= f(aux[m][n]) ;  v = dropout(v)
  *     C_z[m][n] = res_z[m][n] + out_scale*v          (res optional)
@@ -106,6 +106,7 @@ typedef struct gt_gemm_desc {
     float alpha;
     const float* bias;
     int32_t rp; const float* rp_a; int64_t rp_lda, rp_a_bs0; const float* rp_b; int64_t rp_ldb;
+    const float* add; int64_t ldadd, add_bs0, add_bs1;   /* full-matrix addend before the activation */
     float* pre; int64_t ldpre;                  /* batch strides = c_bs0/c_bs1 scaled by ldpre/ldc is NOT assumed: dense [batch][M][ldpre] */
     int32_t act;
     int32_t aux_op; const float* aux; int64_t ldaux, aux_bs0, aux_bs1; float aux_scale;

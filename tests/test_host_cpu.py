@@ -1,0 +1,124 @@
+"""CPU-side checks (-m "not gpu"): the truncated-DFT formulation against torch.fft, module
+construction / state_dict compatibility with the reference inventory, C-ABI symbol export, and the
+no-CPU-fallback contract."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from _util import GOLDEN, Golden, rel_l2
+from oracle import galerkin_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["sconv2d_odd", "sconv2d_even_flat", "sconv2d_relu"])
+def test_truncated_dft_equals_fft(name):
+    """S1..S4 GEMM pipeline (galerkin_transformer/spectral.py) == rfft2/irfft2 oracle, in fp64."""
+    from galerkin_transformer.spectral import spectral_conv2d_reference_math
+    g = Golden(name)
+    m = g.meta
+    sd = {k: v.double() for k, v in g.sd.items()}
+    x = g.inputs["x"].double()
+    B, n = m["B"], m["n"]
+    ref = O.spectral_conv2d(sd, x, modes=m["modes"], activation=m["activation"])
+    act = torch.nn.functional.silu if m["activation"] == "silu" else torch.relu
+    got = spectral_conv2d_reference_math(x.reshape(B, n, n, -1), sd["linear.weight"], sd["linear.bias"],
+                                         sd["fourier_weight.0"], sd["fourier_weight.1"], m["modes"], act)
+    assert rel_l2(got.reshape(ref.shape), ref) < 1e-12
+
+
+def test_dft_bases_1d_match_rfft():
+    from galerkin_transformer.spectral import dft_bases
+    for n, m in ((101, 7), (256, 16), (64, 33)):
+        if 2 * m > n:
+            continue
+        F1, _, _, F4 = dft_bases(n, m)
+        x = torch.randn(3, n, dtype=torch.float64)
+        xf = torch.fft.rfft(x, norm="ortho")[:, :m]
+        got = x @ F1
+        assert torch.allclose(got[:, :m], xf.real, atol=1e-12) and torch.allclose(got[:, m:], xf.imag, atol=1e-12)
+        spec = torch.zeros(3, n // 2 + 1, dtype=torch.complex128)
+        spec[:, :m] = torch.randn(3, m, dtype=torch.complex128)
+        y = torch.fft.irfft(spec, n=n, norm="ortho")
+        z = torch.cat([spec.real[:, :m], spec.imag[:, :m]], 1)
+        assert torch.allclose(z @ F4.t(), y, atol=1e-12)
+
+
+def test_state_dict_inventory_matches_reference():
+    """Same 187 keys / shapes / 2 220 829 parameters as the reference's ex2 Darcy-141 model."""
+    import yaml
+    import galerkin_transformer as gt
+    with open(os.path.join(GOLDEN, "darcy141_state_dict_keys.json")) as f:
+        inv = json.load(f)
+    with open(os.path.join(ROOT, "galerkin-transformer_amd", "config.yml")) as f:
+        cfg = yaml.full_load(f)["ex2_darcy"]
+    cfg.update(downscaler_size=tuple(inv["downscaler_size"]),
+               upscaler_size=tuple(tuple(s) for s in inv["upscaler_size"]), norm_eps=1e-7)
+    model = gt.FourierTransformer2D(**cfg)
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert mine == inv["keys"]
+    assert sum(p.numel() for p in model.parameters()) == inv["n_params"] == 2220829
+    # all encoder layers start identical (deep copies of one layer, reference model.py:1153-1154)
+    l0, l5 = model.encoder_layers[0].state_dict(), model.encoder_layers[5].state_dict()
+    assert all(torch.equal(l0[k], l5[k]) for k in l0)
+    import copy
+    copy.deepcopy(model)
+
+
+@pytest.mark.parametrize("name", ["enc_galerkin_c2", "enc_fourier_c3", "enc_galerkin_c5_ln",
+                                  "spectral_regressor2d", "model_darcy_small", "model_darcy_inv_small",
+                                  "model_burgers_small", "model_ns_lite_small"])
+def test_golden_state_dicts_load_strict(name):
+    from test_modules_gpu import build_module
+    import galerkin_transformer as gt
+    g = Golden(name)
+    mod = build_module(gt, g)
+    res = mod.load_state_dict(g.sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_encoder_defaulting_rules():
+    import galerkin_transformer as gt
+    l = gt.SimpleTransformerEncoderLayer(d_model=32, n_head=2, layer_norm=False, attn_norm=False)
+    assert l.attn.add_norm                      # both False -> attn_norm forced on (model.py:63-64)
+    l = gt.SimpleTransformerEncoderLayer(d_model=32, n_head=2, attention_type="galerkin", layer_norm=True)
+    assert not l.attn.add_norm and hasattr(l, "layer_norm1")
+    with pytest.raises(AssertionError):
+        gt.SimpleAttention(n_head=3, d_model=32)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from galerkin_transformer import _hip
+    hdr = open(os.path.join(ROOT, "include", "gt_hip.h")).read()
+    declared = set(re.findall(r"\b(gt_[a-z0-9_]+)\s*\(", hdr))
+    lib = ctypes.CDLL(_hip.lib_path())
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(_hip.EXPORTED_SYMBOLS)
+    assert _hip.lib().gt_abi_version() == 1
+    assert _hip.lib().gt_target_arch() == b"gfx950"
+
+
+def test_no_cpu_fallback():
+    """The product path refuses CPU tensors instead of silently computing elsewhere."""
+    import galerkin_transformer as gt
+    layer = gt.SimpleTransformerEncoderLayer(d_model=32, n_head=2, pos_dim=1, attention_type="galerkin",
+                                             layer_norm=False, dropout=0.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(torch.randn(1, 8, 32), torch.rand(1, 8, 1))
+    conv = gt.SpectralConv2d(4, 4, 2, dropout=0.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        conv(torch.randn(1, 8, 8, 4))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "galerkin-transformer_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dp, f)

@@ -1,0 +1,146 @@
+"""Module-level parity (-m gpu): our nn.Modules (HIP path, through the C ABI) against the golden
+vectors recorded from the reference modules -- outputs, input gradients and every parameter
+gradient, at the BASELINE.json tolerance (1e-5 relative L2, fp32)."""
+import pytest
+import torch
+
+from _util import Golden, TOL, all_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def GT(gpu_device):
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip
+    _hip.lib()
+    return gt
+
+
+def build_module(gt, g: Golden):
+    m, kind = g.meta, g.meta["kind"]
+    if kind == "encoder_layer":
+        kw = {k: v for k, v in m.items() if k not in ("kind", "B", "n", "base")}
+        return gt.SimpleTransformerEncoderLayer(dropout=0.0, ffn_dropout=0.0, **kw)
+    if kind == "spectral_conv2d":
+        return gt.SpectralConv2d(m["in_dim"], m["out_dim"], m["modes"], dropout=0.0, activation=m["activation"])
+    if kind == "spectral_conv1d":
+        return gt.SpectralConv1d(m["in_dim"], m["out_dim"], m["modes"], dropout=0.0)
+    if kind == "spectral_regressor":
+        kw = {k: v for k, v in m.items() if k != "kind"}
+        return gt.SpectralRegressor(dropout=0.0, **kw)
+    if kind == "pointwise_regressor":
+        kw = {k: v for k, v in m.items() if k != "kind"}
+        return gt.PointwiseRegressor(dropout=0.0, **kw)
+    cfg = dict(m["config"])
+    for k in ("downscaler_size", "upscaler_size"):
+        if cfg.get(k) is not None:
+            cfg[k] = tuple(tuple(s) if isinstance(s, list) else s for s in cfg[k])
+    if kind == "fourier_transformer_2d":
+        return gt.FourierTransformer2D(**cfg)
+    if kind == "simple_transformer":
+        return gt.SimpleTransformer(**cfg)
+    if kind == "fourier_transformer_2d_lite":
+        return gt.FourierTransformer2DLite(**cfg)
+    raise KeyError(kind)
+
+
+def run_module(mod, g: Golden, ins):
+    kind = g.meta["kind"]
+    if kind == "encoder_layer":
+        return mod(ins["x"], ins["pos"])
+    if kind in ("spectral_conv2d", "spectral_conv1d"):
+        return mod(ins["x"])
+    if kind in ("spectral_regressor", "pointwise_regressor"):
+        return mod(ins["x"], grid=ins["grid"])
+    if kind == "simple_transformer":
+        return mod(ins["node"], None, ins["pos"])["preds"]
+    return mod(ins["node"], None, ins["pos"], ins["grid"])["preds"]
+
+
+@pytest.mark.parametrize("name", all_golden())
+def test_module_matches_reference_golden(GT, gpu_device, name):
+    g = Golden(name)
+    dev = gpu_device
+    torch.manual_seed(0)
+    mod = build_module(GT, g)
+    missing = mod.load_state_dict(g.sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    mod = mod.to(dev).train()       # train(): nn.Dropout p=0 everywhere, so only the attention mask matters
+    if g.masks:
+        GT.set_attention_dropout("replay")
+        GT.push_attention_masks([m.to(dev) for m in g.masks])
+    else:
+        GT.set_attention_dropout("off")
+    try:
+        ins = {k: v.to(dev) for k, v in g.inputs.items()}
+        for k in g.din:
+            ins[k].requires_grad_(True)
+        out = run_module(mod, g, ins)
+        assert out.shape == g.out.shape
+        e_out = rel_l2(out, g.out)
+        out.backward(g.cot.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        GT.set_attention_dropout("reference")
+    errs = {"out": e_out}
+    for k in g.din:
+        errs["d" + k] = rel_l2(ins[k].grad, g.din[k])
+    params = dict(mod.named_parameters())
+    for k, ref in g.dparam.items():
+        assert params[k].grad is not None, k
+        errs["dW:" + k] = rel_l2(params[k].grad, ref)
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, f"{name}: {bad}  (worst {max(errs.values()):.2e})"
+
+
+def test_reference_dropout_mode_statistics(GT, gpu_device):
+    """Default mode reproduces the reference's always-on p=0.5 attention dropout: ~half of the
+    attention matrix is zero, survivors are doubled, and two forwards differ."""
+    g = Golden("enc_galerkin_c2")
+    mod = build_module(GT, g)
+    mod.load_state_dict(g.sd)
+    mod = mod.to(gpu_device).eval()
+    mod.attn_weight = True
+    x, pos = g.inputs["x"].to(gpu_device), g.inputs["pos"].to(gpu_device)
+    GT.set_attention_dropout("off")
+    _, w0 = mod(x, pos)
+    GT.set_attention_dropout("reference")
+    y1, w1 = mod(x, pos)
+    y2, w2 = mod(x, pos)
+    torch.cuda.synchronize()
+    kept = (w1 != 0)
+    assert abs(kept.float().mean().item() - 0.5) < 0.05
+    assert torch.allclose(w1[kept], 2 * w0[kept], rtol=1e-5, atol=1e-7)
+    assert not torch.equal(w1, w2) and rel_l2(y1, y2) > 1e-4
+
+
+def test_training_dropout_backward_consistency(GT, gpu_device):
+    """With every dropout active (ex2 config values) the backward pass regenerates the forward masks:
+    directional derivative from autograd == finite difference of the same-seed forward."""
+    from galerkin_transformer import _hip
+    dev = gpu_device
+    g = Golden("enc_galerkin_c2")
+    kw = {k: v for k, v in g.meta.items() if k not in ("kind", "B", "n", "base")}
+    mod = GT.SimpleTransformerEncoderLayer(dropout=0.05, ffn_dropout=0.05, **kw)
+    mod.load_state_dict(g.sd)
+    mod = mod.to(dev).train()
+    x0, pos = g.inputs["x"].to(dev), g.inputs["pos"].to(dev)
+    v = torch.randn_like(x0)
+    cot = g.cot.to(dev)
+
+    def fwd(x):
+        _hip.set_seed(4242, dev)
+        from galerkin_transformer import ops
+        ops._salt[0] = 1000
+        return mod(x, pos)
+
+    x = x0.clone().requires_grad_(True)
+    y = fwd(x)
+    gx, = torch.autograd.grad(y, x, cot)
+    eps = 1e-2
+    with torch.no_grad():
+        fd = ((fwd(x0 + eps * v) - fwd(x0 - eps * v)) * cot).sum().double() / (2 * eps)
+    torch.cuda.synchronize()
+    an = (gx * v).sum().double()
+    assert abs(float(fd - an)) / abs(float(an)) < 1e-2
