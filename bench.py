@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training samples/s of the Darcy 141x141 Galerkin-encoder model
+(BASELINE.json configs[1]: ex2_darcy.py FourierTransformer2D, 6 x (d=128, 4 heads, d_k'=34) encoder
+layers on the 43x43 coarse grid, two SpectralConv2d decoder layers at 141x141).
+
+    python bench.py --gpus N --steps K --warmup W [--batch B_per_gpu]
+
+A step = forward + MSE loss + backward + (gradient all-reduce) + clip_grad_norm_(0.99) + Adam on one
+batch of synthetic tensors already resident in HBM (the recipe of the reference's
+examples/ex2_memory_profile.py:58-71 plus the optimizer of examples/ex2_darcy.py).  Every dropout of
+config.yml:ex2_darcy is active (train mode), including the reference's always-on p=0.5 attention
+dropout.  fp32 throughout (the reference's arithmetic; the 1e-5 parity gate holds in this mode).
+
+One process per GPU (launched by torch.distributed.run for N>1), batch-sharded data parallel:
+per-GPU batch fixed (weak scaling), one flat gradient all-reduce over RCCL per step.
+Rank 0 prints ONE JSON line (see the bench contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "galerkin-transformer_amd"))
+
+import torch
+import torch.distributed as dist
+
+N_FINE, N_COARSE = 141, 43          # 421 grid subsampled by 3 / by 10 (ex2_darcy.py defaults)
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def darcy_config():
+    import yaml
+    from galerkin_transformer.ft import DarcyDataset
+    with open(os.path.join(ROOT, "galerkin-transformer_amd", "config.yml")) as f:
+        cfg = yaml.full_load(f)["ex2_darcy"]
+    down, up = DarcyDataset.get_scaler_sizes(N_FINE, N_COARSE)
+    cfg.update(downscaler_size=down, upscaler_size=up, attn_norm=True, norm_eps=1e-7, normalizer=None)
+    return cfg
+
+
+def synthetic_batch(B, device, seed):
+    from galerkin_transformer.ft import DarcyDataset
+    g = torch.Generator().manual_seed(seed)
+    node = torch.randn(B, N_FINE, N_FINE, 1, generator=g)
+    target = torch.randn(B, N_FINE, N_FINE, 1, generator=g)
+    pos = torch.from_numpy(DarcyDataset.get_grid(421, subsample=10, return_elem=False)).float()
+    grid = torch.from_numpy(DarcyDataset.get_grid(421, subsample=3, return_elem=False)).float()
+    pos = pos.reshape(1, -1, 2).repeat(B, 1, 1)
+    grid = grid.unsqueeze(0).repeat(B, 1, 1, 1)
+    return [t.to(device).contiguous() for t in (node, pos, grid, target)]
+
+
+class Trainer:
+    """fwd+loss+bwd | all-reduce | clip+Adam, each compute leg captured in a HIP graph."""
+
+    def __init__(self, model, batch, world, lr=1e-3, clip=0.99, use_graph=True):
+        from galerkin_transformer import _hip
+        self._hip = _hip
+        self.model, self.world, self.clip = model, world, clip
+        self.node, self.pos, self.grid, self.target = batch
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.dev = self.node.device
+        try:
+            self.opt = torch.optim.Adam(self.params, lr=lr, capturable=True, fused=True)
+            self.opt_kind = "adam(fused,capturable)"
+        except Exception:
+            self.opt = torch.optim.Adam(self.params, lr=lr, capturable=True, foreach=True)
+            self.opt_kind = "adam(foreach,capturable)"
+        self.loss = torch.zeros((), device=self.dev)
+        self.g_fb = self.g_opt = None
+        self.use_graph = use_graph
+        self.flat = None
+
+    def fwd_bwd(self):
+        self._hip.advance_seed(self.dev)
+        out = self.model(self.node, None, self.pos, self.grid)["preds"]
+        loss = ((out - self.target) ** 2).mean()
+        loss.backward()
+        self.loss.copy_(loss.detach())
+
+    def comm(self):
+        if self.world == 1:
+            return
+        grads = [p.grad for p in self.params]
+        if self.flat is None:
+            self.flat = torch.empty(sum(g.numel() for g in grads), device=self.dev)
+            self.views = list(self.flat.split([g.numel() for g in grads]))
+        torch._foreach_copy_(self.views, [g.reshape(-1) for g in grads])
+        dist.all_reduce(self.flat)                       # one 8.9 MB RCCL all-reduce per step
+        self.flat.mul_(1.0 / self.world)
+        torch._foreach_copy_([g.view(-1) for g in grads], self.views)
+
+    def opt_step(self):
+        torch.nn.utils.clip_grad_norm_(self.params, self.clip, foreach=True)
+        self.opt.step()
+
+    def eager_step(self):
+        for p in self.params:
+            p.grad = None
+        self.fwd_bwd()
+        self.comm()
+        self.opt_step()
+
+    def capture(self, warm=3):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warm):
+                self.eager_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if not self.use_graph:
+            return False
+        try:
+            for p in self.params:
+                p.grad = None
+            self.g_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fb):
+                self.fwd_bwd()
+                if self.world == 1:
+                    self.opt_step()
+            if self.world > 1:
+                self.g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
+                    self.opt_step()
+            torch.cuda.synchronize()
+            return True
+        except Exception as e:                           # graph capture unavailable: stay eager
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            self.g_fb = self.g_opt = None
+            torch.cuda.synchronize()
+            return False
+
+    def step(self):
+        if self.g_fb is None:
+            self.eager_step()
+            return
+        self.g_fb.replay()
+        if self.world > 1:
+            self.comm()
+            self.g_opt.replay()
+
+
+def roofline_leg(trainer):
+    """Per-launch HIP-event timing of one eager step, then the dominant hot-path kernel re-timed
+    back-to-back on the launch stream."""
+    from galerkin_transformer import _hip
+    with _hip.Profile() as prof:
+        trainer.eager_step()
+    torch.cuda.synchronize()
+    table = prof.table()
+    if not table:
+        return None, {}
+    dom = max(table, key=lambda k: table[k]["ms"])
+    recs = [r for r in prof.records if r[0] == dom and r[5] is not None]
+    # the dominant kernel's heaviest launch shape
+    best = max(recs, key=lambda r: r[3].elapsed_time(r[4]))
+    call, _keep = best[5]
+    reps = 50
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    dur_s = e0.elapsed_time(e1) / reps * 1e-3
+    achieved = best[1] / dur_s / 1e12
+    roof = dict(bound="mfma", kernel=dom, launch_shape_MNKb=list(best[6]), avg_launch_us=dur_s * 1e6,
+                achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                algorithmic_flops_per_launch=best[1], algorithmic_bytes_per_launch=best[2])
+    return roof, table
+
+
+def cpu_baseline_leg(model_cpu_sd, cfg, budget_s=20.0):
+    """The oracle's plain-torch CPU restatement of the same training step (B=4, the reference default
+    batch) timed on this host's cores: 1 warm-up + as many steps as fit the budget (>= 3)."""
+    from oracle import galerkin_oracle as O
+    B = 4
+    node, pos, grid, target = synthetic_batch(B, torch.device("cpu"), seed=7)
+    sd = {k: v.detach().clone().float().requires_grad_(v.is_floating_point()) for k, v in model_cpu_sd.items()}
+    state = {}
+    O.model_train_step_cpu(sd, cfg, node, pos, grid, target, state)
+    t0, n = time.perf_counter(), 0
+    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 40):
+        O.model_train_step_cpu(sd, cfg, node, pos, grid, target, state)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=round(B * n / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} steps of batch {B} (fwd+MSE+bwd+clip+Adam, oracle/galerkin_oracle.py), "
+                       f"{dt:.1f} s of CPU time")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--table", default=None, help="write the per-kernel event table to this JSON file")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip
+    _hip.lib()                                           # fail loudly if the HIP library is missing
+    cfg = darcy_config()
+    torch.manual_seed(1127802)                           # identical init on every rank
+    model = gt.FourierTransformer2D(**cfg)
+    cpu_sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    gt.set_attention_dropout("reference")
+    _hip.set_seed(1127802 + 7919 * rank, dev)            # per-rank dropout streams
+    batch = synthetic_batch(a.batch, dev, seed=1000 + rank)
+    tr = Trainer(model, batch, world, use_graph=not a.no_graph)
+    graphed = tr.capture()
+
+    for _ in range(a.warmup):
+        tr.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(tr.loss.item())
+
+    roof, table = (None, {})
+    if rank == 0 and not a.no_roofline:
+        try:
+            roof, table = roofline_leg(tr)
+        except Exception as e:
+            print(f"[bench] roofline leg failed: {type(e).__name__}: {e}", file=sys.stderr)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline_leg(cpu_sd, cfg)
+        except Exception as e:
+            print(f"[bench] cpu baseline failed: {type(e).__name__}: {e}", file=sys.stderr)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        gb = a.batch * world
+        value = gb * a.steps / elapsed
+        out = {
+            "metric": "training samples/s, Darcy 141x141 Galerkin encoder (fwd+loss+bwd+clip+Adam)",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (randn node/target of the Darcy shapes, true 43^2/141^2 grids, random init)",
+            "config": {"workload": "ex2_darcy FourierTransformer2D 141x141 fine / 43x43 coarse, galerkin, "
+                                   "6 layers d=128 h=4 ffn=256, 2x SpectralConv2d(32, modes 12)",
+                       "params": sum(p.numel() for p in model.parameters()),
+                       "global_batch": gb, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
+                       "hip_graph": bool(graphed), "optimizer": tr.opt_kind,
+                       "dropout": "config.yml ex2_darcy (train mode) + reference attention dropout p=0.5",
+                       "final_loss": round(loss, 6)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if a.table and table:
+            with open(a.table, "w") as f:
+                json.dump({k: v for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"])}, f, indent=1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

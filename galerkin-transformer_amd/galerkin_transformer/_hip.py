@@ -117,6 +117,50 @@ def lib():
     return _lib
 
 
+# ----------------------------------------------------------------------------------- per-launch timing
+_prof = None
+
+
+class Profile:
+    """``with Profile() as p:`` brackets every C-ABI launch with HIP events on the launch stream
+    (torch's current stream is the stream handed to the library).  Used by bench.py for the
+    roofline leg; adds a few microseconds of host work per launch, so never inside timed regions."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _prof
+        _prof = self
+        return self
+
+    def __exit__(self, *exc):
+        global _prof
+        _prof = None
+
+    def table(self):
+        """key -> dict(calls, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        out = {}
+        for key, flops, nbytes, e0, e1, _, _ in self.records:
+            r = out.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            r["calls"] += 1
+            r["ms"] += e0.elapsed_time(e1)
+            r["flops"] += flops
+            r["bytes"] += nbytes
+        return out
+
+
+def _timed(key, flops, nbytes, fn, replay=None, shape=None):
+    if _prof is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    _prof.records.append((key, flops, nbytes, e0, e1, replay, shape))
+    return rc
+
+
 class GtError(RuntimeError):
     pass
 
@@ -251,7 +295,20 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if need > 0:
         ws = workspace(A.device, need)
         wsp, wsn = ws.data_ptr(), ws.numel()
-    check(L.gt_gemm(C.byref(d), wsp, wsn, stream_ptr()), "gt_gemm")
+    if _prof is None:
+        check(L.gt_gemm(C.byref(d), wsp, wsn, stream_ptr()), "gt_gemm")
+    else:
+        nb = batch[0] * batch[1]
+        bm, bn, sp = C.c_int32(), C.c_int32(), C.c_int32()
+        L.gt_gemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(sp))
+        key = f"gemm<la={layout_a},lb={layout_b},{bm.value}x{bn.value}>" + ("+splitk" if sp.value > 1 else "")
+        flops = 2.0 * M * N * K * nb
+        nbytes = 4.0 * nb * (M * K + K * N + M * N * (1 + (res is not None) + (aux is not None) +
+                                                      (add is not None) + (pre is not None)))
+        keep = (A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, d)
+        st = stream_ptr()
+        call = lambda: L.gt_gemm(C.byref(d), wsp, wsn, st)
+        check(_timed(key, flops, nbytes, call, replay=(call, keep), shape=(M, N, K, nb)), "gt_gemm")
     return Cout
 
 
@@ -274,16 +331,15 @@ def colsum(A: torch.Tensor, M: int, N: int, lda: int, a_drop: Optional[GtDropout
     chunks = (M + 255) // 256
     ws = workspace(A.device, chunks * N * 4)
     dp = C.byref(a_drop) if (a_drop is not None and a_drop.p > 0) else None
-    check(lib().gt_colsum(A.data_ptr(), lda, M, N, dp, sign, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                          stream_ptr()), "gt_colsum")
+    check(_timed("gt_colsum", 0, 0, lambda: lib().gt_colsum(A.data_ptr(), lda, M, N, dp, sign, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                          stream_ptr())), "gt_colsum")
     return out
 
 
 def slab_reduce(slabs: torch.Tensor, n_slabs: int, stride: int, n: int, out: torch.Tensor,
                 alpha: float = 1.0):
     need_f32_cuda(slabs, out)
-    check(lib().gt_slab_reduce(slabs.data_ptr(), stride, n_slabs, n, alpha, out.data_ptr(), stream_ptr()),
-          "gt_slab_reduce")
+    check(_timed("gt_slab_reduce", 0, 0, lambda: lib().gt_slab_reduce(slabs.data_ptr(), stride, n_slabs, n, alpha, out.data_ptr(), stream_ptr())), "gt_slab_reduce")
     return out
 
 
@@ -291,16 +347,14 @@ def act_bwd(dout: torch.Tensor, pre: torch.Tensor, act: int) -> torch.Tensor:
     need_f32_cuda(dout, pre)
     dout = dout.contiguous()
     out = torch.empty_like(pre)
-    check(lib().gt_act_bwd(dout.data_ptr(), pre.data_ptr(), out.data_ptr(), pre.numel(), act, stream_ptr()),
-          "gt_act_bwd")
+    check(_timed("gt_act_bwd", 0, 0, lambda: lib().gt_act_bwd(dout.data_ptr(), pre.data_ptr(), out.data_ptr(), pre.numel(), act, stream_ptr())), "gt_act_bwd")
     return out
 
 
 def dropout_apply(x: torch.Tensor, d: GtDropout) -> torch.Tensor:
     need_f32_cuda(x)
     out = torch.empty_like(x)
-    check(lib().gt_dropout_apply(x.data_ptr(), out.data_ptr(), x.numel(), C.byref(d), stream_ptr()),
-          "gt_dropout_apply")
+    check(_timed("gt_dropout_apply", 0, 0, lambda: lib().gt_dropout_apply(x.data_ptr(), out.data_ptr(), x.numel(), C.byref(d), stream_ptr())), "gt_dropout_apply")
     return out
 
 
@@ -315,8 +369,8 @@ def headnorm_fwd(qkv: torch.Tensor, pos: Optional[torch.Tensor], gamma: Optional
     DP = round4(dk + p)
     out = torch.empty(3, T, h, DP, dtype=torch.float32, device=qkv.device)
     stats = torch.empty(2, T, h, 2, dtype=torch.float32, device=qkv.device)
-    check(lib().gt_headnorm_fwd(qkv.data_ptr(), ptr(pos), ptr(gamma), ptr(beta), T, h, dk, p, norm_mask,
-                                eps, out.data_ptr(), stats.data_ptr(), stream_ptr()), "gt_headnorm_fwd")
+    check(_timed("gt_headnorm_fwd", 0, 0, lambda: lib().gt_headnorm_fwd(qkv.data_ptr(), ptr(pos), ptr(gamma), ptr(beta), T, h, dk, p, norm_mask,
+                                eps, out.data_ptr(), stats.data_ptr(), stream_ptr())), "gt_headnorm_fwd")
     return out, stats
 
 
@@ -329,9 +383,9 @@ def headnorm_bwd(d_out: torch.Tensor, qkv: torch.Tensor, gamma: Optional[torch.T
     dbeta = torch.empty(2, h, dk, dtype=torch.float32, device=dev)
     need = lib().gt_headnorm_bwd_ws_bytes(T, h, dk)
     ws = workspace(dev, need)
-    check(lib().gt_headnorm_bwd(d_out.data_ptr(), qkv.data_ptr(), ptr(gamma), stats.data_ptr(), T, h, dk, p,
+    check(_timed("gt_headnorm_bwd", 0, 0, lambda: lib().gt_headnorm_bwd(d_out.data_ptr(), qkv.data_ptr(), ptr(gamma), stats.data_ptr(), T, h, dk, p,
                                 norm_mask, d_qkv.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                ws.data_ptr(), ws.numel(), stream_ptr()), "gt_headnorm_bwd")
+                                ws.data_ptr(), ws.numel(), stream_ptr())), "gt_headnorm_bwd")
     return d_qkv, dgamma, dbeta
 
 
@@ -343,9 +397,9 @@ def galerkin_finalize_fwd(slabs: torch.Tensor, n_slabs: int, slab_stride: int, B
     Mt = torch.empty(B, h, DP, DP, dtype=torch.float32, device=dev)
     P = torch.empty(B, h * DP, d, dtype=torch.float32, device=dev)
     dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
-    check(lib().gt_galerkin_finalize_fwd(slabs.data_ptr(), n_slabs, slab_stride, B, h, DP, Dr, d, n_tokens,
+    check(_timed("gt_galerkin_finalize_fwd", 0, 0, lambda: lib().gt_galerkin_finalize_fwd(slabs.data_ptr(), n_slabs, slab_stride, B, h, DP, Dr, d, n_tokens,
                                          ptr(mask), dp, Wfc.data_ptr(), Mt.data_ptr(), P.data_ptr(),
-                                         stream_ptr()), "gt_galerkin_finalize_fwd")
+                                         stream_ptr())), "gt_galerkin_finalize_fwd")
     return Mt, P
 
 
@@ -357,9 +411,9 @@ def galerkin_finalize_bwd(dPt: torch.Tensor, Mt: torch.Tensor, mask: Optional[to
     dM = torch.empty(B, h, DP, DP, dtype=torch.float32, device=dev)
     dW_slabs = torch.empty(B, d, h * Dr, dtype=torch.float32, device=dev)
     dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
-    check(lib().gt_galerkin_finalize_bwd(dPt.data_ptr(), Mt.data_ptr(), ptr(mask), dp, Wfc.data_ptr(), B, h,
+    check(_timed("gt_galerkin_finalize_bwd", 0, 0, lambda: lib().gt_galerkin_finalize_bwd(dPt.data_ptr(), Mt.data_ptr(), ptr(mask), dp, Wfc.data_ptr(), B, h,
                                          DP, Dr, d, n_tokens, dM.data_ptr(), dW_slabs.data_ptr(),
-                                         stream_ptr()), "gt_galerkin_finalize_bwd")
+                                         stream_ptr())), "gt_galerkin_finalize_bwd")
     return dM, dW_slabs
 
 
@@ -369,8 +423,8 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     T = x.numel() // d
     y = torch.empty_like(x)
     stats = torch.empty(T, 2, dtype=torch.float32, device=x.device)
-    check(lib().gt_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), T, d, eps, y.data_ptr(),
-                                 stats.data_ptr(), stream_ptr()), "gt_layernorm_fwd")
+    check(_timed("gt_layernorm_fwd", 0, 0, lambda: lib().gt_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), T, d, eps, y.data_ptr(),
+                                 stats.data_ptr(), stream_ptr())), "gt_layernorm_fwd")
     return y, stats
 
 
@@ -382,9 +436,9 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats:
     dg = torch.empty(d, dtype=torch.float32, device=x.device)
     db = torch.empty(d, dtype=torch.float32, device=x.device)
     ws = workspace(x.device, lib().gt_layernorm_bwd_ws_bytes(T, d))
-    check(lib().gt_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), T, d,
+    check(_timed("gt_layernorm_bwd", 0, 0, lambda: lib().gt_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), T, d,
                                  dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
-                                 stream_ptr()), "gt_layernorm_bwd")
+                                 stream_ptr())), "gt_layernorm_bwd")
     return dx, dg, db
 
 
@@ -392,16 +446,15 @@ def modemix_fwd(X: torch.Tensor, W: torch.Tensor, Y: torch.Tensor, B: int, Q: in
                 q_total: int, q_off: int):
     """X [B,2,q_total,Cin], W [Cin,Cout,Q,2], Y [B,2,q_total,Cout] (written for q in [q_off,q_off+Q))."""
     need_f32_cuda(X, W, Y)
-    check(lib().gt_modemix_fwd(X.data_ptr(), W.data_ptr(), B, Q, Cin, Cout, 2 * q_total * Cin,
-                               2 * q_total * Cout, q_total, q_total, q_off, Y.data_ptr(), stream_ptr()),
-          "gt_modemix_fwd")
+    check(_timed("gt_modemix_fwd", 0, 0, lambda: lib().gt_modemix_fwd(X.data_ptr(), W.data_ptr(), B, Q, Cin, Cout, 2 * q_total * Cin,
+                               2 * q_total * Cout, q_total, q_total, q_off, Y.data_ptr(), stream_ptr())), "gt_modemix_fwd")
     return Y
 
 
 def modemix_bwd(X: torch.Tensor, W: torch.Tensor, dY: torch.Tensor, dX: torch.Tensor, dW: torch.Tensor,
                 B: int, Q: int, Cin: int, Cout: int, q_total: int, q_off: int):
     need_f32_cuda(X, W, dY, dX, dW)
-    check(lib().gt_modemix_bwd(X.data_ptr(), W.data_ptr(), dY.data_ptr(), B, Q, Cin, Cout, 2 * q_total * Cin,
+    check(_timed("gt_modemix_bwd", 0, 0, lambda: lib().gt_modemix_bwd(X.data_ptr(), W.data_ptr(), dY.data_ptr(), B, Q, Cin, Cout, 2 * q_total * Cin,
                                2 * q_total * Cout, q_total, q_total, q_off, dX.data_ptr(), dW.data_ptr(),
-                               stream_ptr()), "gt_modemix_bwd")
+                               stream_ptr())), "gt_modemix_bwd")
     return dX, dW
