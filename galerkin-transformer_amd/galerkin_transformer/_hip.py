@@ -150,7 +150,15 @@ class Profile:
         return out
 
 
+_DEBUG_SYNC = bool(os.environ.get("GT_DEBUG_SYNC"))
+
+
 def _timed(key, flops, nbytes, fn, replay=None, shape=None):
+    if _DEBUG_SYNC:        # print-before-launch + sync-after: the last line names a faulting launch
+        print(f"[gt] {key} {shape}", flush=True)
+        rc = fn()
+        torch.cuda.synchronize()
+        return rc
     if _prof is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -295,7 +303,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if need > 0:
         ws = workspace(A.device, need)
         wsp, wsn = ws.data_ptr(), ws.numel()
-    if _prof is None:
+    if _prof is None and not _DEBUG_SYNC:
         check(L.gt_gemm(C.byref(d), wsp, wsn, stream_ptr()), "gt_gemm")
     else:
         nb = batch[0] * batch[1]

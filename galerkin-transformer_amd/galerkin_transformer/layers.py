@@ -74,7 +74,7 @@ class PositionalEncoding(nn.Module):
         self.register_buffer("pe", pe.unsqueeze(0))
 
     def forward(self, x):
-        return self.dropout(x + self.pe[:, :x.size(1), :])
+        return ops.dropout(x + self.pe[:, :x.size(1), :], self.dropout.p, self.training)
 
 
 # --------------------------------------------------------------------------------------- CNN scalers (torch/MIOpen)
@@ -101,10 +101,12 @@ class Conv2dResBlock(nn.Module):
             self.res = _Shortcut2d(in_dim, out_dim) if self.apply_shortcut else Identity()
 
     def forward(self, x):
+        # nn.Dropout members are kept for the module tree / state_dict; the masks come from the
+        # library's stateless RNG (ops.dropout) so the whole step shares one graph-safe seed.
         h = self.res(x) if self.add_res else None
-        x = self.conv(x)
+        x = ops.dropout(self.conv[0](x), self.conv[1].p, self.training)
         if self.basic_block:
-            x = self.conv1(x)
+            x = ops.dropout(self.conv1[1](self.activation(x)), self.conv1[2].p, self.training)
         return self.activation(x + h) if self.add_res else self.activation(x)
 
 
@@ -183,7 +185,7 @@ class Interp2dUpsample(nn.Module):
     def forward(self, x):
         x = F.interpolate(x, size=tuple(self.interp_size[0]), mode=self.interp_mode, align_corners=True)
         if self.conv_block:
-            x = self.conv(x)
+            x = self.activation(ops.dropout(self.conv[0](x), self.dropout.p, self.training))
         return F.interpolate(x, size=tuple(self.interp_size[1]), mode=self.interp_mode, align_corners=True)
 
 
@@ -342,7 +344,8 @@ class SpectralConv1d(nn.Module):
         if self.return_freq:
             raise NotImplementedError("return_freq is outside the HIP hot path")
         if self.training and self.dropout.p > 0:
-            x = self.dropout(x)          # decoder_dropout is 0 in every shipped config
+            # NB the reference drops the FFT branch input only (layers.py:1083); p is 0 in every config
+            raise NotImplementedError("decoder dropout > 0 inside SpectralConv1d has no HIP path")
         return spectral.spectral_conv1d(x, self.linear.weight, self.linear.bias, self.fourier_weight,
                                         self.modes, _act_name(self.activation))
 

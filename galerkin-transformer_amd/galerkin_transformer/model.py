@@ -173,6 +173,32 @@ class SpectralRegressor(nn.Module):
         return x
 
 
+class _ToChannelsLast(torch.autograd.Function):
+    """(B,C,H,W) -> (B,H,W,C), both dense.  The backward hands the CNN a dense NCHW gradient: the
+    MIOpen / interpolate backward kernels are only exercised by PyTorch with that layout (a
+    permuted-stride gradient from the token side faulted in the torch CNN backward on gfx950)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.permute(0, 2, 3, 1).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.permute(0, 3, 1, 2).contiguous()
+
+
+class _ToChannelsFirst(torch.autograd.Function):
+    """(B,H,W,C) -> (B,C,H,W), both dense; dense NHWC gradient back to the token side."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.permute(0, 2, 3, 1).contiguous()
+
+
 class DownScaler(nn.Module):
     """(B, n, n, in) -> (B, n_s, n_s, out) with conv + bilinear interpolation (model.py:640-687)."""
 
@@ -189,8 +215,8 @@ class DownScaler(nn.Module):
 
     def forward(self, x):
         n_grid, bsz = x.size(1), x.size(0)
-        x = x.reshape(bsz, n_grid, n_grid, self.in_dim).permute(0, 3, 1, 2)
-        return self.downsample(x).permute(0, 2, 3, 1)
+        x = _ToChannelsFirst.apply(x.reshape(bsz, n_grid, n_grid, self.in_dim))
+        return _ToChannelsLast.apply(self.downsample(x))
 
 
 class UpScaler(nn.Module):
@@ -210,7 +236,7 @@ class UpScaler(nn.Module):
         self.out_dim = out_dim
 
     def forward(self, x):
-        return self.upsample(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        return _ToChannelsLast.apply(self.upsample(_ToChannelsFirst.apply(x)))
 
 
 class _ConfiguredModel(nn.Module):
@@ -255,7 +281,7 @@ class _ConfiguredModel(nn.Module):
                 print(f"{a}: \t", getattr(self, a))
 
     def _drop(self, x):
-        return self.dpo(x) if (self.training and self.dpo.p > 0) else x
+        return ops.dropout(x, self.dpo.p, self.training)
 
 
 class SimpleTransformer(_ConfiguredModel):

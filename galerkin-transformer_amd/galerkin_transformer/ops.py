@@ -52,6 +52,31 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ----------------------------------------------------------------------------------- elementwise dropout
+class DropoutFn(Function):
+    """Stateless-RNG dropout (gt_dropout_apply): one device-resident seed drives every mask of a
+    training step, so a captured HIP graph replays with fresh masks and backward regenerates the
+    forward mask from (seed, salt) instead of storing it."""
+
+    @staticmethod
+    def forward(ctx, x, p: float):
+        xc = _c(x)
+        ctx.cfg = (p, _next_salt(1))
+        return H.dropout_apply(xc, H.dropout_desc(p, ctx.cfg[1], x.device))
+
+    @staticmethod
+    def backward(ctx, g):
+        p, salt = ctx.cfg
+        return H.dropout_apply(_c(g), H.dropout_desc(p, salt, g.device)), None
+
+
+def dropout(x, p: float, training: bool = True):
+    """Drop-in for nn.Dropout.forward on device tensors."""
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p))
+
+
 # ----------------------------------------------------------------------------------- Linear
 class LinearFn(Function):
     """y = res + out_scale * dropout(act(x W^T + b + extra W_e^T)).
