@@ -328,6 +328,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     }
 }
 
+// out_z[m][n..n+3] = alpha * sum_s slab[s][z][m][n..n+3]   (N % 4 == 0, 16-byte aligned everything)
+__global__ void splitk_reduce4_kernel(const float* __restrict__ slabs, int nsplit, int64_t slab_stride,
+                                      int M, int N4, int batch1, float alpha, float* __restrict__ C,
+                                      int64_t ldc, int64_t c_bs0, int64_t c_bs1, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + i;
+        for (int k = 0; k < nsplit; ++k) s += src[k * (slab_stride / 4)];
+        const int n4 = (int)(i % N4);
+        const int64_t r = i / N4;
+        const int m = (int)(r % M);
+        const int z = (int)(r / M);
+        *reinterpret_cast<f32x4*>(C + (z / batch1) * c_bs0 + (z % batch1) * c_bs1 + (int64_t)m * ldc + 4 * n4) =
+            alpha * s;
+    }
+}
+
 // out_z[m][n] = alpha * sum_s slab[s][z][m][n]
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit, int64_t slab_stride,
                                      int M, int N, int batch1, float alpha, float* __restrict__ C,
@@ -388,8 +406,8 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     int split = d->split_k;
     if (split == 0) {
         split = 1;
-        if (!has_epilogue(d) && blocks < 256 && d->K >= 1024) {
-            split = (int)std::min<int64_t>((768 + blocks - 1) / blocks, d->K / 256);
+        if (!has_epilogue(d) && blocks < 192 && d->K >= 1024) {
+            split = (int)std::min<int64_t>((320 + blocks - 1) / blocks, d->K / 256);
             if (split < 1) split = 1;
         }
     }
@@ -496,6 +514,16 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
 
     if (pl.split > 1) {
         const int64_t total = batch * mn;
+        const bool v4 = m4(d->N) && m4(d->ldc) && m4(d->c_bs0) && m4(d->c_bs1) && al16(d->C) && al16(ws);
+        if (v4) {
+            const int64_t total4 = total / 4;
+            const int blocks4 = (int)std::min<int64_t>((total4 + 255) / 256, 2048);
+            hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks4), dim3(256), 0, st,
+                               reinterpret_cast<const float*>(ws), pl.split, batch * mn, d->M, d->N / 4,
+                               d->batch1, d->alpha, d->C, d->ldc, d->c_bs0, d->c_bs1, total4);
+            GT_LAUNCH_CHECK();
+            return 0;
+        }
         const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st,
                            reinterpret_cast<const float*>(ws), pl.split, batch * mn, d->M, d->N,

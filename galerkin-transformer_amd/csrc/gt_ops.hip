@@ -24,33 +24,48 @@ __global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restr
         out[i] = x[i] * (d.thresh ? drop_mul(d, key, (uint32_t)i) : d.scale);
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int64_t stride, int n_slabs,
-                                   int64_t n, float alpha, float* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < n_slabs; ++k) s += slabs[k * stride + i];
-        out[i] = alpha * s;
+// out[i] = alpha * sum_k slabs[k*stride + i].  A block owns 16 consecutive outputs; its 16 slab
+// lanes each walk every 16th slab (fixed order -> deterministic), then a fixed LDS tree combines.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t stride,
+                                                          int n_slabs, int64_t n, float alpha,
+                                                          float* __restrict__ out) {
+    __shared__ float red[16][17];
+    const int ox = threadIdx.x & 15, sy = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + ox;
+    float s = 0.f;
+    if (i < n)
+        for (int k = sy; k < n_slabs; k += 16) s += slabs[k * stride + i];
+    red[sy][ox] = s;
+    __syncthreads();
+    if (sy == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][ox];
+        out[i] = alpha * t;
     }
 }
 
-// partial[chunk][n] = sum over the chunk's rows of A[m][n]*keep(m,n); 64 columns per block.x
+// partial[g][n] = sum over row-group g (rows g*CS_ROWS.. strided by gridDim.y*CS_ROWS) of
+// A[m][n]*keep(m,n); 64 columns per block.x.  The number of partials is bounded (CS_MAXG).
 constexpr int CS_ROWS = 256;
+constexpr int CS_MAXG = 128;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t lda, int M,
                                                      int N, DropDev d, float* __restrict__ partial) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
-    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
     const uint32_t key = drop_key_dev(d);
     float s = 0.f;
     if (n < N) {
+      for (int r0 = blockIdx.y * CS_ROWS; r0 < M; r0 += gridDim.y * CS_ROWS) {
+        const int r1 = min(M, r0 + CS_ROWS);
         for (int m = r0 + w; m < r1; m += 4) {
             float v = A[(int64_t)m * lda + n];
             if (d.thresh) v *= drop_mul(d, key, (uint32_t)((int64_t)m * N + n));
             else v *= d.scale;
             s += v;
         }
+      }
     }
     red[w][lane] = s;
     __syncthreads();
@@ -132,7 +147,11 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(
     float* m1 = dy + HN_TOK * S * pitch;          // [HN_TOK*S]
     float* m2 = m1 + HN_TOK * S;
     float* rs = m2 + HN_TOK * S;
-    const int t0 = blockIdx.x * HN_TOK, nt = min(HN_TOK, T - t0);
+    const int ngroups = (T + HN_TOK - 1) / HN_TOK;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const bool first = (grp == (int)blockIdx.x);
+    const int t0 = grp * HN_TOK, nt = min(HN_TOK, T - t0);
+    __syncthreads();
     for (int e = threadIdx.x; e < nt * d3; e += blockDim.x) {
         const int tok = e / d3, f = e % d3, s = f / dk, j = f % dk;
         xs[(tok * S + s) * pitch + j] = qkv[(int64_t)(t0 + tok) * d3 + f];
@@ -182,8 +201,8 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(
                 sb += gyv;
             }
         }
-        pg[e] = sg;
-        pg[2 * hd + e] = sb;
+        pg[e] = first ? sg : pg[e] + sg;
+        pg[2 * hd + e] = first ? sb : pg[2 * hd + e] + sb;
     }
     for (int e = threadIdx.x; e < nt * d3; e += blockDim.x) {
         const int tok = e / d3, f = e % d3, s = f / dk, j = f % dk, stream = s / h, head = s % h;
@@ -197,6 +216,7 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(
         }
         d_qkv[(int64_t)(t0 + tok) * d3 + f] = g;
     }
+    }   // token groups
 }
 
 // ------------------------------------------------------------------------------------------ galerkin finalize
@@ -316,7 +336,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     float* mg = lds + (w * 2) * d;
     float* mb = mg + d;
     for (int j = lane; j < d; j += 64) { mg[j] = 0.f; mb[j] = 0.f; }
-    const int r0 = blockIdx.x * LN_ROWS, r1 = min(T, r0 + LN_ROWS);
+    for (int r0 = blockIdx.x * LN_ROWS; r0 < T; r0 += gridDim.x * LN_ROWS) {
+    const int r1 = min(T, r0 + LN_ROWS);
     for (int row = r0 + w; row < r1; row += 4) {
         const float mu = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
         const float* xr = x + (int64_t)row * d;
@@ -337,6 +358,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
             dr[j] = rstd * (gr[j] * gamma[j] - a1 - xh * a2);
         }
     }
+    }   // row groups
     __syncthreads();
     float* pg = partial + (int64_t)blockIdx.x * 2 * d;
     for (int j = threadIdx.x; j < 2 * d; j += blockDim.x)
@@ -498,7 +520,7 @@ extern "C" int gt_dropout_apply(const float* x, float* out, int64_t n, const gt_
 extern "C" int gt_slab_reduce(const float* slabs, int64_t stride, int32_t n_slabs, int64_t n, float alpha,
                               float* out, void* stream) {
     if (!slabs || !out || n_slabs <= 0 || n <= 0) return GT_EINVAL;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, slabs,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 16)), dim3(256), 0, (hipStream_t)stream, slabs,
                        stride, n_slabs, n, alpha, out);
     GT_LAUNCH_CHECK();
     return 0;
@@ -508,7 +530,7 @@ extern "C" int gt_colsum(const float* A, int64_t lda, int32_t M, int32_t N, cons
                          float a_sign, float* out, void* ws, int64_t ws_bytes, void* stream) {
     if (!A || !out || M <= 0 || N <= 0) return GT_EINVAL;
     if (a_drop && a_drop->p > 0.f && !a_drop->seed) return GT_EINVAL;
-    const int chunks = ceil_div(M, CS_ROWS);
+    const int chunks = std::min(ceil_div(M, CS_ROWS), CS_MAXG);
     if (!ws || ws_bytes < (int64_t)chunks * N * (int64_t)sizeof(float)) return GT_EWS;
     float* partial = reinterpret_cast<float*>(ws);
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), chunks), dim3(256), 0, (hipStream_t)stream, A,
@@ -546,8 +568,12 @@ extern "C" int gt_headnorm_fwd(const float* qkv, const float* pos, const float* 
 }
 
 static inline int hn_tok_bwd(int h, int dk) { return hn_tok(2 * 3 * h * (dk + 1) + 9 * h); }
+constexpr int HN_MAXB = 512;       // bound on blocks (= dgamma/dbeta partials) of the backward
+static inline int hn_blocks_bwd(int T, int h, int dk) {
+    return std::min(ceil_div(T, hn_tok_bwd(h, dk)), HN_MAXB);
+}
 extern "C" int64_t gt_headnorm_bwd_ws_bytes(int32_t T, int32_t h, int32_t dk) {
-    return (int64_t)ceil_div(T, hn_tok_bwd(h, dk)) * 4 * h * dk * (int64_t)sizeof(float);
+    return (int64_t)hn_blocks_bwd(T, h, dk) * 4 * h * dk * (int64_t)sizeof(float);
 }
 
 extern "C" int gt_headnorm_bwd(const float* d_out, const float* qkv, const float* gamma, const float* stats,
@@ -562,7 +588,7 @@ extern "C" int gt_headnorm_bwd(const float* d_out, const float* qkv, const float
     const int tok = hn_tok_bwd(h, dk);
     const size_t lds = ((size_t)2 * tok * S * (dk + 1) + 3 * tok * S) * sizeof(float);
     if (lds > 64 * 1024) return GT_ENOTSUP;
-    const int nblk = ceil_div(T, tok);
+    const int nblk = hn_blocks_bwd(T, h, dk);
     float* partial = reinterpret_cast<float*>(ws);
     hipLaunchKernelGGL(headnorm_bwd_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, d_out, qkv,
                        gamma, stats, T, h, dk, p, DP, norm_mask, d_qkv, partial, tok);
@@ -621,8 +647,10 @@ extern "C" int gt_layernorm_fwd(const float* x, const float* gamma, const float*
     return 0;
 }
 
+constexpr int LN_MAXB = 512;
+static inline int ln_blocks_bwd(int T) { return std::min(ceil_div(T, LN_ROWS), LN_MAXB); }
 extern "C" int64_t gt_layernorm_bwd_ws_bytes(int32_t T, int32_t d) {
-    return (int64_t)ceil_div(T, LN_ROWS) * 2 * d * (int64_t)sizeof(float);
+    return (int64_t)ln_blocks_bwd(T) * 2 * d * (int64_t)sizeof(float);
 }
 
 extern "C" int gt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats,
@@ -630,7 +658,7 @@ extern "C" int gt_layernorm_bwd(const float* dy, const float* x, const float* ga
                                 int64_t ws_bytes, void* stream) {
     if (!dy || !x || !gamma || !stats || !dx || !dgamma || !dbeta || T <= 0 || d <= 0) return GT_EINVAL;
     if (!ws || ws_bytes < gt_layernorm_bwd_ws_bytes(T, d)) return GT_EWS;
-    const int nblk = ceil_div(T, LN_ROWS);
+    const int nblk = ln_blocks_bwd(T);
     const size_t lds = (size_t)8 * d * sizeof(float);
     if (lds > 64 * 1024) return GT_ENOTSUP;
     float* partial = reinterpret_cast<float*>(ws);
