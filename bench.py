@@ -74,7 +74,8 @@ class Trainer:
         self.loss = torch.zeros((), device=self.dev)
         self.g_fb = self.g_opt = None
         self.use_graph = use_graph
-        self.flat = None
+        from galerkin_transformer.distributed import FlatGradAllReducer
+        self.reducer = FlatGradAllReducer(self.params)
 
     def fwd_bwd(self):
         self._hip.advance_seed(self.dev)
@@ -84,16 +85,7 @@ class Trainer:
         self.loss.copy_(loss.detach())
 
     def comm(self):
-        if self.world == 1:
-            return
-        grads = [p.grad for p in self.params]
-        if self.flat is None:
-            self.flat = torch.empty(sum(g.numel() for g in grads), device=self.dev)
-            self.views = list(self.flat.split([g.numel() for g in grads]))
-        torch._foreach_copy_(self.views, [g.reshape(-1) for g in grads])
-        dist.all_reduce(self.flat)                       # one 8.9 MB RCCL all-reduce per step
-        self.flat.mul_(1.0 / self.world)
-        torch._foreach_copy_([g.view(-1) for g in grads], self.views)
+        self.reducer.reduce()            # one flat 8.9 MB RCCL all-reduce per step (no-op for N=1)
 
     def opt_step(self):
         torch.nn.utils.clip_grad_norm_(self.params, self.clip, foreach=True)
@@ -156,7 +148,9 @@ def roofline_leg(trainer):
     table = prof.table()
     if not table:
         return None, {}
-    dom = max(table, key=lambda k: table[k]["ms"])
+    # dominant kernel of the hand-written path = the GEMM template instance with the largest share
+    gemm_keys = [k for k in table if k.startswith("gemm<")]
+    dom = max(gemm_keys, key=lambda k: table[k]["ms"])
     recs = [r for r in prof.records if r[0] == dom and r[5] is not None]
     # the dominant kernel's heaviest launch shape
     best = max(recs, key=lambda r: r[3].elapsed_time(r[4]))
@@ -230,7 +224,8 @@ def main():
     cpu_sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev).train()
     gt.set_attention_dropout("reference")
-    _hip.set_seed(1127802 + 7919 * rank, dev)            # per-rank dropout streams
+    from galerkin_transformer.distributed import rank_seed
+    _hip.set_seed(rank_seed(1127802, rank), dev)         # per-rank dropout streams
     batch = synthetic_batch(a.batch, dev, seed=1000 + rank)
     tr = Trainer(model, batch, world, use_graph=not a.no_graph)
     graphed = tr.capture()

@@ -122,3 +122,52 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), os.path.join(dp, f)
+
+
+def test_libs_star_import_surface():
+    """Every name the reference's example scripts use after ``from libs import *`` resolves."""
+    ns = {}
+    exec("from libs import *", ns)
+    needed = ["SimpleTransformer", "FourierTransformer2D", "FourierTransformer2DLite",
+              "SimpleTransformerEncoderLayer", "SimpleAttention", "FeedForward", "SpectralConv1d",
+              "SpectralConv2d", "SpectralRegressor", "PointwiseRegressor", "BurgersDataset", "DarcyDataset",
+              "UnitGaussianNormalizer", "WeightedL2Loss", "WeightedL2Loss2d", "run_train",
+              "train_batch_burgers", "train_batch_darcy", "validate_epoch_burgers", "validate_epoch_darcy",
+              "get_args_1d", "get_args_2d", "get_seed", "get_num_params", "get_model_name", "DATA_PATH",
+              "MODEL_PATH", "SRC_ROOT", "OneCycleLR", "DataLoader", "torch", "nn", "F", "np", "os", "yaml",
+              "is_interactive", "showsolution", "showcontour", "tqdm", "copy", "defaultdict",
+              "FourierTransformerEncoderLayer", "FourierTransformer"]
+    missing = [n for n in needed if n not in ns]
+    assert not missing, missing
+
+
+def test_scaler_sizes_and_grids_match_reference_probe():
+    """get_scaler_sizes(141, 43) -> (0.555, 0.555), ((77,77),(141,141))."""
+    from galerkin_transformer.ft import DarcyDataset
+    down, up = DarcyDataset.get_scaler_sizes(141, 43)
+    assert abs(down[0] - 0.555) < 1e-9 and up == ((77, 77), (141, 141))
+    down, up = DarcyDataset.get_scaler_sizes(211, 61)
+    assert abs(down[0] - 0.54) < 1e-9 and up == ((113, 113), (211, 211))
+    g = DarcyDataset.get_grid(421, subsample=10, return_elem=False)
+    assert g.shape == (43, 43, 2) and g[0, 0, 0] == 0 and abs(g[-1, -1, 1] - 1) < 1e-12
+    nodes, elem = DarcyDataset.get_grid(5)
+    assert nodes.shape == (25, 2) and elem.shape == (32, 3)
+
+
+def test_synthetic_datasets_and_losses_cpu():
+    from galerkin_transformer.ft import BurgersDataset, DarcyDataset, WeightedL2Loss, WeightedL2Loss2d
+    ds = DarcyDataset(subsample_attn=60, subsample_nodes=20, train_data=True, train_len=8,
+                      n_samples_synthetic=10, synthetic=True)
+    item = ds[0]
+    assert item["node"].shape == (22, 22, 1) and item["pos"].shape == (64, 2) and item["grid"].shape == (22, 22, 2)
+    loss = WeightedL2Loss2d(regularizer=True, h=1 / 22, gamma=0.5)
+    u = item["target"][None, ..., 0]
+    l, r, m, _ = loss(u * 1.1, u, targets_prime=item["target_grad"][None], K=item["coeff"][None])
+    assert abs(float(l) - 0.1) < 1e-5 and float(r) > 0
+    bs = BurgersDataset(subsample=16, n_grid_fine=2048, n_samples_synthetic=12, synthetic=True)
+    it = bs[0]
+    assert it["node"].shape == (128, 1) and it["pos"].shape == (128, 1)
+    l1 = WeightedL2Loss(regularizer=True, h=1 / 128)
+    t = it["target"][None, :, 0]
+    l, r, o, m = l1(t * 0.9, t, targets_prime=it["target_grad"][None, :, 0])
+    assert abs(float(l) - 0.1) < 1e-5

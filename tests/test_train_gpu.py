@@ -1,0 +1,80 @@
+"""End-to-end (-m gpu): the reference-style training driver on synthetic Darcy data through the HIP
+path -- loss goes down, the best checkpoint round-trips through state_dict, and a HIP-graph-captured
+step reproduces the eager step bit-for-bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_cfg(gt, n_f, n_c):
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "galerkin-transformer_amd", "config.yml")) as f:
+        cfg = yaml.full_load(f)["ex2_darcy"]
+    down, up = gt.DarcyDataset.get_scaler_sizes(n_f, n_c, scale_factor=False)
+    cfg.update(n_hidden=32, n_head=2, dim_feedforward=64, num_encoder_layers=2, freq_dim=16, fourier_modes=4,
+               downscaler_size=down, upscaler_size=up, norm_eps=1e-7)
+    return cfg
+
+
+def test_run_train_synthetic_darcy(gpu_device, tmp_path):
+    import galerkin_transformer as gt
+    from libs import (DarcyDataset, DataLoader, OneCycleLR, WeightedL2Loss2d, get_seed, run_train,
+                      train_batch_darcy, validate_epoch_darcy)
+    get_seed(1127802, printout=False)
+    kw = dict(subsample_attn=30, subsample_nodes=10, synthetic=True, n_samples_synthetic=40)
+    train = DarcyDataset(train_data=True, train_len=32, **kw)
+    valid = DarcyDataset(train_data=False, valid_len=8, normalizer_x=train.normalizer_x, **kw)
+    n_f, n_c = train.n_f, train.n_grid
+    cfg = _small_cfg(gt, n_f, n_c)
+    cfg["normalizer"] = train.normalizer_y.to(gpu_device)
+    model = gt.FourierTransformer2D(**cfg).to(gpu_device)
+    tl = DataLoader(train, batch_size=4, shuffle=True, drop_last=True)
+    vl = DataLoader(valid, batch_size=4, shuffle=False)
+    epochs = 6
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    sched = OneCycleLR(opt, max_lr=2e-3, div_factor=1e2, final_div_factor=1e2, pct_start=0.3,
+                       steps_per_epoch=len(tl), epochs=epochs)
+    h = 1 / n_f
+    res = run_train(model, WeightedL2Loss2d(regularizer=True, h=h, gamma=0.5),
+                    WeightedL2Loss2d(regularizer=False, h=h), tl, vl, opt, sched,
+                    train_batch=train_batch_darcy, validate_epoch=validate_epoch_darcy, epochs=epochs,
+                    patience=None, tqdm_mode='epoch', model_name='m.pt', result_name='r.pkl',
+                    model_save_path=str(tmp_path), device=gpu_device)
+    lt = res["loss_train"][:, 0]
+    assert np.all(np.isfinite(lt)) and lt[-1] < 0.8 * lt[0]
+    fresh = gt.FourierTransformer2D(**cfg).to(gpu_device)
+    fresh.load_state_dict(torch.load(os.path.join(str(tmp_path), "m.pt")))
+    m = validate_epoch_darcy(fresh, WeightedL2Loss2d(regularizer=False, h=h), vl, gpu_device)["metric"]
+    assert np.isfinite(m)
+
+
+def test_graph_step_equals_eager_step(gpu_device):
+    """Same seed => the captured training step (fwd+bwd+clip+Adam, all dropouts on) updates the
+    parameters exactly like the eager step."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip, ops
+    outs = []
+    for graph in (False, True):
+        torch.manual_seed(3)
+        model = gt.FourierTransformer2D(**bench.darcy_config()).to(gpu_device).train()
+        gt.set_attention_dropout("reference")
+        batch = bench.synthetic_batch(2, gpu_device, 5)
+        tr = bench.Trainer(model, batch, 1, use_graph=graph)
+        _hip.set_seed(50, gpu_device)
+        ops._salt[0] = 7
+        assert tr.capture(warm=1) == graph      # one eager warm-up step either way, then (maybe) capture
+        _hip.set_seed(99, gpu_device)
+        tr.step()                                # eager: salts continue where the capture trace started
+        torch.cuda.synchronize()
+        outs.append([p.detach().clone() for p in model.parameters()])
+    worst = max(float((a - b).abs().max()) for a, b in zip(*outs))
+    assert worst < 1e-6, worst
