@@ -148,12 +148,16 @@ def roofline_leg(trainer):
     table = prof.table()
     if not table:
         return None, {}
-    # dominant kernel of the hand-written path = the GEMM template instance with the largest share
+    # dominant kernel of the hand-written path = the GEMM template instance with the largest share of
+    # the step; within it, the launch shape that accounts for most of that time
     gemm_keys = [k for k in table if k.startswith("gemm<")]
     dom = max(gemm_keys, key=lambda k: table[k]["ms"])
     recs = [r for r in prof.records if r[0] == dom and r[5] is not None]
-    # the dominant kernel's heaviest launch shape
-    best = max(recs, key=lambda r: r[3].elapsed_time(r[4]))
+    by_shape = {}
+    for r in recs:
+        by_shape[r[6]] = by_shape.get(r[6], 0.0) + r[3].elapsed_time(r[4])
+    top_shape = max(by_shape, key=by_shape.get)
+    best = next(r for r in recs if r[6] == top_shape)
     call, _keep = best[5]
     reps = 50
     for _ in range(3):
@@ -166,7 +170,9 @@ def roofline_leg(trainer):
     torch.cuda.synchronize()
     dur_s = e0.elapsed_time(e1) / reps * 1e-3
     achieved = best[1] / dur_s / 1e12
-    roof = dict(bound="mfma", kernel=dom, launch_shape_MNKb=list(best[6]), avg_launch_us=dur_s * 1e6,
+    roof = dict(bound="mfma", kernel=dom, launch_shape_MNKb=list(best[6]), launches_per_step=len(recs),
+                share_of_hip_path=round(table[dom]["ms"] / sum(v["ms"] for v in table.values()), 3),
+                avg_launch_us=round(dur_s * 1e6, 2),
                 achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
                 algorithmic_flops_per_launch=best[1], algorithmic_bytes_per_launch=best[2])
@@ -178,6 +184,9 @@ def cpu_baseline_leg(model_cpu_sd, cfg, budget_s=20.0):
     batch) timed on this host's cores: 1 warm-up + as many steps as fit the budget (>= 3)."""
     from oracle import galerkin_oracle as O
     B = 4
+    # torch's CPU kernels stop scaling (and then regress) well below the core count of a GPU host:
+    # cap the thread pool; "cores" in the output is the number of threads actually used
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     node, pos, grid, target = synthetic_batch(B, torch.device("cpu"), seed=7)
     sd = {k: v.detach().clone().float().requires_grad_(v.is_floating_point()) for k, v in model_cpu_sd.items()}
     state = {}

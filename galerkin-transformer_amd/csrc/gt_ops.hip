@@ -45,32 +45,49 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
-// partial[g][n] = sum over row-group g (rows g*CS_ROWS.. strided by gridDim.y*CS_ROWS) of
-// A[m][n]*keep(m,n); 64 columns per block.x.  The number of partials is bounded (CS_MAXG).
-constexpr int CS_ROWS = 256;
-constexpr int CS_MAXG = 128;
+// partial[g][n] = sum over rows r = g*16+ry, stepping gridDim.y*16, of A[r][n]*keep(r,n).
+// Block = 16 float4 column groups (64 columns) x 16 row lanes; fixed-order LDS combine (deterministic).
+constexpr int CS_MAXG = 512;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t lda, int M,
-                                                     int N, DropDev d, float* __restrict__ partial) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
+                                                     int N, DropDev d, int vec, float* __restrict__ partial) {
+    __shared__ float red[16][65];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int n = blockIdx.x * 64 + 4 * cx;
     const uint32_t key = drop_key_dev(d);
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (n < N) {
-      for (int r0 = blockIdx.y * CS_ROWS; r0 < M; r0 += gridDim.y * CS_ROWS) {
-        const int r1 = min(M, r0 + CS_ROWS);
-        for (int m = r0 + w; m < r1; m += 4) {
-            float v = A[(int64_t)m * lda + n];
-            if (d.thresh) v *= drop_mul(d, key, (uint32_t)((int64_t)m * N + n));
-            else v *= d.scale;
-            s += v;
+        const bool full = vec && (n + 3 < N);
+        for (int r = blockIdx.y * 16 + ry; r < M; r += gridDim.y * 16) {
+            const float* p = A + (int64_t)r * lda + n;
+            float v0, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            if (full) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+                v0 = t[0]; v1 = t[1]; v2 = t[2]; v3 = t[3];
+            } else {
+                v0 = p[0];
+                if (n + 1 < N) v1 = p[1];
+                if (n + 2 < N) v2 = p[2];
+                if (n + 3 < N) v3 = p[3];
+            }
+            if (d.thresh) {
+                const uint32_t di = (uint32_t)((int64_t)r * N + n);
+                v0 *= drop_mul(d, key, di); v1 *= drop_mul(d, key, di + 1);
+                v2 *= drop_mul(d, key, di + 2); v3 *= drop_mul(d, key, di + 3);
+            }
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
         }
-      }
     }
-    red[w][lane] = s;
+    red[ry][4 * cx + 0] = s0; red[ry][4 * cx + 1] = s1; red[ry][4 * cx + 2] = s2; red[ry][4 * cx + 3] = s3;
     __syncthreads();
-    if (w == 0 && n < N)
-        partial[(int64_t)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (threadIdx.x < 64) {
+        const int nn = blockIdx.x * 64 + threadIdx.x;
+        if (nn < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+            partial[(int64_t)blockIdx.y * N + nn] = t * (d.thresh ? 1.f : d.scale);
+        }
+    }
 }
 
 __global__ void act_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pre,
@@ -530,11 +547,13 @@ extern "C" int gt_colsum(const float* A, int64_t lda, int32_t M, int32_t N, cons
                          float a_sign, float* out, void* ws, int64_t ws_bytes, void* stream) {
     if (!A || !out || M <= 0 || N <= 0) return GT_EINVAL;
     if (a_drop && a_drop->p > 0.f && !a_drop->seed) return GT_EINVAL;
-    const int chunks = std::min(ceil_div(M, CS_ROWS), CS_MAXG);
+    const int colb = ceil_div(N, 64);
+    const int chunks = std::max(1, std::min({ceil_div(M, 128), CS_MAXG, std::max(1, 768 / colb)}));
     if (!ws || ws_bytes < (int64_t)chunks * N * (int64_t)sizeof(float)) return GT_EWS;
     float* partial = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), chunks), dim3(256), 0, (hipStream_t)stream, A,
-                       lda, M, N, make_drop(a_drop, a_sign), partial);
+    const int vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 3) == 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(colb, chunks), dim3(256), 0, (hipStream_t)stream, A, lda, M, N,
+                       make_drop(a_drop, a_sign), vec, partial);
     GT_LAUNCH_CHECK();
     return gt_slab_reduce(partial, N, chunks, N, 1.f, out, stream);
 }

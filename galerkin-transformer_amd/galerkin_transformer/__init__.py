@@ -12,4 +12,8 @@ from .model import (FourierTransformer, FourierTransformer2D, FourierTransformer
                     FourierTransformerEncoderLayer, PointwiseRegressor, SimpleTransformer,
                     SimpleTransformerEncoderLayer, SpectralRegressor)
 
+from .ft import (BurgersDataset, DarcyDataset, UnitGaussianNormalizer, WeightedL2Loss,  # noqa: F401
+                 WeightedL2Loss2d)
+from .utils import get_num_params, get_seed  # noqa: F401
+
 __version__ = "0.1.0"
