@@ -157,17 +157,25 @@ class DarcyDataset(Dataset):
     def _synthesize(self):
         rng = np.random.RandomState(self.random_state)
         N, n = self.n_samples_synthetic, self.n_grid_fine
-        # piecewise-constant two-phase coefficient from a smooth random field, smooth bump solution:
-        # same shapes / value ranges as piececonst_r421_N1024_smooth*.mat, not a PDE solve
+        # piecewise-constant two-phase coefficient from a smooth random field (same shapes / value
+        # ranges as piececonst_r421_N1024_smooth*.mat).  The "solution" is a deterministic smooth
+        # functional of the coefficient -- the sine-series solve of  -lap(u) = 1/a  with zero Dirichlet
+        # data, truncated to 12 modes per axis -- so a model can actually learn the map a -> u.  It is
+        # not the variable-coefficient Darcy solve of the real dataset.
         k = 6
         coef = rng.randn(N, k, k)
         t = np.linspace(0, np.pi, n)
         basis = np.stack([np.cos(i * t) for i in range(k)], 0)
         field = np.einsum('nij,ix,jy->nxy', coef, basis, basis)
         a = np.where(field > 0, 12.0, 3.0)
-        sol = np.einsum('nij,ix,jy->nxy', rng.randn(N, k, k) / (1 + np.arange(k))[None, :, None],
-                        np.stack([np.sin((i + 1) * t) for i in range(k)], 0),
-                        np.stack([np.sin((i + 1) * t) for i in range(k)], 0)) * 1e-2
+        ks = 12
+        sb = np.stack([np.sin((i + 1) * t) for i in range(ks)], 0)              # [ks, n]
+        w = np.full(n, 1.0 / (n - 1)); w[0] = w[-1] = 0.5 / (n - 1)             # trapezoid weights on [0,1]
+        sw = sb * w[None]
+        fhat = 4.0 * np.einsum('nxj,ix->nij', (1.0 / a) @ sw.T, sw)
+        idx = (1 + np.arange(ks)) ** 2
+        fhat = fhat / (np.pi ** 2 * (idx[:, None] + idx[None, :]))[None]
+        sol = np.einsum('ix,nij->nxj', sb, fhat) @ sb
         return a, sol
 
     def _initialize(self):
