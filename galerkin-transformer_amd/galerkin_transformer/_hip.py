@@ -84,6 +84,8 @@ _PROTOS = {
                        [C.c_int32] * 3 + [C.c_void_p, C.c_void_p]),
     "gt_modemix_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_int64, C.c_int64] +
                        [C.c_int32] * 3 + [C.c_void_p] * 3),
+    "gt_bilinear2d_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p]),
+    "gt_bilinear2d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -173,11 +175,17 @@ class GtError(RuntimeError):
     pass
 
 
+class GtNotSupported(GtError, NotImplementedError):
+    """GT_ENOTSUP: the library has no kernel for this combination (no silent fallback exists)."""
+
+
 _ERR = {-1: "GT_EINVAL (bad shape/flags)", -2: "GT_EALIGN (misaligned pointer/ld)",
         -3: "GT_EWS (scratch too small)", -4: "GT_ENOTSUP (not implemented)"}
 
 
 def check(rc: int, what: str):
+    if rc == -4:
+        raise GtNotSupported(f"{what}: {_ERR[-4]}")
     if rc != 0:
         raise GtError(f"{what} failed: {_ERR.get(rc, 'hipError ' + str(rc))}")
 
@@ -465,3 +473,37 @@ def modemix_bwd(X: torch.Tensor, W: torch.Tensor, dY: torch.Tensor, dX: torch.Te
                                2 * q_total * Cout, q_total, q_total, q_off, dX.data_ptr(), dW.data_ptr(),
                                stream_ptr())), "gt_modemix_bwd")
     return dX, dW
+
+
+def _shape4(t: torch.Tensor, nhwc: bool):
+    if nhwc:
+        B, H, W, Cc = t.shape
+    else:
+        B, Cc, H, W = t.shape
+    return B, Cc, H, W
+
+
+def bilinear2d_fwd(x: torch.Tensor, size, in_nhwc: bool, out_nhwc: bool, act: int = ACT_NONE) -> torch.Tensor:
+    """x dense [B,C,Hi,Wi] (or [B,Hi,Wi,C] when in_nhwc) -> dense [B,C,Ho,Wo] (or [B,Ho,Wo,C])."""
+    need_f32_cuda(x)
+    B, Cc, Hi, Wi = _shape4(x, in_nhwc)
+    Ho, Wo = int(size[0]), int(size[1])
+    y = torch.empty((B, Ho, Wo, Cc) if out_nhwc else (B, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
+    nb = 4.0 * B * Cc * (Hi * Wi + Ho * Wo)
+    check(_timed("gt_bilinear2d_fwd", 0, nb, lambda: lib().gt_bilinear2d_fwd(
+        x.data_ptr(), y.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(in_nhwc), int(out_nhwc), act, stream_ptr())),
+        "gt_bilinear2d_fwd")
+    return y
+
+
+def bilinear2d_bwd(g: torch.Tensor, y_saved: Optional[torch.Tensor], in_size, in_nhwc: bool, out_nhwc: bool,
+                   act: int = ACT_NONE) -> torch.Tensor:
+    need_f32_cuda(g, y_saved)
+    B, Cc, Ho, Wo = _shape4(g, out_nhwc)
+    Hi, Wi = int(in_size[0]), int(in_size[1])
+    dx = torch.empty((B, Hi, Wi, Cc) if in_nhwc else (B, Cc, Hi, Wi), dtype=torch.float32, device=g.device)
+    nb = 4.0 * B * Cc * (Hi * Wi + Ho * Wo * (2 if y_saved is not None else 1))
+    check(_timed("gt_bilinear2d_bwd", 0, nb, lambda: lib().gt_bilinear2d_bwd(
+        g.data_ptr(), ptr(y_saved), dx.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(in_nhwc), int(out_nhwc), act,
+        stream_ptr())), "gt_bilinear2d_bwd")
+    return dx

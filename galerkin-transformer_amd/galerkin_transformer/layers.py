@@ -122,11 +122,15 @@ class _Shortcut2d(nn.Module):
 Shortcut2d = _Shortcut2d
 
 
-def _resize(x, size):
-    if isinstance(size, float):
-        return F.interpolate(x, scale_factor=size, mode="bilinear", recompute_scale_factor=True,
-                             align_corners=True)
-    return F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=True)
+def _resize(x, size, act_module=None, in_nhwc=False, out_nhwc=False):
+    """activation(F.interpolate(x, ..., mode='bilinear', align_corners=True)) on the HIP resize kernel;
+    a ReLU is fused into the kernel, any other activation is applied on its output."""
+    name = "none" if act_module is None else _act_name(act_module)
+    if isinstance(size, (tuple, list)) and isinstance(size[0], float):
+        raise NotImplementedError("per-axis scale factors")
+    y = ops.bilinear_resize(x, size if isinstance(size, float) else tuple(size), in_nhwc, out_nhwc,
+                            act="relu" if name == "relu" else None)
+    return y if name in ("relu", "none") else act_module(y)
 
 
 class Interp2dEncoder(nn.Module):
@@ -153,15 +157,17 @@ class Interp2dEncoder(nn.Module):
         self.add_res = residual
         self.debug = debug
 
-    def forward(self, x):
-        x = self.activation(_resize(self.conv0(x), self.interp_size[0]))
+    def forward(self, x, out_nhwc=False):
+        """x (B, C, H, W).  ``out_nhwc`` returns (B, H', W', C') with the layout change fused into the
+        last resize (what DownScaler feeds the encoder)."""
+        x = _resize(self.conv0(x), self.interp_size[0], self.activation)
         x1 = self.conv1(x)
         x2 = self.conv2(x1)
         x3 = self.conv3(x2)
         out = torch.cat([x1, x2, x3], dim=1)
         if self.add_res:
             out = out + x
-        return self.activation(_resize(out, self.interp_size[1]))
+        return _resize(out, self.interp_size[1], self.activation, out_nhwc=out_nhwc)
 
 
 class Interp2dUpsample(nn.Module):
@@ -182,11 +188,14 @@ class Interp2dUpsample(nn.Module):
         self.interp_mode = interp_mode
         self.debug = debug
 
-    def forward(self, x):
-        x = F.interpolate(x, size=tuple(self.interp_size[0]), mode=self.interp_mode, align_corners=True)
+    def forward(self, x, in_nhwc=False, out_nhwc=False):
+        """x (B, C, H, W), or (B, H, W, C) with ``in_nhwc``; the layout changes ride on the resizes."""
+        if self.interp_mode != "bilinear":
+            raise NotImplementedError(f"interp_mode={self.interp_mode!r}: only bilinear has a HIP path")
+        x = _resize(x, self.interp_size[0], None, in_nhwc=in_nhwc)
         if self.conv_block:
             x = self.activation(ops.dropout(self.conv[0](x), self.dropout.p, self.training))
-        return F.interpolate(x, size=tuple(self.interp_size[1]), mode=self.interp_mode, align_corners=True)
+        return _resize(x, self.interp_size[1], None, out_nhwc=out_nhwc)
 
 
 # --------------------------------------------------------------------------------------- attention (HIP)

@@ -215,8 +215,10 @@ class DownScaler(nn.Module):
 
     def forward(self, x):
         n_grid, bsz = x.size(1), x.size(0)
-        x = _ToChannelsFirst.apply(x.reshape(bsz, n_grid, n_grid, self.in_dim))
-        return _ToChannelsLast.apply(self.downsample(x))
+        x = x.reshape(bsz, n_grid, n_grid, self.in_dim)
+        # one input channel: channels-last and channels-first are the same bytes
+        x = x.reshape(bsz, 1, n_grid, n_grid) if self.in_dim == 1 else _ToChannelsFirst.apply(x)
+        return self.downsample(x, out_nhwc=True)
 
 
 class UpScaler(nn.Module):
@@ -236,7 +238,7 @@ class UpScaler(nn.Module):
         self.out_dim = out_dim
 
     def forward(self, x):
-        return _ToChannelsLast.apply(self.upsample(_ToChannelsFirst.apply(x)))
+        return self.upsample(x, in_nhwc=True, out_nhwc=True)
 
 
 class _ConfiguredModel(nn.Module):

@@ -77,6 +77,37 @@ def dropout(x, p: float, training: bool = True):
     return DropoutFn.apply(x, float(p))
 
 
+# ----------------------------------------------------------------------------------- bilinear resize
+class ResizeFn(Function):
+    """act(F.interpolate(x, size, mode='bilinear', align_corners=True)) with the layout change of the
+    scaler boundaries fused in (layers.py:483-512, 658-670; model.py:675-687, 740-749)."""
+
+    @staticmethod
+    def forward(ctx, x, size, in_nhwc: bool, out_nhwc: bool, act: int):
+        xc = _c(x)
+        y = H.bilinear2d_fwd(xc, size, in_nhwc, out_nhwc, act)
+        in_size = (xc.shape[1], xc.shape[2]) if in_nhwc else (xc.shape[2], xc.shape[3])
+        ctx.cfg = (in_size, in_nhwc, out_nhwc, act)
+        if act == H.ACT_RELU:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        in_size, in_nhwc, out_nhwc, act = ctx.cfg
+        y = ctx.saved_tensors[0] if act == H.ACT_RELU else None
+        return H.bilinear2d_bwd(_c(g), y, in_size, in_nhwc, out_nhwc, act), None, None, None, None
+
+
+def bilinear_resize(x, size, in_nhwc: bool = False, out_nhwc: bool = False, act: str = None):
+    """``size``: (Ho, Wo), or a float scale factor with the reference's recompute_scale_factor=True rule
+    (output = floor(input * scale), then the align_corners scale is recomputed from the sizes)."""
+    hi, wi = (x.shape[1], x.shape[2]) if in_nhwc else (x.shape[2], x.shape[3])
+    if isinstance(size, float):
+        size = (int(math.floor(hi * size)), int(math.floor(wi * size)))
+    return ResizeFn.apply(x, (int(size[0]), int(size[1])), bool(in_nhwc), bool(out_nhwc), H.ACT_CODE[act])
+
+
 # ----------------------------------------------------------------------------------- Linear
 class LinearFn(Function):
     """y = res + out_scale * dropout(act(x W^T + b + extra W_e^T)).

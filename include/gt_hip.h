@@ -197,6 +197,23 @@ int gt_modemix_bwd(const float* X, const float* W, const float* dY, int32_t B, i
                    int32_t q_total_x, int32_t q_total_y, int32_t q_off,
                    float* dX, float* dW, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Bilinear resize, align_corners=True (F.interpolate at layers.py:483-512, 658-670), with the
+ * channels-first <-> channels-last change of the scaler boundaries (model.py:675-687, 740-749)
+ * fused in.  x: [B,C,Hi,Wi] (in_nhwc=0) or [B,Hi,Wi,C] (in_nhwc=1); y likewise with Ho,Wo and
+ * out_nhwc.  act: GT_ACT_NONE or GT_ACT_RELU applied to the resized output.  NHWC sides need
+ * C % 4 == 0 and 16-byte aligned pointers.
+ * Backward: g, y_saved (the activated forward output; only read when act == GT_ACT_RELU) have the
+ * forward OUTPUT shape/layout, dx the forward INPUT shape/layout.  Gather formulation: no atomics,
+ * bitwise deterministic.
+ * ------------------------------------------------------------------------------------------- */
+int gt_bilinear2d_fwd(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi,
+                      int32_t Ho, int32_t Wo, int32_t in_nhwc, int32_t out_nhwc, int32_t act,
+                      void* stream);
+int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx, int32_t B, int32_t C,
+                      int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t in_nhwc,
+                      int32_t out_nhwc, int32_t act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

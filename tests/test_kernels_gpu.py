@@ -326,3 +326,52 @@ def test_ops_refuse_cpu_tensors(H):
     a = torch.zeros(4, 4)
     with pytest.raises(RuntimeError):
         H.gemm(a, a, a, 4, 4, 4, lda=4, ldb=4, ldc=4)
+
+
+# ------------------------------------------------------------------------------------------ bilinear resize
+@pytest.mark.parametrize("in_nhwc,out_nhwc", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("B,C,ni,no,act", [(2, 128, 43, 77, 0), (2, 128, 78, 43, 1), (1, 36, 141, 78, 1),
+                                           (3, 8, 5, 33, 0), (1, 4, 7, 1, 0), (2, 68, 1, 6, 0),
+                                           (1, 12, 34, 34, 1)])
+def test_bilinear_resize_layouts(H, gpu_device, in_nhwc, out_nhwc, B, C, ni, no, act):
+    """gt_bilinear2d_fwd/bwd against F.interpolate(mode='bilinear', align_corners=True) (+ReLU) on the
+    CPU in fp32 (the reference's arithmetic: source index and weights are fp32 there too), every layout
+    combination, up- and down-sampling, degenerate sizes."""
+    import torch.nn.functional as F
+    nj, nq = ni + 3, max(1, no - 2)                     # non-square: H = ni -> no, W = nj -> nq
+    x = rnd(B, C, ni, nj, dev="cpu", seed=1).requires_grad_(True)
+    y = F.interpolate(x, size=(no, nq), mode="bilinear", align_corners=True)
+    if act:
+        y = torch.relu(y)
+    cot = rnd(B, C, no, nq, dev="cpu", seed=2)
+    y.backward(cot)
+    xin = x.detach().float()
+    xin = (xin.permute(0, 2, 3, 1) if in_nhwc else xin).contiguous().to(gpu_device)
+    out = H.bilinear2d_fwd(xin, (no, nq), in_nhwc, out_nhwc, act)
+    got = out.permute(0, 3, 1, 2) if out_nhwc else out
+    assert rel_l2(got, y) < KTOL
+    g = cot.float()
+    g = (g.permute(0, 2, 3, 1) if out_nhwc else g).contiguous().to(gpu_device)
+    dx = H.bilinear2d_bwd(g, out if act else None, (ni, nj), in_nhwc, out_nhwc, act)
+    dgot = dx.permute(0, 3, 1, 2) if in_nhwc else dx
+    assert rel_l2(dgot, x.grad) < KTOL
+    dx2 = H.bilinear2d_bwd(g, out if act else None, (ni, nj), in_nhwc, out_nhwc, act)
+    assert torch.equal(dx, dx2)                         # gather formulation: bitwise deterministic
+
+
+def test_bilinear_resize_autograd_scale_factor(H, gpu_device):
+    """ops.bilinear_resize with the reference's float scale factor (recompute_scale_factor=True)."""
+    import torch.nn.functional as F
+    from galerkin_transformer import ops
+    x = rnd(2, 16, 141, 141, dev="cpu", seed=3).requires_grad_(True)
+    ref = F.interpolate(x, scale_factor=0.555, mode="bilinear", recompute_scale_factor=True,
+                        align_corners=True)
+    cot = rnd(*ref.shape, dev="cpu", seed=4)
+    (gref,) = torch.autograd.grad(ref, x, cot)
+    xg = x.detach().to(gpu_device).requires_grad_(True)
+    y = ops.bilinear_resize(xg, 0.555)
+    assert tuple(y.shape) == tuple(ref.shape) == (2, 16, 78, 78)
+    y.backward(cot.to(gpu_device))
+    assert rel_l2(y, ref) < KTOL and rel_l2(xg.grad, gref) < KTOL
+    with pytest.raises(NotImplementedError):
+        ops.bilinear_resize(torch.zeros(1, 6, 6, 3, device=gpu_device), (4, 4), in_nhwc=True)
