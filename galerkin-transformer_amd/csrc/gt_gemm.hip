@@ -13,6 +13,7 @@
 // ds_write_b32 of k-contiguous operands and the ds_read_b128 of the MFMA loop conflict-free.
 #include "gt_common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace gt {
@@ -36,15 +37,16 @@ struct GemmP {
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------
-// L == 0: operand(x,k) = base[x*ld + k]  (k contiguous)  idx -> x = idx>>2, k = 4*(idx&3)
+// L == 0: operand(x,k) = base[x*ld + k]  (k contiguous)  idx -> x = idx/(BK/4), k = 4*(idx%(BK/4))
 // L == 1: operand(x,k) = base[k*ld + x]  (x contiguous)  idx -> k = idx/(BX/4), x = 4*(idx%(BX/4))
-template <int L, int BX>
+template <int L, int BX, int BK>
 __device__ __forceinline__ f32x4 gload(const float* __restrict__ base, int64_t ld, int x0, int X,
                                        int k0, int kend, int idx, int vec, const DropDev& dd,
                                        uint32_t dkey, int64_t dld, int64_t dboff) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (L == 0) {
-        const int x = x0 + (idx >> 2), k = k0 + ((idx & 3) << 2);
+        constexpr int KQ = BK / 4;
+        const int x = x0 + idx / KQ, k = k0 + ((idx % KQ) << 2);
         if (x < X && k < kend) {
             const float* ptr = base + (int64_t)x * ld + k;
             if (vec && k + 3 < kend) {
@@ -84,12 +86,13 @@ __device__ __forceinline__ f32x4 gload(const float* __restrict__ base, int64_t l
     return v;
 }
 
-// ---- registers -> LDS image s[16][BX], column swizzled by ((k>>2)&3)<<3 ---------------------
-template <int L, int BX>
+// ---- registers -> LDS image s[BK][BX], column swizzled by ((k>>2)&3)<<3 ---------------------
+template <int L, int BX, int BK>
 __device__ __forceinline__ void sstore(float* __restrict__ s, int idx, f32x4 v) {
     if (L == 0) {
-        const int x = idx >> 2, c = idx & 3;
-        const int col = x ^ ((c << 3) & (BX - 1));
+        constexpr int KQ = BK / 4;
+        const int x = idx / KQ, c = idx % KQ;
+        const int col = x ^ (((c & 3) << 3) & (BX - 1));
         s[(4 * c + 0) * BX + col] = v[0];
         s[(4 * c + 1) * BX + col] = v[1];
         s[(4 * c + 2) * BX + col] = v[2];
@@ -136,10 +139,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #endif
 }
 
-template <int LA, int LB, int MT, int NT, int WM, int WN>
+template <int LA, int LB, int MT, int NT, int WM, int WN, int BK>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
-    constexpr int BM = WM * 16 * MT, BN = WN * 16 * NT, BK = 16, T = WM * WN * 64;
-    constexpr int NVA = (BM * 4 + T - 1) / T, NVB = (BN * 4 + T - 1) / T;
+    constexpr int BM = WM * 16 * MT, BN = WN * 16 * NT, T = WM * WN * 64;
+    constexpr int FA = BM * BK / 4, FB = BN * BK / 4;          // float4 per stage
+    constexpr int NVA = (FA + T - 1) / T, NVB = (FB + T - 1) / T;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * BM + 2 * BK * BN];
     float* sA = smem;
     float* sB = smem + 2 * BK * BM;
@@ -170,27 +174,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int idx = tid + i * T;
-            if ((BM * 4) % T == 0 || idx < BM * 4)
-                ra[i] = gload<LA, BM>(A, p.lda, m0, p.M, k0, kend, idx, p.a_vec, p.a_drop, akey,
-                                      p.a_drop_ld, adoff);
+            if (FA % T == 0 || idx < FA)
+                ra[i] = gload<LA, BM, BK>(A, p.lda, m0, p.M, k0, kend, idx, p.a_vec, p.a_drop, akey,
+                                          p.a_drop_ld, adoff);
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int idx = tid + i * T;
-            if ((BN * 4) % T == 0 || idx < BN * 4)
-                rb[i] = gload<LB, BN>(Bm, p.ldb, n0, p.N, k0, kend, idx, p.b_vec, nodrop, 0u, 0, 0);
+            if (FB % T == 0 || idx < FB)
+                rb[i] = gload<LB, BN, BK>(Bm, p.ldb, n0, p.N, k0, kend, idx, p.b_vec, nodrop, 0u, 0, 0);
         }
     };
     auto r2s = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int idx = tid + i * T;
-            if ((BM * 4) % T == 0 || idx < BM * 4) sstore<LA, BM>(sA + buf * BK * BM, idx, ra[i]);
+            if (FA % T == 0 || idx < FA) sstore<LA, BM, BK>(sA + buf * BK * BM, idx, ra[i]);
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int idx = tid + i * T;
-            if ((BN * 4) % T == 0 || idx < BN * 4) sstore<LB, BN>(sB + buf * BK * BN, idx, rb[i]);
+            if (FB % T == 0 || idx < FB) sstore<LB, BN, BK>(sB + buf * BK * BN, idx, rb[i]);
         }
     };
 
@@ -206,9 +210,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         const float* __restrict__ cA = sA + buf * BK * BM;
         const float* __restrict__ cB = sB + buf * BK * BN;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < BK / 4; ++ks) {
             const int k = 4 * ks + kq;
-            const int swa = (ks << 3) & (BM - 1), swb = (ks << 3) & (BN - 1);
+            const int swa = ((ks & 3) << 3) & (BM - 1), swb = ((ks & 3) << 3) & (BN - 1);
             float a[MT], b[NT];
             lds_frag<MT>(cA + k * BM + ((wm * 16 * MT + MT * li) ^ swa), a);
             lds_frag<NT>(cB + k * BN + ((wn * 16 * NT + NT * li) ^ swb), b);
@@ -329,14 +333,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
 }
 
 // out_z[m][n..n+3] = alpha * sum_s slab[s][z][m][n..n+3]   (N % 4 == 0, 16-byte aligned everything)
-__global__ void splitk_reduce4_kernel(const float* __restrict__ slabs, int nsplit, int64_t slab_stride,
-                                      int M, int N4, int batch1, float alpha, float* __restrict__ C,
-                                      int64_t ldc, int64_t c_bs0, int64_t c_bs1, int64_t total4) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+// Block = 32 consecutive float4 outputs x 8 slab lanes; slab lane j sums slabs j, j+8, ... in order,
+// then the 8 partials are combined in a fixed order through LDS (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __restrict__ slabs, int nsplit,
+                                                             int64_t slab_stride, int M, int N4, int batch1,
+                                                             float alpha, float* __restrict__ C, int64_t ldc,
+                                                             int64_t c_bs0, int64_t c_bs1, int64_t total4) {
+    __shared__ f32x4 part[8][32];
+    const int ox = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + ox;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < total4) {
         const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + i;
-        for (int k = 0; k < nsplit; ++k) s += src[k * (slab_stride / 4)];
+        const int64_t st4 = slab_stride / 4;
+#pragma unroll 4
+        for (int k = sl; k < nsplit; k += 8) s += src[k * st4];
+    }
+    part[sl][ox] = s;
+    __syncthreads();
+    if (sl == 0 && i < total4) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s += part[k][ox];
         const int n4 = (int)(i % N4);
         const int64_t r = i / N4;
         const int m = (int)(r % M);
@@ -366,18 +383,18 @@ struct Cfg { int mt, nt, wm, wn; };
 static const Cfg kCfgs[] = {{4, 4, 2, 2}, {2, 4, 2, 2}, {2, 2, 2, 2}, {2, 2, 4, 1}, {2, 1, 4, 1}};
 constexpr int kNumCfg = 5;
 
-template <int LA, int LB>
+template <int LA, int LB, int BK>
 static void launch_cfg(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
     switch (cfg) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<LA, LB, 4, 4, 2, 2>), grid, dim3(256), 0, st, p); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 4, 2, 2>), grid, dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 2, 2, 2>), grid, dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 2, 4, 1>), grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 1, 4, 1>), grid, dim3(256), 0, st, p); break;
+        case 0: hipLaunchKernelGGL((gemm_kernel<LA, LB, 4, 4, 2, 2, BK>), grid, dim3(256), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 4, 2, 2, BK>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 2, 2, 2, BK>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 2, 4, 1, BK>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<LA, LB, 2, 1, 4, 1, BK>), grid, dim3(256), 0, st, p); break;
     }
 }
 
-struct Plan { int cfg, bm, bn, tiles_m, tiles_n, split, k_chunk; };
+struct Plan { int cfg, bm, bn, bk, tiles_m, tiles_n, split, k_chunk; };
 
 static bool has_epilogue(const gt_gemm_desc* d) {
     return d->bias || d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res ||
@@ -397,7 +414,15 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
         if (d->M > 64 && blocks0 >= 384) c = 0;
         else c = (d->N > 64) ? 1 : 2;
     }
+    if (const char* e = getenv("GT_GEMM_CFG")) {      // tuning/debug override (tools/gemm_bench.py)
+        const int f = atoi(e);
+        if (f >= 0 && f < kNumCfg) c = f;
+    }
     pl->cfg = c;
+    // BK=32 pays for the long-K reductions with row-contiguous operands (weight gradients); the
+    // short-K token GEMMs are prologue/epilogue-bound and run better with the smaller stage
+    pl->bk = (d->layout_a == 1 && d->layout_b == 1 && d->K >= 512) ? 32 : 16;
+    if (const char* e = getenv("GT_GEMM_BK")) pl->bk = (atoi(e) == 16) ? 16 : 32;
     pl->bm = kCfgs[c].wm * 16 * kCfgs[c].mt;
     pl->bn = kCfgs[c].wn * 16 * kCfgs[c].nt;
     pl->tiles_m = ceil_div(d->M, pl->bm);
@@ -406,15 +431,18 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     int split = d->split_k;
     if (split == 0) {
         split = 1;
+        // aim at ~2 resident blocks per CU (two waves per SIMD hide each other's barriers and loads)
+        int target = 512;
+        if (const char* e = getenv("GT_GEMM_TARGET")) target = std::max(1, atoi(e));
         if (!has_epilogue(d) && blocks < 192 && d->K >= 1024) {
-            split = (int)std::min<int64_t>((320 + blocks - 1) / blocks, d->K / 256);
+            split = (int)std::min<int64_t>((target + blocks / 2) / blocks, d->K / (4 * pl->bk));
             if (split < 1) split = 1;
         }
     }
     if (split > 1 && has_epilogue(d)) return GT_ENOTSUP;
     if (split > 1024) split = 1024;
     int chunk = ceil_div(std::max(d->K, 1), split);
-    chunk = ((chunk + 15) / 16) * 16;
+    chunk = ((chunk + pl->bk - 1) / pl->bk) * pl->bk;
     split = std::max(1, ceil_div(std::max(d->K, 1), chunk));
     pl->split = split;
     pl->k_chunk = chunk;
@@ -506,10 +534,18 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
     }
 
     dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split, (unsigned)batch);
-    if (d->layout_a == 0 && d->layout_b == 0) launch_cfg<0, 0>(pl.cfg, grid, st, p);
-    else if (d->layout_a == 0 && d->layout_b == 1) launch_cfg<0, 1>(pl.cfg, grid, st, p);
-    else if (d->layout_a == 1 && d->layout_b == 0) launch_cfg<1, 0>(pl.cfg, grid, st, p);
-    else launch_cfg<1, 1>(pl.cfg, grid, st, p);
+    const int lay = d->layout_a * 2 + d->layout_b;
+    if (pl.bk == 32) {
+        if (lay == 0) launch_cfg<0, 0, 32>(pl.cfg, grid, st, p);
+        else if (lay == 1) launch_cfg<0, 1, 32>(pl.cfg, grid, st, p);
+        else if (lay == 2) launch_cfg<1, 0, 32>(pl.cfg, grid, st, p);
+        else launch_cfg<1, 1, 32>(pl.cfg, grid, st, p);
+    } else {
+        if (lay == 0) launch_cfg<0, 0, 16>(pl.cfg, grid, st, p);
+        else if (lay == 1) launch_cfg<0, 1, 16>(pl.cfg, grid, st, p);
+        else if (lay == 2) launch_cfg<1, 0, 16>(pl.cfg, grid, st, p);
+        else launch_cfg<1, 1, 16>(pl.cfg, grid, st, p);
+    }
     GT_LAUNCH_CHECK();
 
     if (pl.split > 1) {
@@ -517,7 +553,7 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
         const bool v4 = m4(d->N) && m4(d->ldc) && m4(d->c_bs0) && m4(d->c_bs1) && al16(d->C) && al16(ws);
         if (v4) {
             const int64_t total4 = total / 4;
-            const int blocks4 = (int)std::min<int64_t>((total4 + 255) / 256, 2048);
+            const int blocks4 = (int)((total4 + 31) / 32);
             hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks4), dim3(256), 0, st,
                                reinterpret_cast<const float*>(ws), pl.split, batch * mn, d->M, d->N / 4,
                                d->batch1, d->alpha, d->C, d->ldc, d->c_bs0, d->c_bs1, total4);

@@ -42,17 +42,31 @@ def main():
         A = torch.randn((M, K) if la == 0 else (K, M), device=dev)
         Bm = torch.randn((N, K) if lb == 0 else (K, N), device=dev)
         C = torch.empty(M, N, device=dev)
+        fl_ = 2.0 * M * N * K
         split = 0 if la == 1 else 1
         f = lambda: H.gemm(A, Bm, C, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1], ldb=Bm.shape[1],
                            ldc=N, split_k=split)
         t = timeit(f)
+        sweep = ""
+        if os.environ.get("SWEEP"):
+            for bk in (16, 32):
+                os.environ["GT_GEMM_BK"] = str(bk)
+                sweep += f"\n      bk{bk}:"
+                for c in range(5):
+                    os.environ["GT_GEMM_CFG"] = str(c)
+                    tg = (256, 512, 1024) if la == 1 else (512,)
+                    for t_ in tg:
+                        os.environ["GT_GEMM_TARGET"] = str(t_)
+                        sweep += f" c{c}" + (f"/t{t_}" if la == 1 else "") + f":{fl_ / timeit(f) / 1e12:5.1f}"
+            for k_ in ("GT_GEMM_CFG", "GT_GEMM_BK", "GT_GEMM_TARGET"):
+                del os.environ[k_]
         a2 = A if la == 0 else A.t()
         b2 = Bm.t() if lb == 0 else Bm
         t2 = timeit(lambda: torch.matmul(a2, b2))
         fl = 2.0 * M * N * K
         print(f"{name}  M={M:7d} N={N:5d} K={K:6d}  plan={H.gemm_plan(M, N, K, split_k=split)}  "
               f"gt {fl / t / 1e12:7.2f} TF/s ({t * 1e6:8.1f} us)   torch {fl / t2 / 1e12:7.2f} TF/s "
-              f"({t2 * 1e6:8.1f} us)", flush=True)
+              f"({t2 * 1e6:8.1f} us)" + sweep, flush=True)
 
 
 if __name__ == "__main__":
