@@ -34,14 +34,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(emu=False, verbose=False, force=False):
+def build(emu=False, verbose=False, force=False, tag=None, defines=()):
+    """tag/defines: extra named variants (ablation builds for tools/ablate_gemm.sh), e.g.
+    build(tag="_nomfma", defines=["GT_ABL_NOMFMA"])."""
     os.makedirs(OUT_DIR, exist_ok=True)
-    tag = "_emu" if emu else ""
+    tag = tag if tag is not None else ("_emu" if emu else "")
     objdir = os.path.join(CSRC, ".obj" + tag)
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC]
     if emu:
         flags.append("-DGT_EMULATE_MFMA=1")
+    flags += ["-D" + d for d in defines]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -65,8 +68,13 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--emu", action="store_true")
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--ablate", action="store_true", help="also build the GEMM ablation variants")
     ap.add_argument("-v", "--verbose", action="store_true")
     a = ap.parse_args()
     print(build(False, a.verbose, a.force))
     if a.emu:
         print(build(True, a.verbose, a.force))
+    if a.ablate:
+        for t, d in (("_nomfma", ["GT_ABL_NOMFMA"]), ("_noload", ["GT_ABL_NOLOAD"]),
+                     ("_nostore", ["GT_ABL_NOSTORE"]), ("_onlymfma", ["GT_ABL_NOLOAD", "GT_ABL_NOSTORE"])):
+            print(build(False, a.verbose, a.force, tag=t, defines=d))

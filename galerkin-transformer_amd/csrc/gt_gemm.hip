@@ -120,6 +120,10 @@ __device__ __forceinline__ void lds_frag(const float* __restrict__ s, float (&f)
 }
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+#ifdef GT_ABL_NOMFMA      // ablation build (tools/ablate_gemm.sh): keep the operands live, skip the matrix pipe
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#endif
 #ifdef GT_EMULATE_MFMA
     // Debug build: the same distributed-operand semantics with shuffles (documents the layout the
     // kernel assumes: A[row=lane&15][k=lane>>4], B[k=lane>>4][col=lane&15], D[row=4*(lane>>4)+r][col=lane&15]).
@@ -206,7 +210,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+#ifndef GT_ABL_NOLOAD
         if (kt + 1 < nk) g2r(kbeg + (kt + 1) * BK);
+#endif
         const float* __restrict__ cA = sA + buf * BK * BM;
         const float* __restrict__ cB = sB + buf * BK * BN;
 #pragma unroll
@@ -228,6 +234,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     // ------------------------------- epilogue -------------------------------------------------
     const int nb = n0 + wn * 16 * NT + NT * li;        // first of this lane's NT columns
     if (nb >= p.N) return;
+#ifdef GT_ABL_NOSTORE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     const bool full = (nb + NT <= p.N);
     const int64_t coff = b0 * p.c_bs0 + b1 * p.c_bs1 + (int64_t)blockIdx.y * p.c_split;
     float* __restrict__ C = p.C + coff;

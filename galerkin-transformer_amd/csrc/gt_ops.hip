@@ -236,6 +236,162 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(
     }   // token groups
 }
 
+// ---- bandwidth-shaped head norm (dk % 4 == 0) ------------------------------------------------------
+// Thread layout: PT = 3h*G lanes per token (G = pow2 >= dk/4 lanes per head segment, one float4 each),
+// R = blockDim/PT tokens in flight per pass; a lane keeps its (segment, quarter) for the whole kernel, so
+// gamma/beta stay in registers and (backward) the affine gradients accumulate in registers.  Segment
+// statistics are G-lane shuffle reductions.  qkv / d_qkv move as aligned float4; the head tiles (offset by
+// the p coordinate columns) move as float2 when p is even, scalars otherwise.
+struct HeadGeom {
+    int T, h, dk, p, DP, norm_mask, G, PT, R, tpb;
+};
+
+__device__ __forceinline__ float group_sum(float v, int G) {
+    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void tile_store4(float* __restrict__ dst, int p, f32x4 v) {
+    if ((p & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+    else if ((p & 1) == 0) {
+        *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
+    } else { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+}
+__device__ __forceinline__ f32x4 tile_load4(const float* __restrict__ src, int p) {
+    if ((p & 3) == 0) return *reinterpret_cast<const f32x4*>(src);
+    if ((p & 1) == 0) {
+        const f32x2 a = *reinterpret_cast<const f32x2*>(src), b = *reinterpret_cast<const f32x2*>(src + 2);
+        return f32x4{a[0], a[1], b[0], b[1]};
+    }
+    return f32x4{src[0], src[1], src[2], src[3]};
+}
+
+__global__ void headnorm_fwd_v2_kernel(const float* __restrict__ qkv, const float* __restrict__ pos,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       HeadGeom g, float eps, float* __restrict__ out,
+                                       float* __restrict__ stats) {
+    const int r = threadIdx.x / g.PT, l = threadIdx.x % g.PT;
+    if (r >= g.R) return;
+    const int seg = l / g.G, q = l % g.G, Q4 = g.dk >> 2;
+    const bool active = q < Q4;
+    const int stream = seg / g.h, head = seg % g.h;
+    const bool normed = (g.norm_mask >> stream) & 1;
+    const int ni = __popc(g.norm_mask & ((1 << stream) - 1));
+    f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
+    if (normed && active) {
+        gm = *reinterpret_cast<const f32x4*>(gamma + (ni * g.h + head) * g.dk + 4 * q);
+        bt = *reinterpret_cast<const f32x4*>(beta + (ni * g.h + head) * g.dk + 4 * q);
+    }
+    const int d3 = 3 * g.h * g.dk;
+    const float inv = 1.f / (float)g.dk;
+    const int t_end = min(g.T, (int)(blockIdx.x + 1) * g.tpb);
+    for (int t = blockIdx.x * g.tpb + r; t < t_end; t += g.R) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (active) x = *reinterpret_cast<const f32x4*>(qkv + (int64_t)t * d3 + seg * g.dk + 4 * q);
+        f32x4 y = x;
+        if (normed) {
+            const float mu = group_sum(x[0] + x[1] + x[2] + x[3], g.G) * inv;
+            f32x4 c = x - mu;
+            if (!active) c = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float var = group_sum(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3], g.G) * inv;
+            const float rstd = 1.f / sqrtf(var + eps);
+            y = c * rstd * gm + bt;
+            if (q == 0)
+                *reinterpret_cast<f32x2*>(stats + (((int64_t)ni * g.T + t) * g.h + head) * 2) = f32x2{mu, rstd};
+        }
+        float* row = out + (((int64_t)stream * g.T + t) * g.h + head) * g.DP;
+        if (active) tile_store4(row + g.p + 4 * q, g.p, y);
+        if (q == 0)
+            for (int j = 0; j < g.p; ++j) row[j] = pos[(int64_t)t * g.p + j];
+        if (q == Q4 - 1)
+            for (int j = g.p + g.dk; j < g.DP; ++j) row[j] = 0.f;
+    }
+}
+
+__global__ void headnorm_bwd_v2_kernel(const float* __restrict__ d_out, const float* __restrict__ qkv,
+                                       const float* __restrict__ gamma, const float* __restrict__ stats,
+                                       HeadGeom g, float* __restrict__ d_qkv,
+                                       float* __restrict__ partial /* [nblk][dg: 2*h*dk | db: 2*h*dk] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [R][PT][8]
+    const int r = threadIdx.x / g.PT, l = threadIdx.x % g.PT;
+    const int hd = g.h * g.dk;
+    if (r < g.R) {
+        const int seg = l / g.G, q = l % g.G, Q4 = g.dk >> 2;
+        const bool active = q < Q4;
+        const int stream = seg / g.h, head = seg % g.h;
+        const bool normed = (g.norm_mask >> stream) & 1;
+        const int ni = __popc(g.norm_mask & ((1 << stream) - 1));
+        f32x4 gm = {1.f, 1.f, 1.f, 1.f};
+        if (normed && active) gm = *reinterpret_cast<const f32x4*>(gamma + (ni * g.h + head) * g.dk + 4 * q);
+        f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+        const int d3 = 3 * hd;
+        const float inv = 1.f / (float)g.dk;
+        const int t_end = min(g.T, (int)(blockIdx.x + 1) * g.tpb);
+        for (int t = blockIdx.x * g.tpb + r; t < t_end; t += g.R) {
+            f32x4 gy = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
+            if (active) {
+                gy = tile_load4(d_out + (((int64_t)stream * g.T + t) * g.h + head) * g.DP + g.p + 4 * q, g.p);
+                if (normed) x = *reinterpret_cast<const f32x4*>(qkv + (int64_t)t * d3 + seg * g.dk + 4 * q);
+            }
+            f32x4 dx = gy;
+            if (normed) {
+                const f32x2 st = *reinterpret_cast<const f32x2*>(stats + (((int64_t)ni * g.T + t) * g.h + head) * 2);
+                const float mu = st[0], rstd = st[1];
+                f32x4 xh = (x - mu) * rstd;
+                if (!active) xh = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 gg = gy * gm;
+                const float m1 = group_sum(gg[0] + gg[1] + gg[2] + gg[3], g.G) * inv;
+                const float m2 = group_sum(gg[0] * xh[0] + gg[1] * xh[1] + gg[2] * xh[2] + gg[3] * xh[3], g.G) * inv;
+                dx = rstd * (gg - m1 - xh * m2);
+                dg += gy * xh;
+                db += gy;
+            }
+            if (active) *reinterpret_cast<f32x4*>(d_qkv + (int64_t)t * d3 + seg * g.dk + 4 * q) = dx;
+        }
+        float* me = lds + ((size_t)r * g.PT + l) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { me[j] = dg[j]; me[4 + j] = db[j]; }
+    }
+    __syncthreads();
+    // fixed-order combine over the R token rows, one thread per (lane slot, component)
+    float* pg = partial + (int64_t)blockIdx.x * 4 * hd;
+    const int nn = __popc(g.norm_mask & 7);
+    for (int e = threadIdx.x; e < 4 * hd; e += blockDim.x)          // slots of absent norm streams
+        if ((e % (2 * hd)) / hd >= nn) pg[e] = 0.f;
+    for (int e = threadIdx.x; e < g.PT * 8; e += blockDim.x) {
+        const int ll = e >> 3, comp = e & 7;
+        const int seg = ll / g.G, q = ll % g.G;
+        const int stream = seg / g.h, head = seg % g.h;
+        if (q >= (g.dk >> 2) || !((g.norm_mask >> stream) & 1)) continue;
+        const int ni = __popc(g.norm_mask & ((1 << stream) - 1));
+        float s = 0.f;
+        for (int rr = 0; rr < g.R; ++rr) s += lds[((size_t)rr * g.PT + ll) * 8 + comp];
+        const int idx = ni * hd + head * g.dk + 4 * q + (comp & 3);
+        pg[(comp < 4 ? 0 : 2 * hd) + idx] = s;
+    }
+}
+
+static bool head_geom(int T, int h, int dk, int p, int norm_mask, int max_blocks, HeadGeom* g, int* threads,
+                      int* blocks) {
+    if (dk & 3) return false;
+    int G = 1;
+    while (G < dk / 4) G <<= 1;
+    if (G > 64) return false;
+    const int PT = 3 * h * G;
+    if (PT > 1024) return false;
+    int thr = std::max(256, ((PT + 63) / 64) * 64);
+    const int R = thr / PT;
+    int nblk = std::min(max_blocks, ceil_div(T, R * 8));
+    nblk = std::max(nblk, 1);
+    int tpb = ceil_div(T, nblk);
+    tpb = ceil_div(tpb, R) * R;
+    nblk = ceil_div(T, tpb);
+    *g = HeadGeom{T, h, dk, p, (dk + p + 3) & ~3, norm_mask, G, PT, R, tpb};
+    *threads = thr;
+    *blocks = nblk;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------ galerkin finalize
 __global__ __launch_bounds__(256) void galerkin_fin_fwd_kernel(
     const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int h, int DP, int Dr, int d,
@@ -577,6 +733,18 @@ extern "C" int gt_headnorm_fwd(const float* qkv, const float* pos, const float* 
     if (norm_mask & ~7) return GT_EINVAL;
     if (norm_mask && (!gamma || !beta || !stats)) return GT_EINVAL;
     const int DP = round4(dk + p);
+    {
+        HeadGeom g; int thr, nblk;
+        const bool al = ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out) |
+                          reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+                          reinterpret_cast<uintptr_t>(stats)) & 15) == 0;
+        if (al && head_geom(T, h, dk, p, norm_mask, 1 << 20, &g, &thr, &nblk)) {
+            hipLaunchKernelGGL(headnorm_fwd_v2_kernel, dim3(nblk), dim3(thr), 0, (hipStream_t)stream, qkv, pos,
+                               gamma, beta, g, eps, out, stats);
+            GT_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const int tok = hn_tok(3 * h * (dk + 1));
     const size_t lds = (size_t)tok * 3 * h * (dk + 1) * sizeof(float);
     if (lds > 64 * 1024) return GT_ENOTSUP;
@@ -592,7 +760,8 @@ static inline int hn_blocks_bwd(int T, int h, int dk) {
     return std::min(ceil_div(T, hn_tok_bwd(h, dk)), HN_MAXB);
 }
 extern "C" int64_t gt_headnorm_bwd_ws_bytes(int32_t T, int32_t h, int32_t dk) {
-    return (int64_t)hn_blocks_bwd(T, h, dk) * 4 * h * dk * (int64_t)sizeof(float);
+    (void)T;
+    return (int64_t)HN_MAXB * 4 * h * dk * (int64_t)sizeof(float);      // upper bound for both kernels
 }
 
 extern "C" int gt_headnorm_bwd(const float* d_out, const float* qkv, const float* gamma, const float* stats,
@@ -606,11 +775,22 @@ extern "C" int gt_headnorm_bwd(const float* d_out, const float* qkv, const float
     const int S = 3 * h;
     const int tok = hn_tok_bwd(h, dk);
     const size_t lds = ((size_t)2 * tok * S * (dk + 1) + 3 * tok * S) * sizeof(float);
-    if (lds > 64 * 1024) return GT_ENOTSUP;
-    const int nblk = hn_blocks_bwd(T, h, dk);
+    int nblk = hn_blocks_bwd(T, h, dk);
     float* partial = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(headnorm_bwd_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, d_out, qkv,
-                       gamma, stats, T, h, dk, p, DP, norm_mask, d_qkv, partial, tok);
+    HeadGeom g; int thr, nb2;
+    const bool al = ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(d_qkv) |
+                      reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(stats) |
+                      reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
+    if (al && head_geom(T, h, dk, p, norm_mask, HN_MAXB, &g, &thr, &nb2)) {
+        nblk = nb2;
+        const size_t lds2 = (size_t)g.R * g.PT * 8 * sizeof(float);
+        hipLaunchKernelGGL(headnorm_bwd_v2_kernel, dim3(nblk), dim3(thr), lds2, (hipStream_t)stream, d_out,
+                           qkv, gamma, stats, g, d_qkv, partial);
+    } else {
+        if (lds > 64 * 1024) return GT_ENOTSUP;
+        hipLaunchKernelGGL(headnorm_bwd_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, d_out, qkv,
+                           gamma, stats, T, h, dk, p, DP, norm_mask, d_qkv, partial, tok);
+    }
     GT_LAUNCH_CHECK();
     if (norm_mask) {
         const int hd = h * dk;
