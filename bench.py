@@ -148,6 +148,7 @@ def roofline_leg(trainer):
     table = prof.table()
     if not table:
         return None, {}
+    trainer.shape_table = prof.table(by_shape=True)
     # dominant kernel of the hand-written path = the GEMM template instance with the largest share of
     # the step; within it, the launch shape that accounts for most of that time
     gemm_keys = [k for k in table if k.startswith("gemm<")]
@@ -293,7 +294,9 @@ def main():
         }
         if a.table and table:
             with open(a.table, "w") as f:
-                json.dump({k: v for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"])}, f, indent=1)
+                json.dump({"by_kernel": dict(sorted(table.items(), key=lambda kv: -kv[1]["ms"])),
+                           "by_shape": dict(sorted(getattr(tr, "shape_table", {}).items(),
+                                                   key=lambda kv: -kv[1]["ms"]))}, f, indent=1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

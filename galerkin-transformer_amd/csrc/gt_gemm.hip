@@ -26,12 +26,13 @@ struct GemmP {
     float* C; int64_t ldc, c_bs0, c_bs1, c_split;
     int a_vec, b_vec, c_vec, raw;
     DropDev a_drop; int64_t a_drop_ld, a_drop_bstride;
+    float* acs;                 // per-(K-slice, batch) partial row sums of the (masked) A operand, or null
     float alpha; const float* bias;
     int rp; const float* rp_a; int64_t rp_lda, rp_a_bs0; const float* rp_b; int64_t rp_ldb;
     const float* add; int64_t ldadd, add_bs0, add_bs1;
     float* pre; int64_t ldpre;
     int act, aux_op; const float* aux; int64_t ldaux, aux_bs0, aux_bs1; float aux_scale;
-    DropDev drop;
+    DropDev drop; int drop_ld, n_off;      // mask index = (z*M + m)*drop_ld + n_off + n
     const float* res; int64_t ldr, r_bs0, r_bs1;
     float out_scale;
 };
@@ -174,13 +175,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         for (int t = 0; t < NT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 ra[NVA], rb[NVB];
+    // LA == 1: a thread's float4 always covers the same 4 rows m of the tile (T is a multiple of BM/4),
+    // so the row sums of A (= bias gradients in the weight-gradient use) accumulate in registers for free
+    f32x4 asum = {0.f, 0.f, 0.f, 0.f};
+    const bool do_acs = (LA == 1) && p.acs != nullptr && tn == 0;
     auto g2r = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int idx = tid + i * T;
-            if (FA % T == 0 || idx < FA)
+            if (FA % T == 0 || idx < FA) {
                 ra[i] = gload<LA, BM, BK>(A, p.lda, m0, p.M, k0, kend, idx, p.a_vec, p.a_drop, akey,
                                           p.a_drop_ld, adoff);
+                if (LA == 1 && do_acs) asum += ra[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
@@ -231,6 +238,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         __syncthreads();
     }
 
+    if (LA == 1 && do_acs) {        // uniform per block; smem is free after the loop's last barrier
+        constexpr int Q = BM / 4, ROWS = T / Q;
+        static_assert(T % Q == 0 && ROWS * BM <= 2 * BK * BM, "row-sum scratch must fit the A stage");
+        *reinterpret_cast<f32x4*>(&smem[(tid / Q) * BM + 4 * (tid % Q)]) = asum;
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) t += smem[r * BM + tid];
+            p.acs[((int64_t)blockIdx.y * gridDim.z + z) * p.M + m0 + tid] = t;
+        }
+    }
+
     // ------------------------------- epilogue -------------------------------------------------
     const int nb = n0 + wn * 16 * NT + NT * li;        // first of this lane's NT columns
     if (nb >= p.N) return;
@@ -277,17 +297,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
                         if (nb + t < p.N) v[t] += aj * p.rp_b[(int64_t)(nb + t) * p.rp_ldb + j];
                 }
             }
-            if (p.add) {
-                const float* ad = p.add + b0 * p.add_bs0 + b1 * p.add_bs1 + (int64_t)m * p.ldadd + nb;
+            const bool vec4 = full && p.c_vec && NT == 4;
+            // tile-row accessors: one 16-byte access when the row segment is aligned, scalars otherwise
+            auto ldrow = [&](const float* src, float (&o)[NT]) {
+                if (vec4) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (nb + t < p.N) v[t] += ad[t];
+                    for (int t = 0; t < NT; ++t) o[t] = t4[t & 3];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) o[t] = (nb + t < p.N) ? src[t] : 0.f;
+                }
+            };
+            if (p.add) {
+                float ad[NT];
+                ldrow(p.add + b0 * p.add_bs0 + b1 * p.add_bs1 + (int64_t)m * p.ldadd + nb, ad);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] += ad[t];
             }
             if (p.pre) {
                 float* pp = p.pre + ((int64_t)z * p.M + m) * p.ldpre + nb;
+                if (vec4) {
+                    *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1 % NT], v[2 % NT], v[3 % NT]};
+                } else {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (nb + t < p.N) pp[t] = v[t];
+                    for (int t = 0; t < NT; ++t)
+                        if (nb + t < p.N) pp[t] = v[t];
+                }
             }
             if (p.act == GT_ACT_RELU) {
 #pragma unroll
@@ -297,33 +333,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
                 for (int t = 0; t < NT; ++t) v[t] = silu_f(v[t]);
             }
             if (p.aux_op) {
-                const float* ap = p.aux + b0 * p.aux_bs0 + b1 * p.aux_bs1 + (int64_t)m * p.ldaux + nb;
+                float ax[NT];
+                ldrow(p.aux + b0 * p.aux_bs0 + b1 * p.aux_bs1 + (int64_t)m * p.ldaux + nb, ax);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    if (nb + t < p.N) {
-                        const float a = ap[t];
-                        v[t] *= (p.aux_op == GT_AUX_GT0)   ? (a > 0.f ? p.aux_scale : 0.f)
-                                : (p.aux_op == GT_AUX_DSILU) ? dsilu_f(a)
-                                                             : a * p.aux_scale;
-                    }
+                    const float a = ax[t];
+                    v[t] *= (p.aux_op == GT_AUX_GT0)   ? (a > 0.f ? p.aux_scale : 0.f)
+                            : (p.aux_op == GT_AUX_DSILU) ? dsilu_f(a)
+                                                         : a * p.aux_scale;
                 }
             }
             if (p.drop.thresh) {
-                const uint32_t di = (uint32_t)(((int64_t)z * p.M + m) * p.N + nb);
+                const uint32_t di = (uint32_t)(((int64_t)z * p.M + m) * p.drop_ld + p.n_off + nb);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) v[t] *= drop_mul(p.drop, dkey, di + t);
             }
             if (p.res) {
-                const float* rp_ = p.res + b0 * p.r_bs0 + b1 * p.r_bs1 + (int64_t)m * p.ldr + nb;
-                if (full && p.c_vec && NT == 4) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(rp_);
+                float rv[NT];
+                ldrow(p.res + b0 * p.r_bs0 + b1 * p.r_bs1 + (int64_t)m * p.ldr + nb, rv);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) v[t] = rv[t] + p.out_scale * v[t];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (nb + t < p.N) v[t] = rp_[t] + p.out_scale * v[t];
-                }
+                for (int t = 0; t < NT; ++t) v[t] = rv[t] + p.out_scale * v[t];
             } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) v[t] *= p.out_scale;
@@ -485,14 +514,24 @@ extern "C" int gt_gemm_plan(const gt_gemm_desc* d, int32_t* bm, int32_t* bn, int
     return 0;
 }
 
-extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
-    Plan pl;
-    if (make_plan(d, &pl)) return 0;
+static int64_t slab_bytes(const gt_gemm_desc* d, const Plan& pl) {
     if (pl.split <= 1) return 0;
     return (int64_t)pl.split * d->batch0 * d->batch1 * d->M * d->N * (int64_t)sizeof(float);
 }
+static int64_t acs_parts(const gt_gemm_desc* d, const Plan& pl) {
+    return d->a_colsum ? (int64_t)pl.split * d->batch0 * d->batch1 : 0;
+}
 
-extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream) {
+extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
+    Plan pl;
+    if (make_plan(d, &pl)) return 0;
+    const int64_t parts = acs_parts(d, pl);
+    return slab_bytes(d, pl) + (parts > 0 ? parts * d->M * (int64_t)sizeof(float) : 0);
+}
+
+// One kernel launch (+ split-K reduce) for the column range [n_off, n_off + d->N) of a problem whose
+// full width is drop_ld (d already points at that column range).
+static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int64_t ws_bytes, void* stream) {
     if (!d || !d->A || !d->B || !d->C) return GT_EINVAL;
     if ((d->layout_a | d->layout_b) & ~1) return GT_EINVAL;
     if (d->rp < 0 || d->rp > 8) return GT_EINVAL;
@@ -516,6 +555,21 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
     p.a_drop_ld = d->a_drop_ld; p.a_drop_bstride = d->a_drop_bstride;
 
     const int64_t mn = (int64_t)d->M * d->N;
+    const int64_t parts = acs_parts(d, pl);
+    float* acs_partial = nullptr;
+    if (d->a_colsum) {
+        if (d->layout_a != 1) return GT_ENOTSUP;
+        // without a mask the sign of a_drop_sign is not applied by the loader: fold it into the reduce
+        const bool need_scale = !(d->a_drop.p > 0.f) && d->a_drop_sign != 1.f;
+        if (parts > 1 || need_scale) {
+            const int64_t off = slab_bytes(d, pl);
+            if (!ws || ws_bytes < off + parts * d->M * (int64_t)sizeof(float)) return GT_EWS;
+            acs_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + off);
+            p.acs = acs_partial;
+        } else {
+            p.acs = d->a_colsum;
+        }
+    }
     if (pl.split > 1) {
         const int64_t need = (int64_t)pl.split * batch * mn * (int64_t)sizeof(float);
         if (!ws || ws_bytes < need) return GT_EWS;
@@ -528,6 +582,9 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
         p.C = d->C; p.ldc = d->ldc; p.c_bs0 = d->c_bs0; p.c_bs1 = d->c_bs1; p.c_split = 0;
         p.c_vec = al16(d->C) && m4(d->ldc) && m4(d->c_bs0) && m4(d->c_bs1);
         if (d->res) p.c_vec = p.c_vec && al16(d->res) && m4(d->ldr) && m4(d->r_bs0) && m4(d->r_bs1);
+        if (d->add) p.c_vec = p.c_vec && al16(d->add) && m4(d->ldadd) && m4(d->add_bs0) && m4(d->add_bs1);
+        if (d->aux_op) p.c_vec = p.c_vec && al16(d->aux) && m4(d->ldaux) && m4(d->aux_bs0) && m4(d->aux_bs1);
+        if (d->pre) p.c_vec = p.c_vec && al16(d->pre) && m4(d->ldpre) && m4((int64_t)d->M * d->ldpre);
         p.alpha = d->alpha; p.bias = d->bias;
         p.rp = d->rp; p.rp_a = d->rp_a; p.rp_lda = d->rp_lda; p.rp_a_bs0 = d->rp_a_bs0;
         p.rp_b = d->rp_b; p.rp_ldb = d->rp_ldb;
@@ -538,6 +595,7 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
         p.aux_bs0 = d->aux_bs0; p.aux_bs1 = d->aux_bs1; p.aux_scale = d->aux_scale;
         if (p.aux_op && !p.aux) return GT_EINVAL;
         p.drop = make_drop(&d->drop);
+        p.drop_ld = drop_ld; p.n_off = n_off;
         p.res = d->res; p.ldr = d->ldr; p.r_bs0 = d->r_bs0; p.r_bs1 = d->r_bs1;
         p.out_scale = d->out_scale;
     }
@@ -556,6 +614,11 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
         else launch_cfg<1, 1, 16>(pl.cfg, grid, st, p);
     }
     GT_LAUNCH_CHECK();
+    if (acs_partial) {
+        const float sc = (d->a_drop.p > 0.f) ? 1.f : d->a_drop_sign;
+        int rc2 = gt_slab_reduce(acs_partial, d->M, (int)parts, d->M, sc, d->a_colsum, stream);
+        if (rc2) return rc2;
+    }
 
     if (pl.split > 1) {
         const int64_t total = batch * mn;
@@ -576,4 +639,35 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
         GT_LAUNCH_CHECK();
     }
     return 0;
+}
+
+// Widths just above a multiple of 128 (the merged-head width h*(d_k+p) = 144 of the Darcy model) would
+// waste most of a second 128-wide tile column: run the aligned part and the remainder as two launches,
+// the remainder on a narrow-tile configuration.
+extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream) {
+    if (!d) return GT_EINVAL;
+    const int rem = d->N % 128;
+    Plan pl;
+    // only when the aligned part alone fills the chip: two half-empty launches would serialise instead
+    if (d->N > 128 && rem != 0 && rem <= 64 && make_plan(d, &pl) == 0 && pl.split == 1 && pl.bn == 128 &&
+        (int64_t)pl.tiles_m * (d->N / 128) * d->batch0 * d->batch1 >= 512) {
+        const int n_main = d->N - rem;
+        gt_gemm_desc a = *d, b = *d;
+        a.N = n_main;
+        b.N = rem;
+        b.B = d->B + (d->layout_b == 0 ? (int64_t)n_main * d->ldb : (int64_t)n_main);
+        b.C = d->C + n_main;
+        if (d->bias) b.bias = d->bias + n_main;
+        if (d->rp) b.rp_b = d->rp_b + (int64_t)n_main * d->rp_ldb;
+        if (d->add) b.add = d->add + n_main;
+        if (d->pre) b.pre = d->pre + n_main;
+        if (d->aux) b.aux = d->aux + n_main;
+        if (d->res) b.res = d->res + n_main;
+        a.split_k = b.split_k = 1;
+        b.a_colsum = nullptr;
+        int rc = gemm_one(&a, d->N, 0, ws, ws_bytes, stream);
+        if (rc) return rc;
+        return gemm_one(&b, d->N, n_main, ws, ws_bytes, stream);
+    }
+    return gemm_one(d, d->N, 0, ws, ws_bytes, stream);
 }

@@ -33,7 +33,7 @@ class GtGemmDesc(C.Structure):
         ("B", C.c_void_p), ("ldb", C.c_int64), ("b_bs0", C.c_int64), ("b_bs1", C.c_int64),
         ("C", C.c_void_p), ("ldc", C.c_int64), ("c_bs0", C.c_int64), ("c_bs1", C.c_int64),
         ("a_drop", GtDropout), ("a_drop_sign", C.c_float),
-        ("a_drop_ld", C.c_int64), ("a_drop_bstride", C.c_int64),
+        ("a_drop_ld", C.c_int64), ("a_drop_bstride", C.c_int64), ("a_colsum", C.c_void_p),
         ("alpha", C.c_float), ("bias", C.c_void_p),
         ("rp", C.c_int32), ("rp_a", C.c_void_p), ("rp_lda", C.c_int64), ("rp_a_bs0", C.c_int64),
         ("rp_b", C.c_void_p), ("rp_ldb", C.c_int64),
@@ -113,7 +113,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.gt_abi_version() != 1:
+        if handle.gt_abi_version() != 2:
             raise RuntimeError("libgt_hip ABI version mismatch")
         _lib = handle
     return _lib
@@ -140,10 +140,12 @@ class Profile:
         global _prof
         _prof = None
 
-    def table(self):
+    def table(self, by_shape=False):
         """key -> dict(calls, ms, flops, bytes); call after torch.cuda.synchronize()."""
         out = {}
-        for key, flops, nbytes, e0, e1, _, _ in self.records:
+        for key, flops, nbytes, e0, e1, _, shape in self.records:
+            if by_shape and shape is not None:
+                key = f"{key} {tuple(shape)}"
             r = out.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
             r["calls"] += 1
             r["ms"] += e0.elapsed_time(e1)
@@ -264,7 +266,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          batch: Tuple[int, int] = (1, 1), a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), split_k: int = 1,
          alpha: float = 1.0, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
          a_drop: Optional[GtDropout] = None, a_drop_sign: float = 1.0, a_drop_ld: int = 0,
-         a_drop_bstride: int = 0,
+         a_drop_bstride: int = 0, a_colsum: Optional[torch.Tensor] = None,
          rp: int = 0, rp_a: Optional[torch.Tensor] = None, rp_lda: int = 0, rp_a_bs0: int = 0,
          rp_b: Optional[torch.Tensor] = None, rp_ldb: int = 0,
          add: Optional[torch.Tensor] = None, ldadd: int = 0, add_bs=(0, 0),
@@ -273,7 +275,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          aux_scale: float = 1.0, drop: Optional[GtDropout] = None,
          res: Optional[torch.Tensor] = None, ldr: int = 0, r_bs=(0, 0), out_scale: float = 1.0):
     """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics)."""
-    need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res)
+    need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, a_colsum)
     L = lib()
     d = GtGemmDesc()
     L.gt_gemm_desc_init(C.byref(d))
@@ -288,6 +290,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         d.a_drop = a_drop
         d.a_drop_ld, d.a_drop_bstride = a_drop_ld, a_drop_bstride
     d.a_drop_sign = a_drop_sign
+    d.a_colsum = ptr(a_colsum)
     d.alpha = alpha
     d.bias = ptr(bias)
     if rp:

@@ -167,13 +167,17 @@ class LinearFn(Function):
             dx = torch.empty(T, K, dtype=torch.float32, device=dev)
             H.gemm(gp, w, dx, T, K, N, layout_b=1, lda=N, ldb=K + pe, ldc=K)
             dx = dx.reshape(xshape)
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty(N, K + pe, dtype=torch.float32, device=dev)
-            H.gemm(gp, x2, dw, N, K, T, layout_a=1, layout_b=1, lda=N, ldb=K, ldc=K + pe, split_k=0)
+            if want_db:         # the bias gradient rides on the weight-gradient GEMM (row sums of its A)
+                db = torch.empty(N, dtype=torch.float32, device=dev)
+            H.gemm(gp, x2, dw, N, K, T, layout_a=1, layout_b=1, lda=N, ldb=K, ldc=K + pe, split_k=0,
+                   a_colsum=db)
             if pe:
                 H.gemm(gp, e2, dw[:, K:], N, pe, T, layout_a=1, layout_b=1, lda=N, ldb=pe, ldc=K + pe,
                        split_k=0)
-        if has_bias and ctx.needs_input_grad[2]:
+        elif want_db:
             db = H.colsum(gp, T, N, N)
         return dx, dw, db, de, None, None
 
@@ -251,13 +255,14 @@ class FeedForwardFn(Function):
             H.gemm(g, w2c, gh, T, f, dout, layout_b=1, lda=dout, ldb=f, ldc=f, a_drop=dro, a_drop_ld=dout,
                    aux_op=H.AUX_DSILU, aux=pre, ldaux=f,
                    drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None)
+        # bias gradients ride on the weight-gradient GEMMs (row sums of their masked A operand)
         dw2 = torch.empty(dout, f, dtype=torch.float32, device=dev)
+        db2 = torch.empty(dout, dtype=torch.float32, device=dev) if hb2 else None
         H.gemm(g, hid, dw2, dout, f, T, layout_a=1, layout_b=1, lda=dout, ldb=f, ldc=f, split_k=0,
-               a_drop=dro, a_drop_ld=dout)
-        db2 = H.colsum(g, T, dout, dout, a_drop=dro) if hb2 else None
+               a_drop=dro, a_drop_ld=dout, a_colsum=db2)
         dw1 = torch.empty(f, d, dtype=torch.float32, device=dev)
-        H.gemm(gh, xc, dw1, f, d, T, layout_a=1, layout_b=1, lda=f, ldb=d, ldc=d, split_k=0)
-        db1 = H.colsum(gh, T, f, f) if hb1 else None
+        db1 = torch.empty(f, dtype=torch.float32, device=dev) if hb1 else None
+        H.gemm(gh, xc, dw1, f, d, T, layout_a=1, layout_b=1, lda=f, ldb=d, ldc=d, split_k=0, a_colsum=db1)
         dx = torch.empty(T, d, dtype=torch.float32, device=dev)
         same = has_res and dout == d
         H.gemm(gh, w1c, dx, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=g if same else None, ldr=d)
@@ -349,8 +354,9 @@ class SimpleAttentionFn(Function):
         g = _c(gy).reshape(T, d)
         d_out = H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None
         dO3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
-        dbfc = H.colsum(g, T, d, d, a_drop=d_out, sign=sign) if hbf else None
+        dbfc = None
         if kind == "galerkin":
+            dbfc = torch.empty(d, dtype=torch.float32, device=dev) if hbf else None
             xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask = ctx.saved_tensors
             d_attn = H.dropout_desc(p_attn, salt, dev) if (p_attn > 0 and mask is None) else None
             Qp, Kp, Vp = out3[0], out3[1], out3[2]
@@ -358,7 +364,8 @@ class SimpleAttentionFn(Function):
             dPt = torch.empty(B, d, hD, dtype=torch.float32, device=dev)
             H.gemm(g, Qp, dPt, d, hD, n, layout_a=1, layout_b=1, lda=d, ldb=hD, ldc=hD, batch=(B, 1),
                    a_bs=(n * d, 0), b_bs=(n * hD, 0), c_bs=(d * hD, 0), split_k=0, a_drop=d_out,
-                   a_drop_sign=sign, a_drop_ld=d, a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0))
+                   a_drop_sign=sign, a_drop_ld=d, a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0),
+                   a_colsum=dbfc)       # + d(fc bias) = column sums of the masked, signed g
             # dQ'[b] = (sign*g*mask1)[b] P[b]^T
             H.gemm(g, P, dO3[0], n, hD, d, lda=d, ldb=d, ldc=hD, batch=(B, 1), a_bs=(n * d, 0),
                    b_bs=(hD * d, 0), c_bs=(n * hD, 0), a_drop=d_out, a_drop_sign=sign, a_drop_ld=d,
@@ -378,8 +385,9 @@ class SimpleAttentionFn(Function):
             scale = 1.0 / math.sqrt(Dr) / n
             asc = sign if d_out is None else 1.0
             dwpad = torch.empty(d, hD, dtype=torch.float32, device=dev)
+            dbfc = torch.empty(d, dtype=torch.float32, device=dev) if hbf else None
             H.gemm(g, att, dwpad, d, hD, T, layout_a=1, layout_b=1, lda=d, ldb=hD, ldc=hD, split_k=0,
-                   a_drop=d_out, a_drop_sign=sign, a_drop_ld=d, alpha=asc)
+                   a_drop=d_out, a_drop_sign=sign, a_drop_ld=d, alpha=asc, a_colsum=dbfc)
             dwfc = dwpad.reshape(d, h, DP)[:, :, :Dr].reshape(d, h * Dr)
             datt = torch.empty(T, hD, dtype=torch.float32, device=dev)
             H.gemm(g, wpad, datt, T, hD, d, layout_b=1, lda=d, ldb=hD, ldc=hD, a_drop=d_out,
@@ -398,8 +406,9 @@ class SimpleAttentionFn(Function):
                    a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
         dqkv, dgamma, dbeta = H.headnorm_bwd(dO3, qkv, gamma, stats, T, h, dk, p, norm_mask)
         dwqkv = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
-        H.gemm(dqkv, xc, dwqkv, 3 * d, d, T, layout_a=1, layout_b=1, lda=3 * d, ldb=d, ldc=d, split_k=0)
-        dbqkv = H.colsum(dqkv, T, 3 * d, 3 * d) if hbq else None
+        dbqkv = torch.empty(3 * d, dtype=torch.float32, device=dev) if hbq else None
+        H.gemm(dqkv, xc, dwqkv, 3 * d, d, T, layout_a=1, layout_b=1, lda=3 * d, ldb=d, ldc=d, split_k=0,
+               a_colsum=dbqkv)
         dx = torch.empty(T, d, dtype=torch.float32, device=dev)
         H.gemm(dqkv, wq, dx, T, d, 3 * d, layout_b=1, lda=3 * d, ldb=d, ldc=d, res=g if has_res else None,
                ldr=d)

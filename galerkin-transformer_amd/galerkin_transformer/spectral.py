@@ -152,8 +152,8 @@ class SpectralConv2dFn(Function):
         H.gemm(F1, dX1, dx, n, C, 2 * m, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B * n, 1),
                b_bs=(2 * m * C, 0), c_bs=(n * C, 0), res=dxl, ldr=C, r_bs=(n * C, 0))
         dwl = torch.empty(Co, C, **f32)
-        H.gemm(dpre, xc, dwl, Co, C, T, layout_a=1, layout_b=1, lda=Co, ldb=C, ldc=C, split_k=0)
-        dbl = H.colsum(dpre, T, Co, Co) if has_b else None
+        dbl = torch.empty(Co, **f32) if has_b else None
+        H.gemm(dpre, xc, dwl, Co, C, T, layout_a=1, layout_b=1, lda=Co, ldb=C, ldc=C, split_k=0, a_colsum=dbl)
         return dx, dwl, dbl, dw0, dw1, None, None
 
 
@@ -206,8 +206,8 @@ class SpectralConv1dFn(Function):
         H.gemm(F1, dX, dx, n, C, 2 * m, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B, 1),
                b_bs=(2 * m * C, 0), c_bs=(n * C, 0), res=dxl, ldr=C, r_bs=(n * C, 0))
         dwl = torch.empty(Co, C, **f32)
-        H.gemm(dpre, xc, dwl, Co, C, T, layout_a=1, layout_b=1, lda=Co, ldb=C, ldc=C, split_k=0)
-        dbl = H.colsum(dpre, T, Co, Co) if has_b else None
+        dbl = torch.empty(Co, **f32) if has_b else None
+        H.gemm(dpre, xc, dwl, Co, C, T, layout_a=1, layout_b=1, lda=Co, ldb=C, ldc=C, split_k=0, a_colsum=dbl)
         return dx, dwl, dbl, dw, None, None
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 1
+#define GT_ABI_VERSION 2
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -101,6 +101,11 @@ typedef struct gt_gemm_desc {
     /* prologue: stateless dropout mask on A.  The mask index of A's element (outer, inner) is
        z*a_drop_bstride + outer*a_drop_ld + inner  (outer = the lda-strided index).          */
     gt_dropout a_drop; float a_drop_sign; int64_t a_drop_ld, a_drop_bstride;
+    /* optional by-product (layout_a = 1 only): a_colsum[m] = sum over batch and k of A_z(m,k)*keepA(m,k),
+       i.e. the column sums of the [K, M] tensor behind A -- the bias gradient that goes with a weight
+       gradient (autograd of nn.Linear: layers.py:811,823,964,976).  Deterministic (per-slice partials in
+       `ws`, reduced in a fixed order). */
+    float* a_colsum;
 
     /* epilogue */
     float alpha;

@@ -375,3 +375,55 @@ def test_bilinear_resize_autograd_scale_factor(H, gpu_device):
     assert rel_l2(y, ref) < KTOL and rel_l2(xg.grad, gref) < KTOL
     with pytest.raises(NotImplementedError):
         ops.bilinear_resize(torch.zeros(1, 6, 6, 3, device=gpu_device), (4, 4), in_nhwc=True)
+
+
+@pytest.mark.parametrize("N", [144, 192, 160 + 128])
+@pytest.mark.parametrize("lb", [0, 1])
+def test_gemm_width_remainder_split(H, gpu_device, N, lb):
+    """Widths just above a multiple of 128 run as two launches (aligned part + narrow remainder): every
+    epilogue term (bias, rank update, add, pre, aux, dropout index, residual) must follow the column
+    offset.  144 = h*(d_k+p) of the Darcy model."""
+    dev = gpu_device
+    H.set_seed(4321, dev)
+    M, K, p = 333, 136, 2
+    A = rnd(M, K, dev=dev, seed=30)
+    Bm = rnd(N, K + p, dev=dev, seed=31, scale=0.3) if lb == 0 else rnd(K, N, dev=dev, seed=31, scale=0.3)
+    bias, ea = rnd(N, dev=dev, seed=32), rnd(M, p, dev=dev, seed=33)
+    eb = rnd(N, p, dev=dev, seed=34)
+    add, aux, res = rnd(M, N, dev=dev, seed=35), rnd(M, N, dev=dev, seed=36), rnd(M, N, dev=dev, seed=37)
+    d = H.dropout_desc(0.25, salt=5, device=dev)
+    mask = H.dropout_apply(torch.ones(M * N, device=dev), d).reshape(M, N).double()
+    Cc, pre = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    H.gemm(A, Bm, Cc, M, N, K, layout_b=lb, lda=K, ldb=(K + p if lb == 0 else N), ldc=N, bias=bias, rp=p, rp_a=ea,
+           rp_lda=p, rp_b=eb, rp_ldb=p, add=add, ldadd=N, pre=pre, ldpre=N, act=H.ACT_SILU, aux_op=H.AUX_MUL,
+           aux=aux, ldaux=N, aux_scale=0.5, drop=d, res=res, ldr=N, out_scale=-1.0)
+    torch.cuda.synchronize()
+    Bk = Bm[:, :K].double().t() if lb == 0 else Bm.double()
+    p64 = A.double() @ Bk + bias.double() + ea.double() @ eb.double().t() + add.double()
+    assert rel_l2(pre, p64) < KTOL
+    ref = res.double() - torch.nn.functional.silu(p64) * aux.double() * 0.5 * mask
+    assert rel_l2(Cc, ref) < KTOL
+
+
+@pytest.mark.parametrize("split,batch,p_drop,sign", [(1, 1, 0.0, 1.0), (0, 1, 0.0, -1.0), (7, 1, 0.3, -1.0),
+                                                     (1, 5, 0.3, 1.0), (0, 3, 0.0, -1.0)])
+def test_gemm_a_colsum_byproduct(H, gpu_device, split, batch, p_drop, sign):
+    """Bias gradient as a by-product of the weight-gradient GEMM: a_colsum[m] = sum_{z,k} A_z(m,k)*keep,
+    through split-K, batching, the dropout prologue and the sign convention of gt_colsum."""
+    dev = gpu_device
+    H.set_seed(99, dev)
+    Kt, M, N = 2500, 200, 72
+    G = rnd(batch, Kt, M, dev=dev, seed=40)
+    X = rnd(batch, Kt, N, dev=dev, seed=41)
+    d = H.dropout_desc(p_drop, salt=9, device=dev) if p_drop > 0 else None
+    mask = (H.dropout_apply(torch.ones(batch * Kt * M, device=dev), d).reshape(batch, Kt, M).double()
+            if d is not None else torch.ones(batch, Kt, M, dtype=torch.float64, device=dev))
+    Cc = torch.empty(batch, M, N, device=dev)
+    cs = torch.empty(M, device=dev)
+    H.gemm(G, X, Cc, M, N, Kt, layout_a=1, layout_b=1, lda=M, ldb=N, ldc=N, batch=(batch, 1),
+           a_bs=(Kt * M, 0), b_bs=(Kt * N, 0), c_bs=(M * N, 0), split_k=split, a_drop=d, a_drop_sign=sign,
+           a_drop_ld=M, a_drop_bstride=Kt * M, alpha=(sign if d is None else 1.0), a_colsum=cs)
+    torch.cuda.synchronize()
+    Gm = sign * G.double() * mask
+    assert rel_l2(Cc, Gm.transpose(1, 2) @ X.double()) < KTOL
+    assert rel_l2(cs, Gm.sum((0, 1))) < KTOL
