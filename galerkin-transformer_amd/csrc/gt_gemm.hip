@@ -13,6 +13,7 @@
 // ds_write_b32 of k-contiguous operands and the ds_read_b128 of the MFMA loop conflict-free.
 #include "gt_common.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -20,7 +21,7 @@ namespace gt {
 
 struct GemmP {
     int M, N, K;
-    int tiles_n, batch1, k_chunk;
+    int tiles_m, tiles_n, batch1, k_chunk, n_split, n_batch, n_work;
     const float* A; int64_t lda, a_bs0, a_bs1;
     const float* B; int64_t ldb, b_bs0, b_bs1;
     float* C; int64_t ldc, c_bs0, c_bs1, c_split;
@@ -144,6 +145,128 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #endif
 }
 
+// Fused epilogue shared by both kernels.  The calling lane holds, for each of the MT x NT 16x16
+// accumulator tiles, rows  mw0 + MT*(4*kq + r) + s  (r = 0..3) and columns  nb + t.
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, const f32x4 (&acc)[MT][NT], int mw0, int nb,
+                                              int z, int b0, int b1, int sidx, int kq) {
+        if (nb >= p.N) return;
+#ifdef GT_ABL_NOSTORE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+    const bool full = (nb + NT <= p.N);
+    const int64_t coff = b0 * p.c_bs0 + b1 * p.c_bs1 + (int64_t)sidx * p.c_split;
+    float* __restrict__ C = p.C + coff;
+
+    float biasv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
+    const uint32_t dkey = drop_key_dev(p.drop);
+
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mw0 + MT * (4 * kq + r) + s;
+            if (m >= p.M) continue;
+            float v[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = acc[s][t][r];
+            float* cp = C + (int64_t)m * p.ldc + nb;
+            if (p.raw) {
+                if (full && p.c_vec && NT == 4) {
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (nb + t < p.N) cp[t] = v[t];
+                }
+                continue;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = p.alpha * v[t] + biasv[t];
+            if (p.rp) {
+                const float* ra_ = p.rp_a + b0 * p.rp_a_bs0 + (int64_t)m * p.rp_lda;
+                for (int j = 0; j < p.rp; ++j) {
+                    const float aj = ra_[j];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (nb + t < p.N) v[t] += aj * p.rp_b[(int64_t)(nb + t) * p.rp_ldb + j];
+                }
+            }
+            const bool vec4 = full && p.c_vec && NT == 4;
+            // tile-row accessors: one 16-byte access when the row segment is aligned, scalars otherwise
+            auto ldrow = [&](const float* src, float (&o)[NT]) {
+                if (vec4) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) o[t] = t4[t & 3];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) o[t] = (nb + t < p.N) ? src[t] : 0.f;
+                }
+            };
+            if (p.add) {
+                float ad[NT];
+                ldrow(p.add + b0 * p.add_bs0 + b1 * p.add_bs1 + (int64_t)m * p.ldadd + nb, ad);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] += ad[t];
+            }
+            if (p.pre) {
+                float* pp = p.pre + ((int64_t)z * p.M + m) * p.ldpre + nb;
+                if (vec4) {
+                    *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1 % NT], v[2 % NT], v[3 % NT]};
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (nb + t < p.N) pp[t] = v[t];
+                }
+            }
+            if (p.act == GT_ACT_RELU) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = fmaxf(v[t], 0.f);
+            } else if (p.act == GT_ACT_SILU) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = silu_f(v[t]);
+            }
+            if (p.aux_op) {
+                float ax[NT];
+                ldrow(p.aux + b0 * p.aux_bs0 + b1 * p.aux_bs1 + (int64_t)m * p.ldaux + nb, ax);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float a = ax[t];
+                    v[t] *= (p.aux_op == GT_AUX_GT0)   ? (a > 0.f ? p.aux_scale : 0.f)
+                            : (p.aux_op == GT_AUX_DSILU) ? dsilu_f(a)
+                                                         : a * p.aux_scale;
+                }
+            }
+            if (p.drop.thresh) {
+                const uint32_t di = (uint32_t)(((int64_t)z * p.M + m) * p.drop_ld + p.n_off + nb);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] *= drop_mul(p.drop, dkey, di + t);
+            }
+            if (p.res) {
+                float rv[NT];
+                ldrow(p.res + b0 * p.r_bs0 + b1 * p.r_bs1 + (int64_t)m * p.ldr + nb, rv);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = rv[t] + p.out_scale * v[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] *= p.out_scale;
+            }
+            if (full && p.c_vec && NT == 4) {
+                *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            } else if (full && p.c_vec && NT == 2) {
+                *reinterpret_cast<f32x2*>(cp) = f32x2{v[0], v[1]};
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (nb + t < p.N) cp[t] = v[t];
+            }
+        }
+    }
+}
+
 template <int LA, int LB, int MT, int NT, int WM, int WN, int BK>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     constexpr int BM = WM * 16 * MT, BN = WN * 16 * NT, T = WM * WN * 64;
@@ -252,121 +375,206 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     }
 
     // ------------------------------- epilogue -------------------------------------------------
-    const int nb = n0 + wn * 16 * NT + NT * li;        // first of this lane's NT columns
-    if (nb >= p.N) return;
-#ifdef GT_ABL_NOSTORE
-    if (acc[0][0][0] != 12345.678f) return;
+    gemm_epilogue<MT, NT>(p, acc, m0 + wm * 16 * MT, n0 + wn * 16 * NT + NT * li, z, b0, b1, (int)blockIdx.y, kq);
+}
+
+// =================================================================================================
+// Streamed kernel (aligned operands, 128-wide N tiles): persistent blocks, direct global->LDS loads.
+//
+// The v1 kernel above runs every tile as load -> MFMA -> store with all co-resident blocks in the same
+// phase, so HBM and the matrix pipe take turns.  Here a block walks a list of (tile, K-slice) items as ONE
+// stream of 32-deep K stages: stage g+1 is requested with `global_load_lds_dwordx4` (no VGPR staging, no
+// ds_write pass) right after the barrier that publishes stage g, and the stream does not stop at a tile
+// boundary -- the first stage of the next tile is in flight while the current tile's last MFMAs and its
+// epilogue run, and the epilogue's stores drain under the next tile's MFMAs.
+//
+// LDS images (per stage, A then B), chosen so that a direct load (wave-uniform base + lane*16 B) lands
+// conflict-free for the MFMA fragment reads:
+//   k-contiguous operand (L==0):  [rows][32]  with the 16-byte granule g of row r stored at slot
+//                                 g ^ ((r>>2)&7)           -> lane reads one float per (row, k)
+//   x-contiguous operand (L==1):  [32][BX]    with column granules XOR-ed by ((k>>2)&3)<<1 (same image
+//                                 as v1)                   -> lane reads MT/NT consecutive floats
+// The swizzles are applied on the SOURCE address (the LDS side of a direct load is linear).
+// Out-of-range rows / K-tail granules read a 16-byte device zero instead.
+__device__ __attribute__((aligned(16))) float gt_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+struct SItem {
+    int m0, n0, z, b0, b1, sidx, kbeg, kend, nk;
+    const float* A;
+    const float* B;
+    int64_t adoff;
+};
+
+// second launch-bound argument = waves per SIMD the register allocation must leave room for: the LDS
+// footprint admits 2 (128-row tiles) or 3 (64-row tiles) blocks per CU
+template <int LA, int LB, int MT>
+__global__ __launch_bounds__(256, (MT == 4 ? 2 : 3)) void gemm_stream_kernel(const GemmP p) {
+    constexpr int NT = 4, WN = 2, BK = 32, T = 256;
+    constexpr int BM = 32 * MT, BN = 128;
+    constexpr int SA = BM * BK, SB = BN * BK, STAGE = SA + SB;
+    constexpr int NIA = BM / 32, NIB = BN / 32;               // 1-KiB load instructions per wave per stage
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, kq = lane >> 4;
+    const uint32_t akey = drop_key_dev(p.a_drop);
+
+    const int per_xcd = (p.n_work + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slots = gridDim.x >> 3;
+    int jpos = blockIdx.x >> 3;
+
+    auto decode = [&](int j, SItem& it) -> bool {
+        const int w = xcd * per_xcd + j;
+        if (j >= per_xcd || w >= p.n_work) return false;
+        const int tiles = p.tiles_m * p.tiles_n;
+        const int t = w % tiles, r = w / tiles;
+        it.sidx = r % p.n_split;
+        it.z = r / p.n_split;
+        it.m0 = (t / p.tiles_n) * BM;
+        it.n0 = (t % p.tiles_n) * BN;
+        it.b0 = it.z / p.batch1;
+        it.b1 = it.z % p.batch1;
+        it.kbeg = it.sidx * p.k_chunk;
+        it.kend = min(p.K, it.kbeg + p.k_chunk);
+        it.nk = (it.kend - it.kbeg + BK - 1) / BK;
+        it.A = p.A + it.b0 * p.a_bs0 + it.b1 * p.a_bs1;
+        it.B = p.B + it.b0 * p.b_bs0 + it.b1 * p.b_bs1;
+        it.adoff = (int64_t)it.z * p.a_drop_bstride;
+        return true;
+    };
+
+    // request one 32-deep stage (A and B tiles of item `it` at k0) into buffer `buf`
+    auto issue = [&](const SItem& it, int k0, int buf) {
+        float* sa = smem + buf * STAGE;
+        float* sb = sa + SA;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int q = wave * NIA + i;                      // 1-KiB chunk of the A image
+            const float* src;
+            if (LA == 0) {
+                const int row = 8 * q + (lane >> 3), slot = lane & 7;
+                const int g = slot ^ ((row >> 2) & 7);
+                const int m = it.m0 + row, k = k0 + 4 * g;
+                src = (m < p.M && k < it.kend) ? it.A + (int64_t)m * p.lda + k : gt_zero16;
+            } else {
+                constexpr int GPR = BM / 4;                    // granules per k-row
+                const int e = q * 64 + lane, kr = e / GPR, pc = e % GPR;
+                const int g = pc ^ ((((kr >> 2) & 3) << 1) & (GPR - 1));
+                const int k = k0 + kr, m = it.m0 + 4 * g;
+                src = (k < it.kend && m < p.M) ? it.A + (int64_t)k * p.lda + m : gt_zero16;
+            }
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(sa + q * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) {
+            const int q = wave * NIB + i;
+            const float* src;
+            if (LB == 0) {
+                const int row = 8 * q + (lane >> 3), slot = lane & 7;
+                const int g = slot ^ ((row >> 2) & 7);
+                const int n = it.n0 + row, k = k0 + 4 * g;
+                src = (n < p.N && k < it.kend) ? it.B + (int64_t)n * p.ldb + k : gt_zero16;
+            } else {
+                constexpr int GPR = BN / 4;
+                const int e = q * 64 + lane, kr = e / GPR, pc = e % GPR;
+                const int g = pc ^ ((((kr >> 2) & 3) << 1) & (GPR - 1));
+                const int k = k0 + kr, n = it.n0 + 4 * g;
+                src = (k < it.kend && n < p.N) ? it.B + (int64_t)k * p.ldb + n : gt_zero16;
+            }
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(sb + q * 256), 16, 0, 0);
+        }
+    };
+
+    SItem cur, nxt;
+    bool have = decode(jpos, cur);
+    int g = 0;                                                 // running stage counter -> LDS buffer g&1
+    if (have) issue(cur, cur.kbeg, 0);
+
+    while (have) {
+        jpos += slots;
+        const bool have_next = decode(jpos, nxt);
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int s = 0; s < MT; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float asum[MT];
+#pragma unroll
+        for (int s = 0; s < MT; ++s) asum[s] = 0.f;
+        const bool do_acs = (LA == 1) && p.acs != nullptr && cur.n0 == 0 && wn == 0;
+
+        for (int kt = 0; kt < cur.nk; ++kt, ++g) {
+            // stage g has landed for this wave (vmcnt) and for everybody (barrier); everybody is also done
+            // reading the other buffer, which the next request overwrites
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifndef GT_ABL_NOLOAD
+            if (kt + 1 < cur.nk) issue(cur, cur.kbeg + (kt + 1) * BK, (g + 1) & 1);
+            else if (have_next) issue(nxt, nxt.kbeg, (g + 1) & 1);
 #endif
-    const bool full = (nb + NT <= p.N);
-    const int64_t coff = b0 * p.c_bs0 + b1 * p.c_bs1 + (int64_t)blockIdx.y * p.c_split;
-    float* __restrict__ C = p.C + coff;
-
-    float biasv[NT];
+            const float* __restrict__ cA = smem + (g & 1) * STAGE;
+            const float* __restrict__ cB = cA + SA;
+            const int kbase = cur.kbeg + kt * BK;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
-    const uint32_t dkey = drop_key_dev(p.drop);
-
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                const int k = 4 * ks + kq;
+                float a[MT], b[NT];
+                if (LA == 0) {
 #pragma unroll
-    for (int s = 0; s < MT; ++s) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * 16 * MT + MT * (4 * kq + r) + s;
-            if (m >= p.M) continue;
-            float v[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = acc[s][t][r];
-            float* cp = C + (int64_t)m * p.ldc + nb;
-            if (p.raw) {
-                if (full && p.c_vec && NT == 4) {
-                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                    for (int s = 0; s < MT; ++s) {
+                        const int row = wm * 16 * MT + MT * li + s;
+                        a[s] = cA[row * 32 + 4 * (ks ^ ((row >> 2) & 7)) + kq];
+                    }
                 } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (nb + t < p.N) cp[t] = v[t];
+                    lds_frag<MT>(cA + k * BM + ((wm * 16 * MT + MT * li) ^ (((ks & 3) << 3) & (BM - 1))), a);
                 }
-                continue;
-            }
+                if (LB == 0) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = p.alpha * v[t] + biasv[t];
-            if (p.rp) {
-                const float* ra_ = p.rp_a + b0 * p.rp_a_bs0 + (int64_t)m * p.rp_lda;
-                for (int j = 0; j < p.rp; ++j) {
-                    const float aj = ra_[j];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (nb + t < p.N) v[t] += aj * p.rp_b[(int64_t)(nb + t) * p.rp_ldb + j];
-                }
-            }
-            const bool vec4 = full && p.c_vec && NT == 4;
-            // tile-row accessors: one 16-byte access when the row segment is aligned, scalars otherwise
-            auto ldrow = [&](const float* src, float (&o)[NT]) {
-                if (vec4) {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(src);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) o[t] = t4[t & 3];
+                    for (int t = 0; t < NT; ++t) {
+                        const int row = wn * 16 * NT + NT * li + t;
+                        b[t] = cB[row * 32 + 4 * (ks ^ ((row >> 2) & 7)) + kq];
+                    }
                 } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) o[t] = (nb + t < p.N) ? src[t] : 0.f;
+                    lds_frag<NT>(cB + k * BN + ((wn * 16 * NT + NT * li) ^ (((ks & 3) << 3) & (BN - 1))), b);
                 }
-            };
-            if (p.add) {
-                float ad[NT];
-                ldrow(p.add + b0 * p.add_bs0 + b1 * p.add_bs1 + (int64_t)m * p.ldadd + nb, ad);
+                if (p.a_drop.thresh) {                          // dropout mask on A, regenerated from its index
 #pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] += ad[t];
-            }
-            if (p.pre) {
-                float* pp = p.pre + ((int64_t)z * p.M + m) * p.ldpre + nb;
-                if (vec4) {
-                    *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1 % NT], v[2 % NT], v[3 % NT]};
-                } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (nb + t < p.N) pp[t] = v[t];
+                    for (int s = 0; s < MT; ++s) {
+                        const int m = cur.m0 + wm * 16 * MT + MT * li + s, kk = kbase + k;
+                        const int64_t di = cur.adoff + (LA == 0 ? (int64_t)m * p.a_drop_ld + kk
+                                                                : (int64_t)kk * p.a_drop_ld + m);
+                        a[s] *= drop_mul(p.a_drop, akey, (uint32_t)di);
+                    }
                 }
-            }
-            if (p.act == GT_ACT_RELU) {
+                if (LA == 1 && do_acs) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] = fmaxf(v[t], 0.f);
-            } else if (p.act == GT_ACT_SILU) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] = silu_f(v[t]);
-            }
-            if (p.aux_op) {
-                float ax[NT];
-                ldrow(p.aux + b0 * p.aux_bs0 + b1 * p.aux_bs1 + (int64_t)m * p.ldaux + nb, ax);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float a = ax[t];
-                    v[t] *= (p.aux_op == GT_AUX_GT0)   ? (a > 0.f ? p.aux_scale : 0.f)
-                            : (p.aux_op == GT_AUX_DSILU) ? dsilu_f(a)
-                                                         : a * p.aux_scale;
+                    for (int s = 0; s < MT; ++s) asum[s] += a[s];
                 }
-            }
-            if (p.drop.thresh) {
-                const uint32_t di = (uint32_t)(((int64_t)z * p.M + m) * p.drop_ld + p.n_off + nb);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] *= drop_mul(p.drop, dkey, di + t);
-            }
-            if (p.res) {
-                float rv[NT];
-                ldrow(p.res + b0 * p.r_bs0 + b1 * p.r_bs1 + (int64_t)m * p.ldr + nb, rv);
+                for (int s = 0; s < MT; ++s)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] = rv[t] + p.out_scale * v[t];
-            } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] *= p.out_scale;
-            }
-            if (full && p.c_vec && NT == 4) {
-                *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-            } else if (full && p.c_vec && NT == 2) {
-                *reinterpret_cast<f32x2*>(cp) = f32x2{v[0], v[1]};
-            } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (nb + t < p.N) cp[t] = v[t];
+                    for (int t = 0; t < NT; ++t) acc[s][t] = mfma16(a[s], b[t], acc[s][t]);
             }
         }
+
+        if (LA == 1 && do_acs) {        // row sums of A: combine the 4 k-lanes; lanes kq == 0 hold MT rows each
+#pragma unroll
+            for (int s = 0; s < MT; ++s) {
+                float v = asum[s];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int m = cur.m0 + wm * 16 * MT + MT * li + s;
+                if (kq == 0 && m < p.M)
+                    p.acs[((int64_t)cur.sidx * p.n_batch + cur.z) * p.M + m] = v;
+            }
+        }
+        gemm_epilogue<MT, NT>(p, acc, cur.m0 + wm * 16 * MT, cur.n0 + wn * 16 * NT + NT * li, cur.z, cur.b0, cur.b1,
+                              cur.sidx, kq);
+        cur = nxt;
+        have = have_next;
     }
 }
 
@@ -432,7 +640,42 @@ static void launch_cfg(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
     }
 }
 
-struct Plan { int cfg, bm, bn, bk, tiles_m, tiles_n, split, k_chunk; };
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;      // MI355X
+        n = v;
+    }
+    return n;
+}
+
+// Persistent launch: the grid never exceeds what is resident at once (a block runs until its share of the
+// work list is empty, so a block waiting for a slot would serialise behind the others).
+template <int LA, int LB, int MT>
+static void launch_stream(hipStream_t st, const GemmP& p) {
+    static const int per_cu = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_stream_kernel<LA, LB, MT>, 256, 0) != hipSuccess ||
+            n < 1)
+            n = 1;
+        return std::min(n, 4);
+    }();
+    int nblk = std::min(p.n_work, num_cus() * per_cu);
+    if (const char* e = getenv("GT_GEMM_BLOCKS")) nblk = std::min(p.n_work, std::max(1, atoi(e)));
+    nblk = ((nblk + 7) / 8) * 8;
+    if (getenv("GT_GEMM_DEBUG"))
+        fprintf(stderr, "[gt_gemm] stream<%d,%d,%d> M=%d N=%d K=%d work=%d per_cu=%d grid=%d\n", LA, LB, MT, p.M, p.N,
+                p.K, p.n_work, per_cu, nblk);
+    hipLaunchKernelGGL((gemm_stream_kernel<LA, LB, MT>), dim3(nblk), dim3(256), 0, st, p);
+}
+
+struct Plan { int cfg, bm, bn, bk, tiles_m, tiles_n, split, k_chunk, stream; };
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline bool m4(int64_t v) { return (v & 3) == 0; }
 
 static bool has_epilogue(const gt_gemm_desc* d) {
     return d->bias || d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res ||
@@ -461,6 +704,14 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     // short-K token GEMMs are prologue/epilogue-bound and run better with the smaller stage
     pl->bk = (d->layout_a == 1 && d->layout_b == 1 && d->K >= 512) ? 32 : 16;
     if (const char* e = getenv("GT_GEMM_BK")) pl->bk = (atoi(e) == 16) ? 16 : 32;
+    // streamed kernel: 128-wide N tiles, 16-byte aligned operands, whole granules at every edge
+    // (measured: it wins from K = 256 up; at K = 128 a tile is only 4 stages long and the v1 kernel's
+    // higher occupancy hides the per-tile epilogue better)
+    pl->stream = (c <= 1) && d->K >= 256 && (d->K & 3) == 0 && al16(d->A) && al16(d->B) && m4(d->lda) &&
+                 m4(d->ldb) && m4(d->a_bs0) && m4(d->a_bs1) && m4(d->b_bs0) && m4(d->b_bs1) &&
+                 (d->layout_a == 0 || (d->M & 3) == 0) && (d->layout_b == 0 || (d->N & 3) == 0);
+    if (const char* e = getenv("GT_GEMM_STREAM")) pl->stream = pl->stream && atoi(e) != 0;
+    if (pl->stream) pl->bk = 32;
     pl->bm = kCfgs[c].wm * 16 * kCfgs[c].mt;
     pl->bn = kCfgs[c].wn * 16 * kCfgs[c].nt;
     pl->tiles_m = ceil_div(d->M, pl->bm);
@@ -487,8 +738,6 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     return 0;
 }
 
-static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-static inline bool m4(int64_t v) { return (v & 3) == 0; }
 
 }  // namespace gt
 
@@ -546,7 +795,11 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     GemmP p;
     memset(&p, 0, sizeof(p));
     p.M = d->M; p.N = d->N; p.K = d->K;
-    p.tiles_n = pl.tiles_n; p.batch1 = d->batch1; p.k_chunk = pl.k_chunk;
+    p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.batch1 = d->batch1; p.k_chunk = pl.k_chunk;
+    p.n_split = pl.split; p.n_batch = (int)batch;
+    const int64_t n_work64 = (int64_t)pl.tiles_m * pl.tiles_n * pl.split * batch;
+    if (n_work64 > (1 << 30)) return GT_EINVAL;
+    p.n_work = (int)n_work64;
     p.A = d->A; p.lda = d->lda; p.a_bs0 = d->a_bs0; p.a_bs1 = d->a_bs1;
     p.B = d->B; p.ldb = d->ldb; p.b_bs0 = d->b_bs0; p.b_bs1 = d->b_bs1;
     p.a_vec = al16(d->A) && m4(d->lda) && m4(d->a_bs0) && m4(d->a_bs1);
@@ -602,7 +855,19 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
 
     dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split, (unsigned)batch);
     const int lay = d->layout_a * 2 + d->layout_b;
-    if (pl.bk == 32) {
+    if (pl.stream) {
+        if (pl.cfg == 0) {
+            if (lay == 0) launch_stream<0, 0, 4>(st, p);
+            else if (lay == 1) launch_stream<0, 1, 4>(st, p);
+            else if (lay == 2) launch_stream<1, 0, 4>(st, p);
+            else launch_stream<1, 1, 4>(st, p);
+        } else {
+            if (lay == 0) launch_stream<0, 0, 2>(st, p);
+            else if (lay == 1) launch_stream<0, 1, 2>(st, p);
+            else if (lay == 2) launch_stream<1, 0, 2>(st, p);
+            else launch_stream<1, 1, 2>(st, p);
+        }
+    } else if (pl.bk == 32) {
         if (lay == 0) launch_cfg<0, 0, 32>(pl.cfg, grid, st, p);
         else if (lay == 1) launch_cfg<0, 1, 32>(pl.cfg, grid, st, p);
         else if (lay == 2) launch_cfg<1, 0, 32>(pl.cfg, grid, st, p);

@@ -145,48 +145,110 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const ResizeP p) {
 // p.x = upstream gradient g (output-shaped, layout G_NHWC), p.y = dx (input-shaped, layout DX_NHWC),
 // p.gate = saved activated forward output (same shape/layout as g) or null.  Hi/Wi are the sizes of
 // the FORWARD input (= dx), Ho/Wo of the forward output (= g).  blockIdx.y = input row iy.
+//
+// The outputs that touch input index i form a contiguous range; their weights are gathered once per
+// thread (x) / per block (y) into a small register table, so the channel loop is pure load + fma.
+constexpr int RS_MAXT = 6;          // taps per axis held in registers (covers up-sampling factors < 2.5)
+struct Taps {
+    int lo, n;
+    float w[RS_MAXT];
+};
+__device__ __forceinline__ Taps taps_of(int i, float scale, int ni, int no) {
+    Taps t;
+    int lo = first_out(i, scale, no);
+    while (lo < no && axis_of(lo, scale, ni).i0 < i - 1) ++lo;
+    t.lo = lo;
+    t.n = 0;
+#pragma unroll
+    for (int j = 0; j < RS_MAXT; ++j) t.w[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < RS_MAXT; ++j) {
+        const int o = lo + j;
+        if (o < no) {
+            const Axis a = axis_of(o, scale, ni);
+            if (a.i0 <= i) {
+                t.w[j] = (a.i0 == i ? a.l0 : 0.f) + (a.i1 == i ? a.l1 : 0.f);
+                t.n = j + 1;
+            }
+        }
+    }
+    // more than RS_MAXT contributing outputs (very strong up-sampling): flag with n = -1
+    if (lo + RS_MAXT < no && axis_of(lo + RS_MAXT, scale, ni).i0 <= i) t.n = -1;
+    return t;
+}
+
 template <bool G_NHWC, bool DX_NHWC>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const ResizeP p) {
     __shared__ float tile[RS_TC][RS_TX + 1];
     const int t = threadIdx.x;
     const int xt = blockIdx.x % p.xtiles, ct = blockIdx.x / p.xtiles;
     const int ix0 = xt * RS_TX, c0 = ct * RS_TC, iy = blockIdx.y, b = blockIdx.z;
-
-    // output rows touching iy: i0(oy) in {iy-1, iy}
-    int oy_lo = first_out(iy, p.sy, p.Ho);
-    while (oy_lo < p.Ho && axis_of(oy_lo, p.sy, p.Hi).i0 < iy - 1) ++oy_lo;
-    int oy_hi = oy_lo;
-    while (oy_hi < p.Ho && axis_of(oy_hi, p.sy, p.Hi).i0 <= iy) ++oy_hi;
+    const Taps ty = taps_of(iy, p.sy, p.Hi, p.Ho);
 
     if (!G_NHWC) {
         const int ix_l = t & 31, cg = t >> 5;
         const int ix = ix0 + ix_l;
         if (ix < p.Wi) {
-            int ox_lo = first_out(ix, p.sx, p.Wo);
-            while (ox_lo < p.Wo && axis_of(ox_lo, p.sx, p.Wi).i0 < ix - 1) ++ox_lo;
-            int ox_hi = ox_lo;
-            while (ox_hi < p.Wo && axis_of(ox_hi, p.sx, p.Wi).i0 <= ix) ++ox_hi;
-#pragma unroll 1
-            for (int k = 0; k < 8; ++k) {
-                const int c_l = cg + 8 * k, c = c0 + c_l;
-                if (c >= p.C) break;
-                float acc = 0.f;
-                for (int oy = oy_lo; oy < oy_hi; ++oy) {
-                    const Axis ay = axis_of(oy, p.sy, p.Hi);
-                    const float wy = (ay.i0 == iy ? ay.l0 : 0.f) + (ay.i1 == iy ? ay.l1 : 0.f);
-                    const int64_t ro = addr<false>(b, c, oy, 0, p.C, p.Ho, p.Wo);
-                    float racc = 0.f;
-                    for (int ox = ox_lo; ox < ox_hi; ++ox) {
-                        const Axis ax = axis_of(ox, p.sx, p.Wi);
-                        const float wx = (ax.i0 == ix ? ax.l0 : 0.f) + (ax.i1 == ix ? ax.l1 : 0.f);
-                        float g = p.x[ro + ox];
-                        if (p.gate && !(p.gate[ro + ox] > 0.f)) g = 0.f;
-                        racc = fmaf(wx, g, racc);
+            const Taps tx = taps_of(ix, p.sx, p.Wi, p.Wo);
+            if (ty.n >= 0 && tx.n >= 0) {
+                float accs[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {           // 8 independent channels in flight per lane
+                    const int c = c0 + cg + 8 * k;
+                    float acc = 0.f;
+                    if (c < p.C) {
+#pragma unroll
+                        for (int jy = 0; jy < RS_MAXT; ++jy) {
+                            if (jy < ty.n) {
+                                const int64_t ro = addr<false>(b, c, ty.lo + jy, tx.lo, p.C, p.Ho, p.Wo);
+                                float racc = 0.f;
+#pragma unroll
+                                for (int jx = 0; jx < RS_MAXT; ++jx) {
+                                    if (jx < tx.n) {
+                                        float g = p.x[ro + jx];
+                                        if (p.gate && !(p.gate[ro + jx] > 0.f)) g = 0.f;
+                                        racc = fmaf(tx.w[jx], g, racc);
+                                    }
+                                }
+                                acc = fmaf(ty.w[jy], racc, acc);
+                            }
+                        }
                     }
-                    acc = fmaf(wy, racc, acc);
+                    accs[k] = acc;
                 }
-                if (!DX_NHWC) p.y[addr<false>(b, c, iy, ix, p.C, p.Hi, p.Wi)] = acc;
-                else tile[c_l][ix_l] = acc;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int c_l = cg + 8 * k, c = c0 + c_l;
+                    if (c < p.C) {
+                        if (!DX_NHWC) p.y[addr<false>(b, c, iy, ix, p.C, p.Hi, p.Wi)] = accs[k];
+                        else tile[c_l][ix_l] = accs[k];
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < 8; ++k) {           // generic path: arbitrary number of taps
+                    const int c_l = cg + 8 * k, c = c0 + c_l;
+                    if (c >= p.C) break;
+                    float acc = 0.f;
+                    for (int oy = ty.lo; oy < p.Ho; ++oy) {
+                        const Axis ay = axis_of(oy, p.sy, p.Hi);
+                        if (ay.i0 > iy) break;
+                        const float wy = (ay.i0 == iy ? ay.l0 : 0.f) + (ay.i1 == iy ? ay.l1 : 0.f);
+                        const int64_t ro = addr<false>(b, c, oy, 0, p.C, p.Ho, p.Wo);
+                        float racc = 0.f;
+                        for (int ox = tx.lo; ox < p.Wo; ++ox) {
+                            const Axis ax = axis_of(ox, p.sx, p.Wi);
+                            if (ax.i0 > ix) break;
+                            const float wx = (ax.i0 == ix ? ax.l0 : 0.f) + (ax.i1 == ix ? ax.l1 : 0.f);
+                            float g = p.x[ro + ox];
+                            if (p.gate && !(p.gate[ro + ox] > 0.f)) g = 0.f;
+                            racc = fmaf(wx, g, racc);
+                        }
+                        acc = fmaf(wy, racc, acc);
+                    }
+                    if (!DX_NHWC) p.y[addr<false>(b, c, iy, ix, p.C, p.Hi, p.Wi)] = acc;
+                    else tile[c_l][ix_l] = acc;
+                }
             }
         }
     } else {
@@ -197,28 +259,50 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const ResizeP p) {
             for (int k = 0; k < 2; ++k) {
                 const int ix_l = xg + 16 * k, ix = ix0 + ix_l;
                 if (ix >= p.Wi) break;
-                int ox_lo = first_out(ix, p.sx, p.Wo);
-                while (ox_lo < p.Wo && axis_of(ox_lo, p.sx, p.Wi).i0 < ix - 1) ++ox_lo;
-                int ox_hi = ox_lo;
-                while (ox_hi < p.Wo && axis_of(ox_hi, p.sx, p.Wi).i0 <= ix) ++ox_hi;
+                const Taps tx = taps_of(ix, p.sx, p.Wi, p.Wo);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int oy = oy_lo; oy < oy_hi; ++oy) {
-                    const Axis ay = axis_of(oy, p.sy, p.Hi);
-                    const float wy = (ay.i0 == iy ? ay.l0 : 0.f) + (ay.i1 == iy ? ay.l1 : 0.f);
-                    f32x4 racc = {0.f, 0.f, 0.f, 0.f};
-                    for (int ox = ox_lo; ox < ox_hi; ++ox) {
-                        const Axis ax = axis_of(ox, p.sx, p.Wi);
-                        const float wx = (ax.i0 == ix ? ax.l0 : 0.f) + (ax.i1 == ix ? ax.l1 : 0.f);
-                        const int64_t o = addr<true>(b, c, oy, ox, p.C, p.Ho, p.Wo);
-                        f32x4 g = *reinterpret_cast<const f32x4*>(p.x + o);
-                        if (p.gate) {
-                            const f32x4 y = *reinterpret_cast<const f32x4*>(p.gate + o);
+                if (ty.n >= 0 && tx.n >= 0) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) g[j] = 0.f;
+                    for (int jy = 0; jy < RS_MAXT; ++jy) {
+                        if (jy < ty.n) {
+                            f32x4 racc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int jx = 0; jx < RS_MAXT; ++jx) {
+                                if (jx < tx.n) {
+                                    const int64_t o = addr<true>(b, c, ty.lo + jy, tx.lo + jx, p.C, p.Ho, p.Wo);
+                                    f32x4 g = *reinterpret_cast<const f32x4*>(p.x + o);
+                                    if (p.gate) {
+                                        const f32x4 y = *reinterpret_cast<const f32x4*>(p.gate + o);
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) g[j] = 0.f;
+                                    }
+                                    racc += tx.w[jx] * g;
+                                }
+                            }
+                            acc += ty.w[jy] * racc;
                         }
-                        racc += wx * g;
                     }
-                    acc += wy * racc;
+                } else {
+                    for (int oy = ty.lo; oy < p.Ho; ++oy) {
+                        const Axis ay = axis_of(oy, p.sy, p.Hi);
+                        if (ay.i0 > iy) break;
+                        const float wy = (ay.i0 == iy ? ay.l0 : 0.f) + (ay.i1 == iy ? ay.l1 : 0.f);
+                        f32x4 racc = {0.f, 0.f, 0.f, 0.f};
+                        for (int ox = tx.lo; ox < p.Wo; ++ox) {
+                            const Axis ax = axis_of(ox, p.sx, p.Wi);
+                            if (ax.i0 > ix) break;
+                            const float wx = (ax.i0 == ix ? ax.l0 : 0.f) + (ax.i1 == ix ? ax.l1 : 0.f);
+                            const int64_t o = addr<true>(b, c, oy, ox, p.C, p.Ho, p.Wo);
+                            f32x4 g = *reinterpret_cast<const f32x4*>(p.x + o);
+                            if (p.gate) {
+                                const f32x4 y = *reinterpret_cast<const f32x4*>(p.gate + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) g[j] = 0.f;
+                            }
+                            racc += wx * g;
+                        }
+                        acc += wy * racc;
+                    }
                 }
                 if (DX_NHWC) {
                     *reinterpret_cast<f32x4*>(p.y + addr<true>(b, c, iy, ix, p.C, p.Hi, p.Wi)) = acc;
@@ -253,6 +337,70 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const ResizeP p) {
                 const int c_l = cg + 8 * k, c = c0 + c_l;
                 if (c < p.C) p.y[addr<false>(b, c, iy, ix, p.C, p.Hi, p.Wi)] = tile[c_l][ix_l];
             }
+        }
+    }
+}
+
+// NCHW -> NCHW backward over flattened planes: a thread owns one input pixel (iy, ix) of 8 channel planes,
+// so the stores of a wave are 256 contiguous bytes per plane regardless of the (odd) row length.
+__global__ __launch_bounds__(256) void resize_bwd_planar_kernel(const ResizeP p) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.Hi * p.Wi) return;
+    const int iy = e / p.Wi, ix = e - iy * p.Wi;
+    const int b = blockIdx.z, cbase = blockIdx.y * 8;
+    const Taps ty = taps_of(iy, p.sy, p.Hi, p.Ho);
+    const Taps tx = taps_of(ix, p.sx, p.Wi, p.Wo);
+    const int64_t plane_o = (int64_t)p.Ho * p.Wo, plane_i = (int64_t)p.Hi * p.Wi;
+    if (ty.n >= 0 && tx.n >= 0) {
+        float accs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = cbase + k;
+            float acc = 0.f;
+            if (c < p.C) {
+                const int64_t po = ((int64_t)b * p.C + c) * plane_o;
+#pragma unroll
+                for (int jy = 0; jy < RS_MAXT; ++jy) {
+                    if (jy < ty.n) {
+                        const int64_t ro = po + (int64_t)(ty.lo + jy) * p.Wo + tx.lo;
+                        float racc = 0.f;
+#pragma unroll
+                        for (int jx = 0; jx < RS_MAXT; ++jx) {
+                            if (jx < tx.n) {
+                                float g = p.x[ro + jx];
+                                if (p.gate && !(p.gate[ro + jx] > 0.f)) g = 0.f;
+                                racc = fmaf(tx.w[jx], g, racc);
+                            }
+                        }
+                        acc = fmaf(ty.w[jy], racc, acc);
+                    }
+                }
+            }
+            accs[k] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (cbase + k < p.C) p.y[((int64_t)b * p.C + cbase + k) * plane_i + e] = accs[k];
+    } else {
+        for (int k = 0; k < 8 && cbase + k < p.C; ++k) {
+            const int64_t po = ((int64_t)b * p.C + cbase + k) * plane_o;
+            float acc = 0.f;
+            for (int oy = ty.lo; oy < p.Ho; ++oy) {
+                const Axis ay = axis_of(oy, p.sy, p.Hi);
+                if (ay.i0 > iy) break;
+                const float wy = (ay.i0 == iy ? ay.l0 : 0.f) + (ay.i1 == iy ? ay.l1 : 0.f);
+                float racc = 0.f;
+                for (int ox = tx.lo; ox < p.Wo; ++ox) {
+                    const Axis ax = axis_of(ox, p.sx, p.Wi);
+                    if (ax.i0 > ix) break;
+                    const float wx = (ax.i0 == ix ? ax.l0 : 0.f) + (ax.i1 == ix ? ax.l1 : 0.f);
+                    float g = p.x[po + (int64_t)oy * p.Wo + ox];
+                    if (p.gate && !(p.gate[po + (int64_t)oy * p.Wo + ox] > 0.f)) g = 0.f;
+                    racc = fmaf(wx, g, racc);
+                }
+                acc = fmaf(wy, racc, acc);
+            }
+            p.y[((int64_t)b * p.C + cbase + k) * plane_i + e] = acc;
         }
     }
 }
@@ -301,7 +449,11 @@ extern "C" int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx
               scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX)};
     dim3 grid((unsigned)(p.xtiles * ceil_div(C, RS_TC)), (unsigned)Hi, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    if (!out_nhwc && !in_nhwc) hipLaunchKernelGGL((resize_bwd_kernel<false, false>), grid, dim3(256), 0, st, p);
+    if (!out_nhwc && !in_nhwc) {
+        if (ceil_div(C, 8) > 65535) return GT_EINVAL;
+        dim3 pg((unsigned)ceil_div((int64_t)Hi * Wi, 256), (unsigned)ceil_div(C, 8), (unsigned)B);
+        hipLaunchKernelGGL(resize_bwd_planar_kernel, pg, dim3(256), 0, st, p);
+    }
     else if (!out_nhwc && in_nhwc) hipLaunchKernelGGL((resize_bwd_kernel<false, true>), grid, dim3(256), 0, st, p);
     else if (out_nhwc && !in_nhwc) hipLaunchKernelGGL((resize_bwd_kernel<true, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((resize_bwd_kernel<true, true>), grid, dim3(256), 0, st, p);

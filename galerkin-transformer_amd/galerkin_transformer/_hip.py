@@ -494,8 +494,8 @@ def bilinear2d_fwd(x: torch.Tensor, size, in_nhwc: bool, out_nhwc: bool, act: in
     y = torch.empty((B, Ho, Wo, Cc) if out_nhwc else (B, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
     nb = 4.0 * B * Cc * (Hi * Wi + Ho * Wo)
     check(_timed("gt_bilinear2d_fwd", 0, nb, lambda: lib().gt_bilinear2d_fwd(
-        x.data_ptr(), y.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(in_nhwc), int(out_nhwc), act, stream_ptr())),
-        "gt_bilinear2d_fwd")
+        x.data_ptr(), y.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(in_nhwc), int(out_nhwc), act, stream_ptr()),
+        shape=(B, Cc, Hi, Ho, int(in_nhwc), int(out_nhwc))), "gt_bilinear2d_fwd")
     return y
 
 
@@ -508,5 +508,5 @@ def bilinear2d_bwd(g: torch.Tensor, y_saved: Optional[torch.Tensor], in_size, in
     nb = 4.0 * B * Cc * (Hi * Wi + Ho * Wo * (2 if y_saved is not None else 1))
     check(_timed("gt_bilinear2d_bwd", 0, nb, lambda: lib().gt_bilinear2d_bwd(
         g.data_ptr(), ptr(y_saved), dx.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(in_nhwc), int(out_nhwc), act,
-        stream_ptr())), "gt_bilinear2d_bwd")
+        stream_ptr()), shape=(B, Cc, Hi, Ho, int(in_nhwc), int(out_nhwc))), "gt_bilinear2d_bwd")
     return dx
