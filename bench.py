@@ -151,7 +151,7 @@ def roofline_leg(trainer):
     trainer.shape_table = prof.table(by_shape=True)
     # dominant kernel of the hand-written path = the GEMM template instance with the largest share of
     # the step; within it, the launch shape that accounts for most of that time
-    gemm_keys = [k for k in table if k.startswith("gemm<")]
+    gemm_keys = [k for k in table if k.startswith("gemm_")]
     dom = max(gemm_keys, key=lambda k: table[k]["ms"])
     recs = [r for r in prof.records if r[0] == dom and r[5] is not None]
     by_shape = {}
@@ -171,11 +171,22 @@ def roofline_leg(trainer):
     torch.cuda.synchronize()
     dur_s = e0.elapsed_time(e1) / reps * 1e-3
     achieved = best[1] / dur_s / 1e12
-    roof = dict(bound="mfma", kernel=dom, launch_shape_MNKb=list(best[6]), launches_per_step=len(recs),
+    # HBM traffic of this kernel + launch shape from the rocprofv3 --pmc passes (tools/gpu_pmc.sh), when a
+    # measurement for exactly this launch is on file under profiles/
+    traffic, tsrc = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(f"{dom}|{','.join(str(v) for v in best[6])}")
+        if rec:
+            traffic, tsrc = int(rec["read_bytes"] + rec["write_bytes"]), rec["source"]
+    except (OSError, ValueError):
+        pass
+    roof = dict(bound="mfma", kernel="gt::" + dom.replace("+splitk", ""), launch_shape_MNKb=list(best[6]),
+                includes_splitk_reduce=dom.endswith("+splitk"), launches_per_step=len(recs),
                 share_of_hip_path=round(table[dom]["ms"] / sum(v["ms"] for v in table.values()), 3),
                 avg_launch_us=round(dur_s * 1e6, 2),
                 achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=tsrc,
                 algorithmic_flops_per_launch=best[1], algorithmic_bytes_per_launch=best[2])
     return roof, table
 
@@ -207,7 +218,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

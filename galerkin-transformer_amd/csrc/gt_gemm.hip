@@ -279,7 +279,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, kq = lane >> 4;
-    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+    // XCD-aware tile order: blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), so give each
+    // XCD a contiguous range of tile ids -- the N-tiles that share an A row panel then hit the same L2
+    // instead of fetching the panel once per XCD (bijective for any tile count; speed only).
+    int tile;
+    {
+        const int tiles = gridDim.x, q = tiles >> 3, r = tiles & 7;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z, b0 = z / p.batch1, b1 = z % p.batch1;
     const int kbeg = blockIdx.y * p.k_chunk;
@@ -769,6 +778,22 @@ static int64_t slab_bytes(const gt_gemm_desc* d, const Plan& pl) {
 }
 static int64_t acs_parts(const gt_gemm_desc* d, const Plan& pl) {
     return d->a_colsum ? (int64_t)pl.split * d->batch0 * d->batch1 : 0;
+}
+
+// Symbol of the kernel instance gt_gemm would launch for `d` (as rocprofv3 prints it), for matching the
+// bench's roofline line against a kernel trace.
+extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) {
+    Plan pl;
+    if (!d || !buf || n <= 0) return GT_EINVAL;
+    int rc = make_plan(d, &pl);
+    if (rc) return rc;
+    const Cfg& c = kCfgs[pl.cfg];
+    if (pl.stream)
+        snprintf(buf, n, "void gt::gemm_stream_kernel<%d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b, c.mt);
+    else
+        snprintf(buf, n, "void gt::gemm_kernel<%d, %d, %d, %d, %d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b,
+                 c.mt, c.nt, c.wm, c.wn, pl.bk);
+    return 0;
 }
 
 extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {

@@ -59,6 +59,7 @@ _PROTOS = {
     "gt_gemm": (C.c_int, [C.POINTER(GtGemmDesc), C.c_void_p, C.c_int64, C.c_void_p]),
     "gt_gemm_plan": (C.c_int, [C.POINTER(GtGemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                C.POINTER(C.c_int32)]),
+    "gt_gemm_kernel_name": (C.c_int, [C.POINTER(GtGemmDesc), C.c_char_p, C.c_int32]),
     "gt_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GtDropout), C.c_float,
                             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gt_act_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
@@ -320,7 +321,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         nb = batch[0] * batch[1]
         bm, bn, sp = C.c_int32(), C.c_int32(), C.c_int32()
         L.gt_gemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(sp))
-        key = f"gemm<la={layout_a},lb={layout_b},{bm.value}x{bn.value}>" + ("+splitk" if sp.value > 1 else "")
+        nm = C.create_string_buffer(160)
+        L.gt_gemm_kernel_name(C.byref(d), nm, 160)
+        key = nm.value.decode().replace("void gt::", "").replace("(gt::GemmP)", "") + ("+splitk" if sp.value > 1 else "")
         flops = 2.0 * M * N * K * nb
         nbytes = 4.0 * nb * (M * K + K * N + M * N * (1 + (res is not None) + (aux is not None) +
                                                       (add is not None) + (pre is not None)))

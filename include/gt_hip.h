@@ -125,6 +125,8 @@ int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d);
 int     gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream);
 /* debugging/tests: which tile configuration and split the library picks */
 int     gt_gemm_plan(const gt_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* split);
+/* symbol of the kernel instance gt_gemm would launch for d, as a profiler prints it */
+int     gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n);
 
 /* ---------------------------------------------------------------------------------------------
  * out[n] (+)= sum_m A[m*lda + n] * keepA(m,n)  -- bias gradients.  Two deterministic passes.
