@@ -50,7 +50,23 @@ struct ResizeP {
     float sy, sx;
     int act;                    // fwd: GT_ACT_NONE / GT_ACT_RELU applied to the output
     int xtiles;
+    // optional affine term added to the resized value of channel c at output pixel q (NHWC outputs only):
+    //   + bias[c] + sum_j rp_a[q*rp_lda + j] * rp_b[c*rp_ldb + j]
+    const float* bias; int rp; const float* rp_a; int64_t rp_lda; const float* rp_b; int64_t rp_ldb;
 };
+
+__device__ __forceinline__ f32x4 resize_affine(const ResizeP& p, f32x4 v, int b, int c, int oy, int ox) {
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c);
+    if (p.rp) {
+        const float* ga = p.rp_a + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * p.rp_lda;
+        for (int j = 0; j < p.rp; ++j) {
+            const float a = ga[j];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = fmaf(a, p.rp_b[(int64_t)(c + t) * p.rp_ldb + j], v[t]);
+        }
+    }
+    return v;
+}
 
 template <bool NHWC>
 __device__ __forceinline__ int64_t addr(int b, int c, int y, int x, int C, int H, int W) {
@@ -99,6 +115,7 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const ResizeP p) {
                     const f32x4 v10 = *reinterpret_cast<const f32x4*>(p.x + addr<true>(b, c, ay.i1, ax.i0, p.C, p.Hi, p.Wi));
                     const f32x4 v11 = *reinterpret_cast<const f32x4*>(p.x + addr<true>(b, c, ay.i1, ax.i1, p.C, p.Hi, p.Wi));
                     f32x4 v = ay.l0 * (ax.l0 * v00 + ax.l1 * v01) + ay.l1 * (ax.l0 * v10 + ax.l1 * v11);
+                    if (OUT_NHWC) v = resize_affine(p, v, b, c, oy, ox);
                     if (p.act == GT_ACT_RELU) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -421,12 +438,20 @@ static inline float scale_of(int ni, int no) { return (no > 1) ? (float)(ni - 1)
 
 using namespace gt;
 
-extern "C" int gt_bilinear2d_fwd(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi,
-                                 int32_t Ho, int32_t Wo, int32_t in_nhwc, int32_t out_nhwc, int32_t act,
-                                 void* stream) {
+extern "C" int gt_bilinear2d_fwd_affine(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi,
+                                        int32_t Ho, int32_t Wo, int32_t in_nhwc, int32_t out_nhwc, int32_t act,
+                                        const gt_resize_affine* aff, void* stream) {
     if (int rc = check_resize(x, y, B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc)) return rc;
     if (act != GT_ACT_NONE && act != GT_ACT_RELU) return GT_ENOTSUP;
-    ResizeP p{x, y, nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho), scale_of(Wi, Wo), act, ceil_div(Wo, RS_TX)};
+    ResizeP p{x, y, nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho), scale_of(Wi, Wo), act, ceil_div(Wo, RS_TX),
+              nullptr, 0, nullptr, 0, nullptr, 0};
+    if (aff && (aff->bias || aff->rp)) {
+        if (!(in_nhwc && out_nhwc)) return GT_ENOTSUP;
+        if (aff->rp < 0 || aff->rp > 8 || (aff->rp && (!aff->rp_a || !aff->rp_b))) return GT_EINVAL;
+        if (aff->bias && (reinterpret_cast<uintptr_t>(aff->bias) & 15)) return GT_EALIGN;
+        p.bias = aff->bias; p.rp = aff->rp; p.rp_a = aff->rp_a; p.rp_lda = aff->rp_lda;
+        p.rp_b = aff->rp_b; p.rp_ldb = aff->rp_ldb;
+    }
     dim3 grid((unsigned)(p.xtiles * ceil_div(C, RS_TC)), (unsigned)Ho, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     if (!in_nhwc && !out_nhwc) hipLaunchKernelGGL((resize_fwd_kernel<false, false>), grid, dim3(256), 0, st, p);
@@ -435,6 +460,12 @@ extern "C" int gt_bilinear2d_fwd(const float* x, float* y, int32_t B, int32_t C,
     else hipLaunchKernelGGL((resize_fwd_kernel<true, true>), grid, dim3(256), 0, st, p);
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gt_bilinear2d_fwd(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi,
+                                 int32_t Ho, int32_t Wo, int32_t in_nhwc, int32_t out_nhwc, int32_t act,
+                                 void* stream) {
+    return gt_bilinear2d_fwd_affine(x, y, B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, act, nullptr, stream);
 }
 
 extern "C" int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx, int32_t B, int32_t C,
@@ -446,7 +477,7 @@ extern "C" int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx
     if (act == GT_ACT_RELU && !y_saved) return GT_EINVAL;
     if (out_nhwc && y_saved && (reinterpret_cast<uintptr_t>(y_saved) & 15)) return GT_EALIGN;
     ResizeP p{g, dx, act == GT_ACT_RELU ? y_saved : nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho),
-              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX)};
+              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX), nullptr, 0, nullptr, 0, nullptr, 0};
     dim3 grid((unsigned)(p.xtiles * ceil_div(C, RS_TC)), (unsigned)Hi, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     if (!out_nhwc && !in_nhwc) {

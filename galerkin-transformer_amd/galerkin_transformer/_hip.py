@@ -24,6 +24,11 @@ class GtDropout(C.Structure):
     _fields_ = [("p", C.c_float), ("salt", C.c_uint32), ("seed", C.c_void_p)]
 
 
+class GtResizeAffine(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("rp", C.c_int32), ("rp_a", C.c_void_p), ("rp_lda", C.c_int64),
+                ("rp_b", C.c_void_p), ("rp_ldb", C.c_int64)]
+
+
 class GtGemmDesc(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
@@ -86,6 +91,8 @@ _PROTOS = {
     "gt_modemix_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_int64, C.c_int64] +
                        [C.c_int32] * 3 + [C.c_void_p] * 3),
     "gt_bilinear2d_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p]),
+    "gt_bilinear2d_fwd_affine": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.POINTER(GtResizeAffine),
+                                                                                C.c_void_p]),
     "gt_bilinear2d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
 }
 
@@ -489,15 +496,25 @@ def _shape4(t: torch.Tensor, nhwc: bool):
     return B, Cc, H, W
 
 
-def bilinear2d_fwd(x: torch.Tensor, size, in_nhwc: bool, out_nhwc: bool, act: int = ACT_NONE) -> torch.Tensor:
-    """x dense [B,C,Hi,Wi] (or [B,Hi,Wi,C] when in_nhwc) -> dense [B,C,Ho,Wo] (or [B,Ho,Wo,C])."""
-    need_f32_cuda(x)
+def bilinear2d_fwd(x: torch.Tensor, size, in_nhwc: bool, out_nhwc: bool, act: int = ACT_NONE,
+                   bias: Optional[torch.Tensor] = None, rp_a: Optional[torch.Tensor] = None,
+                   rp_b: Optional[torch.Tensor] = None, rp_ldb: int = 0) -> torch.Tensor:
+    """x dense [B,C,Hi,Wi] (or [B,Hi,Wi,C] when in_nhwc) -> dense [B,C,Ho,Wo] (or [B,Ho,Wo,C]).
+    bias [C] / rp_a [B,Ho,Wo,p] / rp_b ([C,p] view with row stride rp_ldb): the affine epilogue of
+    gt_bilinear2d_fwd_affine."""
+    need_f32_cuda(x, bias, rp_a, rp_b)
     B, Cc, Hi, Wi = _shape4(x, in_nhwc)
     Ho, Wo = int(size[0]), int(size[1])
     y = torch.empty((B, Ho, Wo, Cc) if out_nhwc else (B, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
     nb = 4.0 * B * Cc * (Hi * Wi + Ho * Wo)
-    check(_timed("gt_bilinear2d_fwd", 0, nb, lambda: lib().gt_bilinear2d_fwd(
-        x.data_ptr(), y.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(in_nhwc), int(out_nhwc), act, stream_ptr()),
+    aff = GtResizeAffine()
+    aff.bias = ptr(bias)
+    if rp_a is not None:
+        aff.rp, aff.rp_a, aff.rp_lda = rp_a.shape[-1], rp_a.data_ptr(), rp_a.shape[-1]
+        aff.rp_b, aff.rp_ldb = rp_b.data_ptr(), rp_ldb
+    check(_timed("gt_bilinear2d_fwd", 0, nb, lambda: lib().gt_bilinear2d_fwd_affine(
+        x.data_ptr(), y.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(in_nhwc), int(out_nhwc), act, C.byref(aff),
+        stream_ptr()),
         shape=(B, Cc, Hi, Ho, int(in_nhwc), int(out_nhwc))), "gt_bilinear2d_fwd")
     return y
 

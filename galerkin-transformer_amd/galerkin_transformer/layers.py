@@ -188,14 +188,18 @@ class Interp2dUpsample(nn.Module):
         self.interp_mode = interp_mode
         self.debug = debug
 
-    def forward(self, x, in_nhwc=False, out_nhwc=False):
-        """x (B, C, H, W), or (B, H, W, C) with ``in_nhwc``; the layout changes ride on the resizes."""
+    def forward_features(self, x, in_nhwc=False):
+        """Everything but the final resize: (B, C, H1, W1) channels-first at the intermediate size."""
         if self.interp_mode != "bilinear":
             raise NotImplementedError(f"interp_mode={self.interp_mode!r}: only bilinear has a HIP path")
         x = _resize(x, self.interp_size[0], None, in_nhwc=in_nhwc)
         if self.conv_block:
             x = self.activation(ops.dropout(self.conv[0](x), self.dropout.p, self.training))
-        return _resize(x, self.interp_size[1], None, out_nhwc=out_nhwc)
+        return x
+
+    def forward(self, x, in_nhwc=False, out_nhwc=False):
+        """x (B, C, H, W), or (B, H, W, C) with ``in_nhwc``; the layout changes ride on the resizes."""
+        return _resize(self.forward_features(x, in_nhwc), self.interp_size[1], None, out_nhwc=out_nhwc)
 
 
 # --------------------------------------------------------------------------------------- attention (HIP)

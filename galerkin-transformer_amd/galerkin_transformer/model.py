@@ -156,9 +156,14 @@ class SpectralRegressor(nn.Module):
         self.return_latent = return_latent
         self.debug = debug
 
-    def forward(self, x, edge=None, pos=None, grid=None):
+    def forward(self, x, edge=None, pos=None, grid=None, upsample_to=None):
+        """``upsample_to=(Ho, Wo)``: x is the channels-first (B, C, H1, W1) feature map BEFORE the scaler's
+        final bilinear resize; the resize is then commuted behind ``fc`` (ops.upsample_fc)."""
         x_latent = []
-        if self.spacial_fc:
+        if upsample_to is not None:
+            assert self.spacial_fc
+            x = ops.upsample_fc(x, upsample_to, self.fc.weight, self.fc.bias, grid)
+        elif self.spacial_fc:
             x = ops.linear(x, self.fc.weight, self.fc.bias, extra=grid)
         for layer in self.spectral_conv:
             x = layer(x)
@@ -414,15 +419,24 @@ class FourierTransformer2D(_ConfiguredModel):
             if self.return_latent:
                 x_latent.append(x.contiguous())
         x = x.view(bsz, n_s, n_s, self.n_hidden)
-        x = self.upscaler(x)
-        if self.return_latent:
-            x_latent.append(x.contiguous())
-        x = self._drop(x)
-        if self.return_latent:
-            x, xr_latent = self.regressor(x, grid=grid)
-            x_latent.append(xr_latent)
+        up = getattr(self.upscaler, 'upsample', None)
+        if (isinstance(up, Interp2dUpsample) and up.interp_mode == 'bilinear' and not self.return_latent
+                and isinstance(self.regressor, SpectralRegressor) and self.regressor.spacial_fc
+                and grid is not None and not (self.training and self.dpo.p > 0)):
+            # nothing sits between the upscaler's last resize and the regressor's fc: run fc at the coarse
+            # resolution and interpolate its freq_dim channels instead of the n_hidden ones
+            x = self.regressor(up.forward_features(x, in_nhwc=True), grid=grid,
+                               upsample_to=tuple(up.interp_size[1]))
         else:
-            x = self.regressor(x, grid=grid)
+            x = self.upscaler(x)
+            if self.return_latent:
+                x_latent.append(x.contiguous())
+            x = self._drop(x)
+            if self.return_latent:
+                x, xr_latent = self.regressor(x, grid=grid)
+                x_latent.append(xr_latent)
+            else:
+                x = self.regressor(x, grid=grid)
         if self.normalizer:
             x = self.normalizer.inverse_transform(x)
         if self.boundary_condition == 'dirichlet':

@@ -108,6 +108,70 @@ def bilinear_resize(x, size, in_nhwc: bool = False, out_nhwc: bool = False, act:
     return ResizeFn.apply(x, (int(size[0]), int(size[1])), bool(in_nhwc), bool(out_nhwc), H.ACT_CODE[act])
 
 
+class UpsampleFcFn(Function):
+    """fc(cat[upsample(x), grid]) without ever materialising upsample(x).
+
+    Reference: Interp2dUpsample's final F.interpolate (layers.py:658-670) followed by SpectralRegressor /
+    PointwiseRegressor ``fc(torch.cat([x, grid], -1))`` (model.py:615-617, 507-512).  A pointwise Linear
+    commutes with bilinear interpolation (the four weights sum to one), so
+
+        fc(cat[up(x), grid]) = up(x W_x^T) + grid W_g^T + b
+
+    x: (B, K, Hi, Wi) channels-first (what the scaler's conv block produces); weight (N, K+p); grid
+    (B, Ho, Wo, p).  Returns (B, Ho, Wo, N).  Only valid when nothing (dropout) sits between the resize and
+    the Linear -- the caller checks."""
+
+    @staticmethod
+    def forward(ctx, x, size, weight, bias, grid):
+        H.need_f32_cuda(x, weight, bias, grid)
+        B, K, Hi, Wi = x.shape
+        N, p = weight.shape[0], grid.shape[-1]
+        assert weight.shape[1] == K + p
+        Ho, Wo = size
+        xc, w, gc = _c(x), _c(weight), _c(grid)
+        dev, HW = x.device, Hi * Wi
+        z = torch.empty(B, Hi, Wi, N, dtype=torch.float32, device=dev)
+        H.gemm(xc, w, z, HW, N, K, layout_a=1, lda=HW, ldb=K + p, ldc=N, batch=(B, 1), a_bs=(K * HW, 0),
+               c_bs=(HW * N, 0))
+        out = H.bilinear2d_fwd(z, (Ho, Wo), True, True, H.ACT_NONE, bias=bias, rp_a=gc.reshape(B, Ho, Wo, p),
+                               rp_b=w[:, K:], rp_ldb=K + p)
+        ctx.save_for_backward(xc, w, gc)
+        ctx.cfg = (B, K, Hi, Wi, Ho, Wo, N, p, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, w, gc = ctx.saved_tensors
+        B, K, Hi, Wi, Ho, Wo, N, p, has_b = ctx.cfg
+        dev, HW, To = g.device, Hi * Wi, B * Ho * Wo
+        gg = _c(g)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dz = H.bilinear2d_bwd(gg, None, (Hi, Wi), True, True, H.ACT_NONE)              # (B, Hi, Wi, N)
+        dw = torch.empty(N, K + p, **f32)
+        db = torch.empty(N, **f32) if has_b else None
+        # d W_g = g^T grid  (+ d bias = column sums of g as a by-product)
+        H.gemm(gg, gc, dw[:, K:], N, p, To, layout_a=1, layout_b=1, lda=N, ldb=p, ldc=K + p, split_k=0,
+               a_colsum=db)
+        # d W_x = sum_b dz_b^T x_b^T : one [N, K] slab per batch entry, reduced in a fixed order
+        slabs = torch.empty(B, N, K, **f32)
+        H.gemm(dz, xc, slabs, N, K, HW, layout_a=1, layout_b=0, lda=N, ldb=HW, ldc=K, batch=(B, 1),
+               a_bs=(HW * N, 0), b_bs=(K * HW, 0), c_bs=(N * K, 0), split_k=0)
+        dwx = torch.empty(N, K, **f32)
+        H.slab_reduce(slabs, B, N * K, N * K, dwx)
+        dw[:, :K].copy_(dwx)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dx_b [K, HW] = W_x^T dz_b^T
+            dx = torch.empty(B, K, Hi, Wi, **f32)
+            H.gemm(w, dz, dx, K, HW, N, layout_a=1, layout_b=0, lda=K + p, ldb=N, ldc=HW, batch=(B, 1),
+                   b_bs=(HW * N, 0), c_bs=(K * HW, 0))
+        return dx, None, dw, db, None
+
+
+def upsample_fc(x_cf, size, weight, bias, grid):
+    return UpsampleFcFn.apply(x_cf, (int(size[0]), int(size[1])), weight, bias, grid)
+
+
 # ----------------------------------------------------------------------------------- Linear
 class LinearFn(Function):
     """y = res + out_scale * dropout(act(x W^T + b + extra W_e^T)).

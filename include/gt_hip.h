@@ -217,6 +217,21 @@ int gt_modemix_bwd(const float* X, const float* W, const float* dY, int32_t B, i
 int gt_bilinear2d_fwd(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi,
                       int32_t Ho, int32_t Wo, int32_t in_nhwc, int32_t out_nhwc, int32_t act,
                       void* stream);
+/* Same, plus an affine term per output pixel q and channel c (NHWC in and out only):
+ *     y = act( resize(x) + bias[c] + sum_j rp_a[q*rp_lda + j] * rp_b[c*rp_ldb + j] )
+ * This is what makes  fc(cat[upsample(x), grid])  (model.py:740-749 followed by model.py:615-617)
+ * computable as  upsample(x W_x^T) + grid W_g^T + b : the pointwise Linear commutes with the bilinear
+ * interpolation (its weights sum to one), so the Linear runs at the coarse resolution and only the
+ * freq_dim-channel result is interpolated. */
+typedef struct gt_resize_affine {
+    const float* bias;                 /* [C] or NULL */
+    int32_t rp;                        /* 0..8 */
+    const float* rp_a; int64_t rp_lda; /* [B*Ho*Wo, rp] */
+    const float* rp_b; int64_t rp_ldb; /* [C, rp] */
+} gt_resize_affine;
+int gt_bilinear2d_fwd_affine(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi,
+                             int32_t Ho, int32_t Wo, int32_t in_nhwc, int32_t out_nhwc, int32_t act,
+                             const gt_resize_affine* aff, void* stream);
 int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx, int32_t B, int32_t C,
                       int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t in_nhwc,
                       int32_t out_nhwc, int32_t act, void* stream);

@@ -427,3 +427,26 @@ def test_gemm_a_colsum_byproduct(H, gpu_device, split, batch, p_drop, sign):
     Gm = sign * G.double() * mask
     assert rel_l2(Cc, Gm.transpose(1, 2) @ X.double()) < KTOL
     assert rel_l2(cs, Gm.sum((0, 1))) < KTOL
+
+
+def test_upsample_fc_commutes(H, gpu_device):
+    """ops.upsample_fc == fc(cat[F.interpolate(x), grid]) (reference order, fp64 on the CPU), outputs and all
+    gradients: the pointwise Linear commutes with the bilinear resize."""
+    import torch.nn.functional as F
+    from galerkin_transformer import ops
+    B, K, Hi, Ho, N, p = 3, 24, 13, 29, 16, 2
+    x = rnd(B, K, Hi, Hi, dev="cpu", seed=50).double().requires_grad_(True)
+    W = rnd(N, K + p, dev="cpu", seed=51, scale=0.3).double().requires_grad_(True)
+    b = rnd(N, dev="cpu", seed=52).double().requires_grad_(True)
+    grid = rnd(B, Ho, Ho, p, dev="cpu", seed=53).double()
+    up = F.interpolate(x, size=(Ho, Ho), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    ref = F.linear(torch.cat([up, grid], -1), W, b)
+    cot = rnd(*ref.shape, dev="cpu", seed=54).double()
+    gx, gW, gb = torch.autograd.grad(ref, (x, W, b), cot)
+    xg = x.detach().float().to(gpu_device).requires_grad_(True)
+    Wg = W.detach().float().to(gpu_device).requires_grad_(True)
+    bg = b.detach().float().to(gpu_device).requires_grad_(True)
+    out = ops.upsample_fc(xg, (Ho, Ho), Wg, bg, grid.float().to(gpu_device))
+    out.backward(cot.float().to(gpu_device))
+    assert rel_l2(out, ref) < 5e-6          # fp32 resize weights vs the fp64 reference (see the resize test)
+    assert rel_l2(xg.grad, gx) < 5e-6 and rel_l2(Wg.grad, gW) < 5e-6 and rel_l2(bg.grad, gb) < 5e-6
