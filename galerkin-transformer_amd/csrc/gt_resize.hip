@@ -422,6 +422,188 @@ __global__ __launch_bounds__(256) void resize_bwd_planar_kernel(const ResizeP p)
     }
 }
 
+// ------------------------------------------------------------------------------------------ conv0 + resize
+// First stage of the down-scaler fused into one pass (layers.py:483-495: Conv2dResBlock(in -> out, 3x3,
+// padding 1, no bias) -> dropout -> act, then F.interpolate -> act):
+//     y0[b,c,iy,ix] = relu( keep(b,c,iy,ix) * sum_{ci,dy,dx} W[c,ci,dy,dx] x[b,ci,iy+dy-1,ix+dx-1] )
+//     y [b,c,oy,ox] = relu( bilinear(y0)[oy,ox] )
+// The input has one (few) channel(s) while y0 has `out` channels at the fine resolution (651 MB at
+// 141^2 x 128 x batch 64): y0 is never written -- the conv is re-evaluated at the 4 source pixels of each
+// output (36 fma per output and input channel), and in backward at every fine pixel, where the gathered
+// gradient is turned straight into the 3x3 weight gradient.  The dropout mask uses the linear NCHW index
+// of y0, so the fused op draws exactly the mask the unfused conv -> gt_dropout_apply sequence would.
+constexpr int CR_MAXCI = 4;         // input channels supported by the fused path
+constexpr int CR_CH = 16;           // output channels per block (forward)
+
+struct ConvResizeP {
+    const float* x; const float* w; float* y;          // fwd: y output.  bwd: y = saved forward output
+    const float* g; float* partial;                    // bwd only
+    int B, Cin, Cout, H, W, Ho, Wo;
+    float sy, sx;
+    DropDev drop;
+};
+
+__device__ __forceinline__ void load_patch(const float* __restrict__ xp, int H, int W, int iy, int ix,
+                                           float (&pt)[9]) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = iy + dy - 1;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = ix + dx - 1;
+            pt[dy * 3 + dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[(int64_t)yy * W + xx] : 0.f;
+        }
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP p) {
+    __shared__ float sw[CR_CH * CIN * 9];
+    const int c0 = blockIdx.y * CR_CH, b = blockIdx.z;
+    for (int i = threadIdx.x; i < CR_CH * CIN * 9; i += 256) {
+        const int c = c0 + i / (CIN * 9);
+        sw[i] = (c < p.Cout) ? p.w[(int64_t)c * CIN * 9 + i % (CIN * 9)] : 0.f;
+    }
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.Ho * p.Wo) return;
+    const int oy = e / p.Wo, ox = e - oy * p.Wo;
+    const Axis ay = axis_of(oy, p.sy, p.H), ax = axis_of(ox, p.sx, p.W);
+    const uint32_t key = drop_key_dev(p.drop);
+    // 3x3 input patches around the 4 source pixels, kept in registers for every output channel
+    float pt[CIN][4][9];
+    uint32_t toff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int iy = (t & 2) ? ay.i1 : ay.i0, ix = (t & 1) ? ax.i1 : ax.i0;
+        toff[t] = (uint32_t)(iy * p.W + ix);
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+            load_patch(p.x + ((int64_t)b * CIN + ci) * p.H * p.W, p.H, p.W, iy, ix, pt[ci][t]);
+    }
+    const uint32_t plane = (uint32_t)(p.H * p.W);
+    const float w00 = ay.l0 * ax.l0, w01 = ay.l0 * ax.l1, w10 = ay.l1 * ax.l0, w11 = ay.l1 * ax.l1;
+#pragma unroll 2
+    for (int j = 0; j < CR_CH; ++j) {
+        const int c = c0 + j;
+        if (c >= p.Cout) break;
+        float cv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float wv = sw[(j * CIN + ci) * 9 + k];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) cv[t] = fmaf(wv, pt[ci][t][k], cv[t]);
+            }
+        const uint32_t cbase = ((uint32_t)b * (uint32_t)p.Cout + (uint32_t)c) * plane;   // mod 2^32, like the
+#pragma unroll                                                                            // stand-alone dropout
+        for (int t = 0; t < 4; ++t) {
+            const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
+            cv[t] = fmaxf(cv[t] * m, 0.f);
+        }
+        // same association as the stand-alone resize: l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
+        const float r = ay.l0 * (ax.l0 * cv[0] + ax.l1 * cv[1]) + ay.l1 * (ax.l0 * cv[2] + ax.l1 * cv[3]);
+        (void)w00; (void)w01; (void)w10; (void)w11;
+        p.y[((int64_t)b * p.Cout + c) * p.Ho * p.Wo + e] = fmaxf(r, 0.f);
+    }
+}
+
+// Backward: weight gradient only (the fused path is used when the input needs no gradient).
+// Output-side formulation: with R the bilinear operator, G = g .* [y > 0], and D = keep .* [y0 > 0],
+//     dW[c][ci][k] = sum_px (R^T G)[px] D[px] x[px + off_k]  =  sum_o G[o] * sum_{4 taps t} w_t D[src_t] x[src_t + off_k]
+// so a thread walks OUTPUT pixels (coalesced reads of g and y, no gather, the same 3x3 patches as the forward)
+// and accumulates dW for CRB_CG channels in registers over CRB_PXT pixels before one block reduction.
+constexpr int CRB_PXT = 8;
+constexpr int CRB_CG = 8;
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_resize_bwd_kernel(const ConvResizeP p) {
+    __shared__ float sw[CRB_CG * CIN * 9];
+    __shared__ float red[4][CRB_CG * CIN * 9];
+    const int c0 = blockIdx.y * CRB_CG, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < CRB_CG * CIN * 9; i += 256) {
+        const int c = c0 + i / (CIN * 9);
+        sw[i] = (c < p.Cout) ? p.w[(int64_t)c * CIN * 9 + i % (CIN * 9)] : 0.f;
+    }
+    __syncthreads();
+    const uint32_t plane = (uint32_t)(p.H * p.W);
+    const int oplane = p.Ho * p.Wo;
+    const uint32_t key = drop_key_dev(p.drop);
+    float acc[CRB_CG][CIN * 9];
+#pragma unroll
+    for (int j = 0; j < CRB_CG; ++j)
+#pragma unroll
+        for (int k = 0; k < CIN * 9; ++k) acc[j][k] = 0.f;
+
+#pragma unroll 1
+    for (int it = 0; it < CRB_PXT; ++it) {
+        const int e = (blockIdx.x * CRB_PXT + it) * 256 + threadIdx.x;
+        if (e >= oplane) continue;
+        const int oy = e / p.Wo, ox = e - oy * p.Wo;
+        const Axis ay = axis_of(oy, p.sy, p.H), ax = axis_of(ox, p.sx, p.W);
+        float pt[CIN][4][9];
+        uint32_t toff[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int iy = (t & 2) ? ay.i1 : ay.i0, ix = (t & 1) ? ax.i1 : ax.i0;
+            toff[t] = (uint32_t)(iy * p.W + ix);
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+                load_patch(p.x + ((int64_t)b * CIN + ci) * plane, p.H, p.W, iy, ix, pt[ci][t]);
+        }
+        const float wt[4] = {ay.l0 * ax.l0, ay.l0 * ax.l1, ay.l1 * ax.l0, ay.l1 * ax.l1};
+#pragma unroll 2
+        for (int j = 0; j < CRB_CG; ++j) {
+            const int c = min(c0 + j, p.Cout - 1);                 // clamped: tail channels are not stored
+            const int64_t o = ((int64_t)b * p.Cout + c) * oplane + e;
+            const float go = (p.y[o] > 0.f) ? p.g[o] : 0.f;
+            float cv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float wv = sw[(j * CIN + ci) * 9 + k];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) cv[t] = fmaf(wv, pt[ci][t][k], cv[t]);
+                }
+            const uint32_t cbase = ((uint32_t)b * (uint32_t)p.Cout + (uint32_t)c) * plane;
+            float coef[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
+                coef[t] = (cv[t] * m > 0.f) ? wt[t] * m * go : 0.f;
+            }
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    float a = acc[j][ci * 9 + k];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a = fmaf(coef[t], pt[ci][t][k], a);
+                    acc[j][ci * 9 + k] = a;
+                }
+        }
+    }
+    // wave reduction, then the 4 waves through LDS (fixed order -> deterministic)
+#pragma unroll
+    for (int j = 0; j < CRB_CG; ++j)
+#pragma unroll
+        for (int k = 0; k < CIN * 9; ++k) {
+            const float v = wave_sum(acc[j][k]);
+            if (lane == 0) red[wave][j * CIN * 9 + k] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < CRB_CG * CIN * 9) {
+        const int c = c0 + threadIdx.x / (CIN * 9);
+        if (c < p.Cout) {
+            float* part = p.partial + ((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * p.Cout) * CIN * 9;
+            part[(int64_t)c0 * CIN * 9 + threadIdx.x] =
+                red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        }
+    }
+}
+
 static int check_resize(const void* x, const void* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
                         int in_nhwc, int out_nhwc) {
     if (!x || !y || B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return GT_EINVAL;
@@ -490,4 +672,61 @@ extern "C" int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx
     else hipLaunchKernelGGL((resize_bwd_kernel<true, true>), grid, dim3(256), 0, st, p);
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+static int check_conv_resize(const void* x, const void* w, const void* y, int B, int Cin, int Cout, int H, int W,
+                             int Ho, int Wo, const gt_dropout* drop, int act) {
+    if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return GT_EINVAL;
+    if (Cin > CR_MAXCI || act != GT_ACT_RELU) return GT_ENOTSUP;
+    if (B > 65535) return GT_EINVAL;
+    if (drop && drop->p > 0.f && !drop->seed) return GT_EINVAL;
+    if (drop && (drop->p < 0.f || drop->p >= 1.f)) return GT_EINVAL;
+    return 0;
+}
+
+extern "C" int gt_conv3x3_resize_fwd(const float* x, const float* w, float* y, int32_t B, int32_t Cin,
+                                     int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                     const gt_dropout* drop, int32_t act, void* stream) {
+    if (int rc = check_conv_resize(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
+    ConvResizeP p{x, w, y, nullptr, nullptr, B, Cin, Cout, H, W, Ho, Wo, scale_of(H, Ho), scale_of(W, Wo),
+                  make_drop(drop)};
+    dim3 grid((unsigned)ceil_div((int64_t)Ho * Wo, 256), (unsigned)ceil_div(Cout, CR_CH), (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL(conv_resize_fwd_kernel<1>, grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(conv_resize_fwd_kernel<2>, grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(conv_resize_fwd_kernel<3>, grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL(conv_resize_fwd_kernel<4>, grid, dim3(256), 0, st, p); break;
+    }
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t gt_conv3x3_resize_bwd_ws_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W) {
+    (void)H; (void)W;      // partial slabs are per (image, strip of OUTPUT pixels): bounded by the input size
+    return (int64_t)B * ceil_div((int64_t)H * W, 256 * CRB_PXT) * Cout * Cin * 9 * (int64_t)sizeof(float);
+}
+
+extern "C" int gt_conv3x3_resize_bwd(const float* g, const float* y, const float* x, const float* w, int32_t B,
+                                     int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                     const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
+                                     void* stream) {
+    if (int rc = check_conv_resize(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
+    if (!g || !dw) return GT_EINVAL;
+    if (!ws || ws_bytes < gt_conv3x3_resize_bwd_ws_bytes(B, Cin, Cout, H, W)) return GT_EWS;
+    ConvResizeP p{x, w, const_cast<float*>(y), g, reinterpret_cast<float*>(ws), B, Cin, Cout, H, W, Ho, Wo,
+                  scale_of(H, Ho), scale_of(W, Wo), make_drop(drop)};
+    if (ceil_div((int64_t)Ho * Wo, 256 * CRB_PXT) > ceil_div((int64_t)H * W, 256 * CRB_PXT)) return GT_ENOTSUP;
+    const int nx = ceil_div((int64_t)Ho * Wo, 256 * CRB_PXT);
+    dim3 grid((unsigned)nx, (unsigned)ceil_div(Cout, CRB_CG), (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL(conv_resize_bwd_kernel<1>, grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(conv_resize_bwd_kernel<2>, grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(conv_resize_bwd_kernel<3>, grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL(conv_resize_bwd_kernel<4>, grid, dim3(256), 0, st, p); break;
+    }
+    GT_LAUNCH_CHECK();
+    const int64_t n = (int64_t)Cout * Cin * 9;
+    return gt_slab_reduce(p.partial, n, B * nx, n, 1.f, dw, stream);
 }

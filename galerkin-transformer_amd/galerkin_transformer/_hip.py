@@ -93,6 +93,12 @@ _PROTOS = {
     "gt_bilinear2d_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p]),
     "gt_bilinear2d_fwd_affine": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.POINTER(GtResizeAffine),
                                                                                 C.c_void_p]),
+    "gt_conv3x3_resize_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.POINTER(GtDropout), C.c_int32,
+                                                                          C.c_void_p]),
+    "gt_conv3x3_resize_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 7 + [C.POINTER(GtDropout), C.c_int32,
+                                                                          C.c_void_p, C.c_void_p, C.c_int64,
+                                                                          C.c_void_p]),
+    "gt_conv3x3_resize_bwd_ws_bytes": (C.c_int64, [C.c_int32] * 5),
     "gt_bilinear2d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
 }
 
@@ -530,3 +536,33 @@ def bilinear2d_bwd(g: torch.Tensor, y_saved: Optional[torch.Tensor], in_size, in
         g.data_ptr(), ptr(y_saved), dx.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(in_nhwc), int(out_nhwc), act,
         stream_ptr()), shape=(B, Cc, Hi, Ho, int(in_nhwc), int(out_nhwc))), "gt_bilinear2d_bwd")
     return dx
+
+
+def conv3x3_resize_fwd(x: torch.Tensor, w: torch.Tensor, size, drop: Optional[GtDropout]) -> torch.Tensor:
+    """relu(resize(relu(dropout(conv3x3(x, w, padding=1))))) -- x [B,Cin,H,W], w [Cout,Cin,3,3] -> [B,Cout,Ho,Wo]."""
+    need_f32_cuda(x, w)
+    B, Cin, Hh, Ww = x.shape
+    Cout, Ho, Wo = w.shape[0], int(size[0]), int(size[1])
+    y = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device)
+    dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
+    check(_timed("gt_conv3x3_resize_fwd", 2.0 * 36 * Cin * y.numel(), 4.0 * (x.numel() + y.numel()),
+                 lambda: lib().gt_conv3x3_resize_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, Cout, Hh, Ww,
+                                                     Ho, Wo, dp, ACT_RELU, stream_ptr()),
+                 shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_fwd")
+    return y
+
+
+def conv3x3_resize_bwd(g: torch.Tensor, y: torch.Tensor, x: torch.Tensor, w: torch.Tensor,
+                       drop: Optional[GtDropout]) -> torch.Tensor:
+    need_f32_cuda(g, y, x, w)
+    B, Cin, Hh, Ww = x.shape
+    Cout, Ho, Wo = w.shape[0], y.shape[2], y.shape[3]
+    dw = torch.empty_like(w)
+    ws = workspace(x.device, lib().gt_conv3x3_resize_bwd_ws_bytes(B, Cin, Cout, Hh, Ww))
+    dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
+    check(_timed("gt_conv3x3_resize_bwd", 0, 4.0 * (x.numel() + 2 * y.numel()),
+                 lambda: lib().gt_conv3x3_resize_bwd(g.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), B, Cin,
+                                                     Cout, Hh, Ww, Ho, Wo, dp, ACT_RELU, dw.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), stream_ptr()),
+                 shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_bwd")
+    return dw

@@ -157,10 +157,27 @@ class Interp2dEncoder(nn.Module):
         self.add_res = residual
         self.debug = debug
 
+    def _conv0_fusable(self, x) -> bool:
+        """conv0 is the plain 3x3 / padding-1 / bias-free block on a <= 4-channel input that needs no
+        gradient, with ReLU on both sides of the resize: the case gt_conv3x3_resize_* implements."""
+        c = self.conv0
+        cv = c.conv[0]
+        size = self.interp_size[0]
+        size_ok = isinstance(size, float) or (isinstance(size, (tuple, list)) and not isinstance(size[0], float))
+        return (size_ok and isinstance(self.activation, nn.ReLU) and isinstance(c.activation, nn.ReLU)
+                and not c.add_res and not c.basic_block and cv.kernel_size == (3, 3) and cv.padding == (1, 1)
+                and cv.stride == (1, 1) and cv.dilation == (1, 1) and cv.groups == 1 and cv.bias is None
+                and cv.in_channels <= 4 and x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad))
+
     def forward(self, x, out_nhwc=False):
         """x (B, C, H, W).  ``out_nhwc`` returns (B, H', W', C') with the layout change fused into the
         last resize (what DownScaler feeds the encoder)."""
-        x = _resize(self.conv0(x), self.interp_size[0], self.activation)
+        if self._conv0_fusable(x):
+            # conv0 -> dropout -> relu -> resize -> relu in one pass; the out_dim-channel fine map never exists
+            x = ops.conv3x3_resize(x, self.conv0.conv[0].weight, self.interp_size[0], self.conv0.conv[1].p,
+                                   self.training)
+        else:
+            x = _resize(self.conv0(x), self.interp_size[0], self.activation)
         x1 = self.conv1(x)
         x2 = self.conv2(x1)
         x3 = self.conv3(x2)

@@ -108,6 +108,37 @@ def bilinear_resize(x, size, in_nhwc: bool = False, out_nhwc: bool = False, act:
     return ResizeFn.apply(x, (int(size[0]), int(size[1])), bool(in_nhwc), bool(out_nhwc), H.ACT_CODE[act])
 
 
+class Conv3x3ResizeFn(Function):
+    """relu(resize(relu(dropout(conv3x3(x))))) in one pass -- the head of Interp2dEncoder (layers.py:483-495)
+    when the input carries few channels and needs no gradient.  See gt_conv3x3_resize_fwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, size, p_drop: float):
+        xc, wc = _c(x), _c(weight)
+        salt = _next_salt(1)                     # the salt the stand-alone dropout would have drawn
+        drop = H.dropout_desc(p_drop, salt, x.device) if p_drop > 0 else None
+        y = H.conv3x3_resize_fwd(xc, wc, size, drop)
+        ctx.save_for_backward(xc, wc, y)
+        ctx.cfg = (p_drop, salt)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, wc, y = ctx.saved_tensors
+        p_drop, salt = ctx.cfg
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("conv3x3_resize: the fused path has no input gradient")
+        drop = H.dropout_desc(p_drop, salt, g.device) if p_drop > 0 else None
+        return None, H.conv3x3_resize_bwd(_c(g), y, xc, wc, drop), None, None
+
+
+def conv3x3_resize(x, weight, size, p_drop: float = 0.0, training: bool = True):
+    hi, wi = x.shape[2], x.shape[3]
+    if isinstance(size, float):
+        size = (int(math.floor(hi * size)), int(math.floor(wi * size)))
+    return Conv3x3ResizeFn.apply(x, weight, (int(size[0]), int(size[1])), float(p_drop) if training else 0.0)
+
+
 class UpsampleFcFn(Function):
     """fc(cat[upsample(x), grid]) without ever materialising upsample(x).
 

@@ -236,6 +236,25 @@ int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx, int32_t B
                       int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t in_nhwc,
                       int32_t out_nhwc, int32_t act, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * First stage of the CNN down-scaler in one pass (layers.py:483-495 with Conv2dResBlock :88-150):
+ *     y = relu( resize( relu( dropout( conv3x3(x; w), p ) ), (Ho, Wo) ) )
+ * x [B,Cin,H,W] (Cin <= 4), w [Cout,Cin,3,3] (padding 1, stride 1, no bias), y [B,Cout,Ho,Wo], all
+ * channels-first.  The Cout-channel fine-resolution map is never materialised.  The dropout mask is
+ * indexed by the linear NCHW index of the (virtual) conv output, i.e. identical to running
+ * gt_dropout_apply on it.  act must be GT_ACT_RELU.
+ * Backward produces the weight gradient only (dw [Cout,Cin,3,3]; two-pass deterministic reduction
+ * through ws); callers that need d/dx use the unfused operators.
+ * ------------------------------------------------------------------------------------------- */
+int gt_conv3x3_resize_fwd(const float* x, const float* w, float* y, int32_t B, int32_t Cin, int32_t Cout,
+                          int32_t H, int32_t W, int32_t Ho, int32_t Wo, const gt_dropout* drop, int32_t act,
+                          void* stream);
+int gt_conv3x3_resize_bwd(const float* g, const float* y, const float* x, const float* w, int32_t B,
+                          int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                          const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
+                          void* stream);
+int64_t gt_conv3x3_resize_bwd_ws_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W);
+
 #ifdef __cplusplus
 }
 #endif

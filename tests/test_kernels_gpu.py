@@ -450,3 +450,36 @@ def test_upsample_fc_commutes(H, gpu_device):
     out.backward(cot.float().to(gpu_device))
     assert rel_l2(out, ref) < 5e-6          # fp32 resize weights vs the fp64 reference (see the resize test)
     assert rel_l2(xg.grad, gx) < 5e-6 and rel_l2(Wg.grad, gW) < 5e-6 and rel_l2(bg.grad, gb) < 5e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout,n,size,p_drop", [(2, 1, 40, 29, (16, 16), 0.0), (2, 1, 128, 57, 0.555, 0.1),
+                                                      (1, 3, 20, 9, (25, 21), 0.2), (2, 2, 8, 6, (1, 4), 0.0)])
+def test_conv3x3_resize_fused_equals_unfused(H, gpu_device, B, Cin, Cout, n, size, p_drop):
+    """gt_conv3x3_resize_fwd/bwd == conv2d -> stateless dropout -> relu -> HIP resize(+relu) with the same
+    seed/salt (identical masks), output and weight gradient; p=0 case also against torch on the CPU."""
+    import torch.nn.functional as F
+    from galerkin_transformer import ops
+    dev = gpu_device
+    x = rnd(B, Cin, n, n + 2, dev=dev, seed=60)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, seed=61, scale=0.5)
+    outs = []
+    for fused in (True, False):
+        H.set_seed(777, dev)
+        ops._salt[0] = 11
+        wg = w.clone().requires_grad_(True)
+        if fused:
+            y = ops.conv3x3_resize(x, wg, size, p_drop, True)
+        else:
+            y0 = torch.relu(ops.dropout(F.conv2d(x, wg, padding=1), p_drop, True))
+            y = ops.bilinear_resize(y0, size, act="relu")
+        cot = rnd(*y.shape, dev=dev, seed=62)
+        y.backward(cot)
+        outs.append((y.detach(), wg.grad.detach()))
+    assert rel_l2(outs[0][0], outs[1][0]) < KTOL and rel_l2(outs[0][1], outs[1][1]) < 1e-5
+    if p_drop == 0.0:
+        xc, wc = x.cpu().double(), w.cpu().double().requires_grad_(True)
+        hw = outs[0][0].shape[2:]
+        ref = torch.relu(F.interpolate(torch.relu(F.conv2d(xc, wc, padding=1)), size=tuple(hw), mode="bilinear",
+                                       align_corners=True))
+        (gw,) = torch.autograd.grad(ref, wc, rnd(*ref.shape, dev="cpu", seed=62).double())
+        assert rel_l2(outs[0][0], ref) < 1e-5 and rel_l2(outs[0][1], gw) < 1e-5
