@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void conv_resize_bwd_kernel(const ConvResizeP 
                 load_patch(p.x + ((int64_t)b * CIN + ci) * plane, p.H, p.W, iy, ix, pt[ci][t]);
         }
         const float wt[4] = {ay.l0 * ax.l0, ay.l0 * ax.l1, ay.l1 * ax.l0, ay.l1 * ax.l1};
-#pragma unroll 2
+#pragma unroll          // full unroll: acc[j][..] must be statically indexed to stay in registers
         for (int j = 0; j < CRB_CG; ++j) {
             const int c = min(c0 + j, p.Cout - 1);                 // clamped: tail channels are not stored
             const int64_t o = ((int64_t)b * p.Cout + c) * oplane + e;
