@@ -13,6 +13,7 @@
 // ds_write_b32 of k-contiguous operands and the ds_read_b128 of the MFMA loop conflict-free.
 #include "gt_common.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -695,14 +696,21 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     if (d->M <= 0 || d->N <= 0 || d->K < 0 || d->batch0 <= 0 || d->batch1 <= 0) return GT_EINVAL;
     const int64_t batch = (int64_t)d->batch0 * d->batch1;
     if (batch > 65535) return GT_EINVAL;
-    int c;
-    if (d->N <= 16) c = 4;
-    else if (d->N <= 32) c = 3;
-    else if (d->N <= 64) c = 2;
-    else {
-        const int64_t blocks0 = (int64_t)ceil_div(d->M, 128) * ceil_div(d->N, 128) * batch;
-        if (d->M > 64 && blocks0 >= 384) c = 0;
-        else c = (d->N > 64) ? 1 : 2;
+    // Tile choice by a small cost model (calibrated on MI355X with tools/gemm_probe.py): the blocks that
+    // share a CU share its matrix pipes, so time ~ ceil(tiles / CUs) * tile area / efficiency of the
+    // configuration (MFMAs per LDS read / per barrier).  Padding waste shows up through the tile count.
+    static const double kEff[kNumCfg] = {1.00, 0.95, 0.80, 0.70, 0.45};
+    int c = 0;
+    double best = 0.0;
+    for (int i = 0; i < kNumCfg; ++i) {
+        const int bm = kCfgs[i].wm * 16 * kCfgs[i].mt, bn = kCfgs[i].wn * 16 * kCfgs[i].nt;
+        const double tiles = (double)ceil_div(d->M, bm) * ceil_div(d->N, bn) * (double)batch;
+        // under-filled grids: with split-K available the K-slices fill the chip (time ~ total padded work),
+        // otherwise every block has a CU to itself (time ~ one tile)
+        const bool can_split = d->split_k != 1 && d->K >= 512 && !has_epilogue(d);
+        const double units = tiles >= 256.0 ? std::ceil(tiles / 256.0) : (can_split ? tiles / 256.0 : 1.0);
+        const double cost = units * bm * bn / kEff[i];
+        if (i == 0 || cost < best) { best = cost; c = i; }
     }
     if (const char* e = getenv("GT_GEMM_CFG")) {      // tuning/debug override (tools/gemm_bench.py)
         const int f = atoi(e);
@@ -732,7 +740,7 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
         // aim at ~2 resident blocks per CU (two waves per SIMD hide each other's barriers and loads)
         int target = 512;
         if (const char* e = getenv("GT_GEMM_TARGET")) target = std::max(1, atoi(e));
-        if (!has_epilogue(d) && blocks < 192 && d->K >= 1024) {
+        if (!has_epilogue(d) && blocks < 384 && d->K >= 512) {
             split = (int)std::min<int64_t>((target + blocks / 2) / blocks, d->K / (4 * pl->bk));
             if (split < 1) split = 1;
         }
