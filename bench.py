@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets the "
+                    "multi-rank path be exercised with several ranks on one GPU in tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--table", default=None, help="write the per-kernel event table to this JSON file")
@@ -230,11 +232,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     import galerkin_transformer as gt
     from galerkin_transformer import _hip

@@ -87,7 +87,7 @@ class FlatGradAllReducer:
         torch._foreach_copy_(self.views, [g.reshape(-1) for g in grads])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.mul_(1.0 / self.world)
-        torch._foreach_copy_([g.view(-1) for g in grads], self.views)
+        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(self.views, grads)])
 
 
 def shard_range(n_items: int, rank: int, world: int, drop_last: bool = True):

@@ -78,3 +78,24 @@ def test_graph_step_equals_eager_step(gpu_device):
         outs.append([p.detach().clone() for p in model.parameters()])
     worst = max(float((a - b).abs().max()) for a, b in zip(*outs))
     assert worst < 1e-6, worst
+
+
+def test_bench_two_ranks_on_one_gpu_gloo(gpu_device):
+    """The multi-rank path of bench.py (split graphs, flat gradient all-reduce between them, barrier +
+    max-over-ranks timing, one JSON line from rank 0) with two ranks sharing cuda:0 over gloo.  RCCL itself
+    needs >= 2 GPUs and is exercised by the driver's scaling run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["hip_graph"]
+    assert rec["value"] > 0 and np.isfinite(rec["config"]["final_loss"])
