@@ -755,7 +755,7 @@ extern "C" int gt_headnorm_fwd(const float* qkv, const float* pos, const float* 
 }
 
 static inline int hn_tok_bwd(int h, int dk) { return hn_tok(2 * 3 * h * (dk + 1) + 9 * h); }
-constexpr int HN_MAXB = 512;       // bound on blocks (= dgamma/dbeta partials) of the backward
+constexpr int HN_MAXB = 1024;      // bound on blocks (= dgamma/dbeta partials) of the backward
 static inline int hn_blocks_bwd(int T, int h, int dk) {
     return std::min(ceil_div(T, hn_tok_bwd(h, dk)), HN_MAXB);
 }
