@@ -37,6 +37,8 @@ struct GemmP {
     DropDev drop; int drop_ld, n_off;      // mask index = (z*M + m)*drop_ld + n_off + n
     const float* res; int64_t ldr, r_bs0, r_bs1;
     float out_scale;
+    int ep_mode, n_out; const float* w2; int64_t ldw2; const float* b2; float* out2; const float* g2;
+    float* dw2_partial;      // MLP_BWD: [tiles_m * WM][n_out][N]
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------
@@ -268,7 +270,115 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const f32x4 (&acc)
     }
 }
 
-template <int LA, int LB, int MT, int NT, int WM, int WN, int BK>
+// Epilogues of the fused two-layer pointwise head (see gt_gemm_desc.ep_mode).  Called by every thread of
+// the block after the K loop (smem is free then); N <= BN, so the block owns complete rows.
+template <int MT, int NT, int WM, int WN, int NO>
+__device__ __forceinline__ void head_epilogue(const GemmP& p, const f32x4 (&acc)[MT][NT], float* smem, int m0,
+                                              int wm, int wn, int li, int kq, int tile_m) {
+    constexpr int BM = WM * 16 * MT;
+    const int nb = wn * 16 * NT + NT * li;
+    const int tid = threadIdx.x;
+    float biasv[NT], w2v[NO][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) w2v[o][t] = (o < p.n_out && nb + t < p.N) ? p.w2[(int64_t)o * p.ldw2 + nb + t] : 0.f;
+    }
+    if (p.ep_mode == GT_EP_ROWDOT) {
+        float* part = smem;                                    // [WN][BM][4]
+#pragma unroll
+        for (int s = 0; s < MT; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ml = wm * 16 * MT + MT * (4 * kq + r) + s;
+                float d[NO];
+#pragma unroll
+                for (int o = 0; o < NO; ++o) d[o] = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float v = p.alpha * acc[s][t][r] + biasv[t];
+                    v = (p.act == GT_ACT_RELU) ? fmaxf(v, 0.f) : (p.act == GT_ACT_SILU ? silu_f(v) : v);
+#pragma unroll
+                    for (int o = 0; o < NO; ++o) d[o] = fmaf(v, w2v[o][t], d[o]);
+                }
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {                 // sum over the 16 column lanes of this row
+                    float x = d[o];
+                    x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64);
+                    x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+                    d[o] = x;
+                }
+                if (li == 0) {
+#pragma unroll
+                    for (int o = 0; o < NO; ++o) part[(wn * BM + ml) * 4 + o] = d[o];
+                }
+            }
+        __syncthreads();
+        for (int e = tid; e < BM * p.n_out; e += blockDim.x) {
+            const int ml = e / p.n_out, o = e % p.n_out, m = m0 + ml;
+            if (m < p.M) {
+                float x = p.b2 ? p.b2[o] : 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) x += part[(w * BM + ml) * 4 + o];
+                p.out2[(int64_t)m * p.n_out + o] = x;
+            }
+        }
+    } else {                                                   // GT_EP_MLP_BWD
+        float cs[NO][NT];
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cs[o][t] = 0.f;
+#pragma unroll
+        for (int s = 0; s < MT; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 16 * MT + MT * (4 * kq + r) + s;
+                const bool ok = m < p.M;
+                float g[NO];
+#pragma unroll
+                for (int o = 0; o < NO; ++o) g[o] = (ok && o < p.n_out) ? p.g2[(int64_t)m * p.n_out + o] : 0.f;
+                float outv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float h = p.alpha * acc[s][t][r] + biasv[t];
+                    float gw = 0.f;
+#pragma unroll
+                    for (int o = 0; o < NO; ++o) gw = fmaf(g[o], w2v[o][t], gw);
+                    float a, da;
+                    if (p.act == GT_ACT_SILU) { a = silu_f(h); da = dsilu_f(h); }
+                    else if (p.act == GT_ACT_RELU) { a = fmaxf(h, 0.f); da = h > 0.f ? 1.f : 0.f; }
+                    else { a = h; da = 1.f; }
+                    outv[t] = gw * da;
+#pragma unroll
+                    for (int o = 0; o < NO; ++o) cs[o][t] = fmaf(g[o], a, cs[o][t]);
+                }
+                if (ok && nb < p.N) {
+                    float* cp = p.C + (int64_t)m * p.ldc + nb;
+                    if (NT == 4 && p.c_vec && nb + 4 <= p.N) *reinterpret_cast<f32x4*>(cp) = f32x4{outv[0], outv[1 % NT], outv[2 % NT], outv[3 % NT]};
+                    else {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) if (nb + t < p.N) cp[t] = outv[t];
+                    }
+                }
+            }
+        // dw2 partial of this wave's 16*MT rows: combine the 4 row lanes (kq), lanes kq == 0 store
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float x = cs[o][t];
+                x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+                if (kq == 0 && o < p.n_out && nb + t < p.N)
+                    p.dw2_partial[(((int64_t)tile_m * WM + wm) * p.n_out + o) * p.N + nb + t] = x;
+            }
+    }
+}
+
+// HEAD: instance with the fused two-layer-head epilogues instead of the general one (kept out of the
+// general instances: its register footprint would cost them occupancy)
+template <int LA, int LB, int MT, int NT, int WM, int WN, int BK, int HEAD = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     constexpr int BM = WM * 16 * MT, BN = WN * 16 * NT, T = WM * WN * 64;
     constexpr int FA = BM * BK / 4, FB = BN * BK / 4;          // float4 per stage
@@ -384,6 +494,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         }
     }
 
+    if (HEAD) {
+        head_epilogue<MT, NT, WM, WN, (HEAD > 0 ? HEAD : 1)>(p, acc, smem, m0, wm, wn, li, kq, tm);
+        return;
+    }
     // ------------------------------- epilogue -------------------------------------------------
     gemm_epilogue<MT, NT>(p, acc, m0 + wm * 16 * MT, n0 + wn * 16 * NT + NT * li, z, b0, b1, (int)blockIdx.y, kq);
 }
@@ -650,6 +764,22 @@ static void launch_cfg(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
     }
 }
 
+// fused two-layer head: activations [tokens, K] times nn.Linear weight [N, K] only (LA = LB = 0)
+template <int NO>
+static void launch_head_no(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
+    switch (cfg) {
+        case 0: hipLaunchKernelGGL((gemm_kernel<0, 0, 4, 4, 2, 2, 16, NO>), grid, dim3(256), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<0, 0, 2, 4, 2, 2, 16, NO>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<0, 0, 2, 2, 2, 2, 16, NO>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_kernel<0, 0, 2, 2, 4, 1, 16, NO>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<0, 0, 2, 1, 4, 1, 16, NO>), grid, dim3(256), 0, st, p); break;
+    }
+}
+static void launch_head(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
+    if (p.n_out == 1) launch_head_no<1>(cfg, grid, st, p);
+    else launch_head_no<4>(cfg, grid, st, p);
+}
+
 static int num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -689,7 +819,7 @@ static inline bool m4(int64_t v) { return (v & 3) == 0; }
 
 static bool has_epilogue(const gt_gemm_desc* d) {
     return d->bias || d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res ||
-           d->out_scale != 1.f;
+           d->out_scale != 1.f || d->ep_mode != GT_EP_NORMAL;
 }
 
 static int make_plan(const gt_gemm_desc* d, Plan* pl) {
@@ -704,13 +834,14 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     double best = 0.0;
     for (int i = 0; i < kNumCfg; ++i) {
         const int bm = kCfgs[i].wm * 16 * kCfgs[i].mt, bn = kCfgs[i].wn * 16 * kCfgs[i].nt;
+        if (d->ep_mode != GT_EP_NORMAL && bn < d->N) continue;      // the fused head needs whole rows per block
         const double tiles = (double)ceil_div(d->M, bm) * ceil_div(d->N, bn) * (double)batch;
         // under-filled grids: with split-K available the K-slices fill the chip (time ~ total padded work),
         // otherwise every block has a CU to itself (time ~ one tile)
         const bool can_split = d->split_k != 1 && d->K >= 512 && !has_epilogue(d);
         const double units = tiles >= 256.0 ? std::ceil(tiles / 256.0) : (can_split ? tiles / 256.0 : 1.0);
         const double cost = units * bm * bn / kEff[i];
-        if (i == 0 || cost < best) { best = cost; c = i; }
+        if (best == 0.0 || cost < best) { best = cost; c = i; }
     }
     if (const char* e = getenv("GT_GEMM_CFG")) {      // tuning/debug override (tools/gemm_bench.py)
         const int f = atoi(e);
@@ -728,6 +859,7 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
                  m4(d->ldb) && m4(d->a_bs0) && m4(d->a_bs1) && m4(d->b_bs0) && m4(d->b_bs1) &&
                  (d->layout_a == 0 || (d->M & 3) == 0) && (d->layout_b == 0 || (d->N & 3) == 0);
     if (const char* e = getenv("GT_GEMM_STREAM")) pl->stream = pl->stream && atoi(e) != 0;
+    if (d->ep_mode != GT_EP_NORMAL) { pl->stream = 0; pl->bk = 16; }
     if (pl->stream) pl->bk = 32;
     pl->bm = kCfgs[c].wm * 16 * kCfgs[c].mt;
     pl->bn = kCfgs[c].wn * 16 * kCfgs[c].nt;
@@ -808,13 +940,23 @@ extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
     Plan pl;
     if (make_plan(d, &pl)) return 0;
     const int64_t parts = acs_parts(d, pl);
+    if (d->ep_mode == GT_EP_MLP_BWD)
+        return (int64_t)pl.tiles_m * kCfgs[pl.cfg].wm * d->n_out * d->N * (int64_t)sizeof(float);
     return slab_bytes(d, pl) + (parts > 0 ? parts * d->M * (int64_t)sizeof(float) : 0);
 }
 
 // One kernel launch (+ split-K reduce) for the column range [n_off, n_off + d->N) of a problem whose
 // full width is drop_ld (d already points at that column range).
 static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int64_t ws_bytes, void* stream) {
-    if (!d || !d->A || !d->B || !d->C) return GT_EINVAL;
+    if (!d || !d->A || !d->B) return GT_EINVAL;
+    if (!d->C && d->ep_mode != GT_EP_ROWDOT) return GT_EINVAL;
+    if (d->ep_mode != GT_EP_NORMAL) {
+        if (d->ep_mode != GT_EP_ROWDOT && d->ep_mode != GT_EP_MLP_BWD) return GT_EINVAL;
+        if (d->N > 128 || d->batch0 * d->batch1 != 1 || d->n_out < 1 || d->n_out > 4 || !d->w2) return GT_ENOTSUP;
+        if (d->ep_mode == GT_EP_ROWDOT && !d->out2) return GT_EINVAL;
+        if (d->ep_mode == GT_EP_MLP_BWD && (!d->g2 || !d->dw2)) return GT_EINVAL;
+        if (d->a_colsum || d->a_drop.p > 0.f) return GT_ENOTSUP;
+    }
     if ((d->layout_a | d->layout_b) & ~1) return GT_EINVAL;
     if (d->rp < 0 || d->rp > 8) return GT_EINVAL;
     if ((d->a_drop.p > 0.f && !d->a_drop.seed) || (d->drop.p > 0.f && !d->drop.seed)) return GT_EINVAL;
@@ -841,6 +983,19 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     p.a_drop_ld = d->a_drop_ld; p.a_drop_bstride = d->a_drop_bstride;
 
     const int64_t mn = (int64_t)d->M * d->N;
+    float* dw2_partial = nullptr;
+    const int dw2_slabs = pl.tiles_m * kCfgs[pl.cfg].wm;
+    if (d->ep_mode != GT_EP_NORMAL) {
+        if (pl.tiles_n != 1 || pl.split != 1) return GT_ENOTSUP;
+        p.ep_mode = d->ep_mode; p.n_out = d->n_out; p.w2 = d->w2; p.ldw2 = d->ldw2; p.b2 = d->b2;
+        p.out2 = d->out2; p.g2 = d->g2;
+        if (d->ep_mode == GT_EP_MLP_BWD) {
+            const int64_t need = (int64_t)dw2_slabs * d->n_out * d->N * (int64_t)sizeof(float);
+            if (!ws || ws_bytes < need) return GT_EWS;
+            dw2_partial = reinterpret_cast<float*>(ws);
+            p.dw2_partial = dw2_partial;
+        }
+    }
     const int64_t parts = acs_parts(d, pl);
     float* acs_partial = nullptr;
     if (d->a_colsum) {
@@ -888,7 +1043,10 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
 
     dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split, (unsigned)batch);
     const int lay = d->layout_a * 2 + d->layout_b;
-    if (pl.stream) {
+    if (d->ep_mode != GT_EP_NORMAL) {
+        if (lay != 0) return GT_ENOTSUP;
+        launch_head(pl.cfg, grid, st, p);
+    } else if (pl.stream) {
         if (pl.cfg == 0) {
             if (lay == 0) launch_stream<0, 0, 4>(st, p);
             else if (lay == 1) launch_stream<0, 1, 4>(st, p);
@@ -912,6 +1070,11 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
         else launch_cfg<1, 1, 16>(pl.cfg, grid, st, p);
     }
     GT_LAUNCH_CHECK();
+    if (dw2_partial) {
+        const int64_t n2 = (int64_t)d->n_out * d->N;
+        int rc3 = gt_slab_reduce(dw2_partial, n2, dw2_slabs, n2, 1.f, d->dw2, stream);
+        if (rc3) return rc3;
+    }
     if (acs_partial) {
         const float sc = (d->a_drop.p > 0.f) ? 1.f : d->a_drop_sign;
         int rc2 = gt_slab_reduce(acs_partial, d->M, (int)parts, d->M, sc, d->a_colsum, stream);

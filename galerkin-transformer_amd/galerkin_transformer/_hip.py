@@ -17,6 +17,7 @@ _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
+EP_NORMAL, EP_ROWDOT, EP_MLP_BWD = 0, 1, 2
 ACT_CODE = {None: ACT_NONE, "none": ACT_NONE, "identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
 
 
@@ -49,6 +50,8 @@ class GtGemmDesc(C.Structure):
         ("drop", GtDropout),
         ("res", C.c_void_p), ("ldr", C.c_int64), ("r_bs0", C.c_int64), ("r_bs1", C.c_int64),
         ("out_scale", C.c_float),
+        ("ep_mode", C.c_int32), ("n_out", C.c_int32), ("w2", C.c_void_p), ("ldw2", C.c_int64),
+        ("b2", C.c_void_p), ("out2", C.c_void_p), ("g2", C.c_void_p), ("dw2", C.c_void_p),
     ]
 
 
@@ -127,7 +130,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.gt_abi_version() != 2:
+        if handle.gt_abi_version() != 3:
             raise RuntimeError("libgt_hip ABI version mismatch")
         _lib = handle
     return _lib
@@ -287,7 +290,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          pre: Optional[torch.Tensor] = None, ldpre: int = 0,
          aux_op: int = AUX_NONE, aux: Optional[torch.Tensor] = None, ldaux: int = 0, aux_bs=(0, 0),
          aux_scale: float = 1.0, drop: Optional[GtDropout] = None,
-         res: Optional[torch.Tensor] = None, ldr: int = 0, r_bs=(0, 0), out_scale: float = 1.0):
+         res: Optional[torch.Tensor] = None, ldr: int = 0, r_bs=(0, 0), out_scale: float = 1.0,
+         ep_mode: int = 0, w2: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None,
+         out2: Optional[torch.Tensor] = None, g2: Optional[torch.Tensor] = None,
+         dw2: Optional[torch.Tensor] = None):
     """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics)."""
     need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, a_colsum)
     L = lib()
@@ -299,7 +305,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     d.split_k = split_k
     d.A, d.lda, d.a_bs0, d.a_bs1 = A.data_ptr(), lda, a_bs[0], a_bs[1]
     d.B, d.ldb, d.b_bs0, d.b_bs1 = B.data_ptr(), ldb, b_bs[0], b_bs[1]
-    d.C, d.ldc, d.c_bs0, d.c_bs1 = Cout.data_ptr(), ldc, c_bs[0], c_bs[1]
+    d.C, d.ldc, d.c_bs0, d.c_bs1 = ptr(Cout), ldc, c_bs[0], c_bs[1]
     if a_drop is not None and a_drop.p > 0:
         d.a_drop = a_drop
         d.a_drop_ld, d.a_drop_bstride = a_drop_ld, a_drop_bstride
@@ -323,6 +329,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if res is not None:
         d.res, d.ldr, d.r_bs0, d.r_bs1 = res.data_ptr(), ldr, r_bs[0], r_bs[1]
     d.out_scale = out_scale
+    if ep_mode:
+        need_f32_cuda(w2, b2, out2, g2, dw2)
+        d.ep_mode, d.n_out, d.w2, d.ldw2 = ep_mode, w2.shape[0], w2.data_ptr(), w2.stride(0)
+        d.b2, d.out2, d.g2, d.dw2 = ptr(b2), ptr(out2), ptr(g2), ptr(dw2)
     need = L.gt_gemm_ws_bytes(C.byref(d))
     wsp, wsn = None, 0
     if need > 0:

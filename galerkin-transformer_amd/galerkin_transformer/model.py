@@ -169,8 +169,8 @@ class SpectralRegressor(nn.Module):
             x = layer(x)
             if self.return_latent:
                 x_latent.append(x.contiguous())
-        x = ops.linear(x, self.regressor[0].weight, self.regressor[0].bias, act=_act_name(self.activation))
-        x = ops.linear(x, self.regressor[2].weight, self.regressor[2].bias)
+        x = ops.mlp_head(x, self.regressor[0].weight, self.regressor[0].bias, self.regressor[2].weight,
+                         self.regressor[2].bias, act=_act_name(self.activation))
         if self.normalizer:
             x = self.normalizer.inverse_transform(x)
         if self.return_freq or self.return_latent:

@@ -281,6 +281,55 @@ def linear(x, weight, bias=None, extra=None, act: str = None, p_drop: float = 0.
     return LinearFn.apply(x, weight, bias, extra, H.ACT_CODE[act], float(p_drop))
 
 
+class MlpHeadFn(Function):
+    """y = W2 act(W1 x + b1) + b2 with a narrow output (n_out <= 4) and hidden width <= 128: the tail of
+    SpectralRegressor / PointwiseRegressor (model.py:575-580, 625-629).  The [T, hidden] activation never
+    reaches HBM in forward (row-dot epilogue); backward recomputes the pre-activation inside the GEMM that
+    produces dL/dh and gets dW2 as a by-product of the same launch."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act: int):
+        H.need_f32_cuda(x, w1, b1, w2, b2)
+        K, N, no = x.shape[-1], w1.shape[0], w2.shape[0]
+        x2 = _c(x).reshape(-1, K)
+        T = x2.shape[0]
+        w1c, w2c = _c(w1), _c(w2)
+        out = torch.empty(T, no, dtype=torch.float32, device=x.device)
+        H.gemm(x2, w1c, None, T, N, K, lda=K, ldb=K, ldc=N, bias=b1, act=act, ep_mode=H.EP_ROWDOT, w2=w2c, b2=b2,
+               out2=out)
+        ctx.save_for_backward(x2, w1c, b1, w2c)
+        ctx.cfg = (act, K, N, no, b1 is not None, b2 is not None, x.shape)
+        return out.reshape(*x.shape[:-1], no)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w1c, b1, w2c = ctx.saved_tensors
+        act, K, N, no, hb1, hb2, xshape = ctx.cfg
+        dev, T = gy.device, x2.shape[0]
+        g = _c(gy).reshape(T, no)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dh, dw2 = torch.empty(T, N, **f32), torch.empty(no, N, **f32)
+        H.gemm(x2, w1c, dh, T, N, K, lda=K, ldb=K, ldc=N, bias=b1, act=act, ep_mode=H.EP_MLP_BWD, w2=w2c, g2=g,
+               dw2=dw2)
+        db2 = H.colsum(g, T, no, no) if hb2 else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(T, K, **f32)
+            H.gemm(dh, w1c, dx, T, K, N, layout_b=1, lda=N, ldb=K, ldc=K)
+            dx = dx.reshape(xshape)
+        dw1 = torch.empty(N, K, **f32)
+        db1 = torch.empty(N, **f32) if hb1 else None
+        H.gemm(dh, x2, dw1, N, K, T, layout_a=1, layout_b=1, lda=N, ldb=K, ldc=K, split_k=0, a_colsum=db1)
+        return dx, dw1, db1, dw2, db2, None
+
+
+def mlp_head(x, w1, b1, w2, b2, act: str = "silu"):
+    """Fused two-layer pointwise head when it fits the kernel (hidden <= 128, n_out <= 4), else two linears."""
+    if w1.shape[0] <= 128 and w2.shape[0] <= 4 and w2.shape[1] == w1.shape[0]:
+        return MlpHeadFn.apply(x, w1, b1, w2, b2, H.ACT_CODE[act])
+    return linear(linear(x, w1, b1, act=act), w2, b2)
+
+
 # ----------------------------------------------------------------------------------- row LayerNorm
 class LayerNormFn(Function):
     """nn.LayerNorm(d_model) of the encoder layer (model.py:84-85, 128-135)."""

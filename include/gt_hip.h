@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 2
+#define GT_ABI_VERSION 3
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -118,7 +118,26 @@ typedef struct gt_gemm_desc {
     gt_dropout drop;                            /* mask index = (z*M + m)*N + n */
     const float* res; int64_t ldr, r_bs0, r_bs1;
     float out_scale;
+
+    /* Fused two-layer pointwise head  y = W2 act(W1 x + b1) + b2  with a narrow second layer (n_out <= 4):
+     * SpectralRegressor / PointwiseRegressor tail, model.py:575-580, 625-629.  Needs N <= 128 (one tile
+     * column), no batching, no split-K; of the epilogue fields above only alpha, bias and act are honoured.
+     *   GT_EP_ROWDOT  : out2[m][o] = sum_n act(alpha*acc + bias)[m][n] * w2[o*ldw2 + n] + b2[o];  C is NOT
+     *                   written -- the [M, N] hidden activation never reaches HBM.
+     *   GT_EP_MLP_BWD : h = alpha*acc + bias is the recomputed pre-activation;
+     *                   C[m][n] = (sum_o g2[m][o] * w2[o*ldw2 + n]) * act'(h[m][n])       (= dL/dh)
+     *                   dw2[o][n] = sum_m g2[m][o] * act(h[m][n])                          (by-product)   */
+    int32_t ep_mode, n_out;
+    const float* w2; int64_t ldw2;
+    const float* b2;        /* ROWDOT: [n_out] or NULL */
+    float* out2;            /* ROWDOT: [M, n_out] */
+    const float* g2;        /* MLP_BWD: [M, n_out] */
+    float* dw2;             /* MLP_BWD: [n_out, N] (row stride N) */
 } gt_gemm_desc;
+
+#define GT_EP_NORMAL  0
+#define GT_EP_ROWDOT  1
+#define GT_EP_MLP_BWD 2
 
 void    gt_gemm_desc_init(gt_gemm_desc* d);            /* zero + alpha=1, out_scale=1, batch=1 */
 int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d);

@@ -483,3 +483,26 @@ def test_conv3x3_resize_fused_equals_unfused(H, gpu_device, B, Cin, Cout, n, siz
                                        align_corners=True))
         (gw,) = torch.autograd.grad(ref, wc, rnd(*ref.shape, dev="cpu", seed=62).double())
         assert rel_l2(outs[0][0], ref) < 1e-5 and rel_l2(outs[0][1], gw) < 1e-5
+
+
+@pytest.mark.parametrize("T,K,N,no,act", [(1000, 32, 128, 1, "silu"), (777, 20, 96, 3, "relu"), (130, 48, 48, 1, "silu")])
+def test_mlp_head_fused(H, gpu_device, T, K, N, no, act):
+    """ops.mlp_head (row-dot epilogue forward, recompute + by-product backward) against fp64 torch."""
+    import torch.nn.functional as F
+    from galerkin_transformer import ops
+    x = rnd(T, K, dev="cpu", seed=70).double().requires_grad_(True)
+    w1 = rnd(N, K, dev="cpu", seed=71, scale=0.3).double().requires_grad_(True)
+    b1 = rnd(N, dev="cpu", seed=72).double().requires_grad_(True)
+    w2 = rnd(no, N, dev="cpu", seed=73, scale=0.3).double().requires_grad_(True)
+    b2 = rnd(no, dev="cpu", seed=74).double().requires_grad_(True)
+    fn = F.silu if act == "silu" else torch.relu
+    ref = F.linear(fn(F.linear(x, w1, b1)), w2, b2)
+    cot = rnd(T, no, dev="cpu", seed=75).double()
+    grads = torch.autograd.grad(ref, (x, w1, b1, w2, b2), cot)
+    dev = gpu_device
+    ins = [t.detach().float().to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    out = ops.mlp_head(*ins, act=act)
+    out.backward(cot.float().to(dev))
+    assert rel_l2(out, ref) < KTOL
+    for t, gref in zip(ins, grads):
+        assert rel_l2(t.grad, gref) < 5e-6
