@@ -1,0 +1,109 @@
+"""Full-size parity (-m gpu): one encoder layer / decoder block at the BASELINE.json configuration sizes
+(C1..C5) through the HIP path against the CPU oracle on the same seeded inputs, outputs
+and every gradient at the 1e-5 relative-L2 bar; plus size-independent properties at the bench batch."""
+import pytest
+import torch
+
+from _util import rel_l2, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer_case(gt, O, dev, *, B, n, d, h, p, ff, kind, layer_norm, attn_norm, eps, seed):
+    torch.manual_seed(seed)
+    layer = gt.SimpleTransformerEncoderLayer(d_model=d, pos_dim=p, n_head=h, dim_feedforward=ff,
+                                             attention_type=kind, layer_norm=layer_norm, attn_norm=attn_norm,
+                                             norm_eps=eps, dropout=0.0, ffn_dropout=0.0)
+    with torch.no_grad():
+        for prm in layer.parameters():
+            prm.add_(0.02 * torch.randn_like(prm))
+    x, pos, cot = torch.randn(B, n, d), torch.rand(B, n, p), torch.randn(B, n, d)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    ref_y, (ref_dx,), ref_dp = O.grads_of(
+        lambda s, xx: O.encoder_layer(s, xx, pos, n_head=h, attention_type=kind, layer_norm=layer_norm,
+                                      attn_norm=attn_norm, norm_eps=eps), sd, [x], cot)
+    gt.set_attention_dropout("off")
+    try:
+        layer = layer.to(dev)
+        xg = x.to(dev).requires_grad_(True)
+        y = layer(xg, pos.to(dev))
+        y.backward(cot.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        gt.set_attention_dropout("reference")
+    errs = {"out": rel_l2(y, ref_y), "dx": rel_l2(xg.grad, ref_dx)}
+    for k, v in dict(layer.named_parameters()).items():
+        errs[k] = rel_l2(v.grad, ref_dp[k])
+    return errs
+
+
+CASES = {
+    # cfg: B, n, d, h, p, ff, kind, layer_norm, attn_norm, eps
+    "C1_burgers_8192": dict(B=2, n=8192, d=64, h=4, p=1, ff=128, kind="galerkin", layer_norm=False, attn_norm=True, eps=1e-5),
+    "C1_yaml_d96_h1": dict(B=1, n=8192, d=96, h=1, p=1, ff=192, kind="galerkin", layer_norm=False, attn_norm=True, eps=1e-5),
+    "C2_darcy141_galerkin": dict(B=4, n=1849, d=128, h=4, p=2, ff=256, kind="galerkin", layer_norm=False, attn_norm=True, eps=1e-7),
+    "C3_darcy211_fourier": dict(B=1, n=3721, d=128, h=4, p=2, ff=256, kind="fourier", layer_norm=False, attn_norm=True, eps=1e-7),
+    "C4_darcy_inv": dict(B=4, n=1296, d=192, h=4, p=2, ff=384, kind="galerkin", layer_norm=False, attn_norm=True, eps=1e-7),
+    "C5_ns_lite": dict(B=2, n=4096, d=48, h=1, p=2, ff=96, kind="galerkin", layer_norm=True, attn_norm=False, eps=1e-5),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_encoder_layer_full_size(gpu_device, name):
+    import galerkin_transformer as gt
+    from oracle import galerkin_oracle as O
+    errs = _layer_case(gt, O, gpu_device, seed=11, **CASES[name])
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
+def test_spectral_conv2d_full_size(gpu_device):
+    """SpectralConv2d at 141x141, 32 channels, 12 modes (the C2 decoder block)."""
+    import galerkin_transformer as gt
+    from oracle import galerkin_oracle as O
+    torch.manual_seed(5)
+    conv = gt.SpectralConv2d(32, 32, 12, dropout=0.0)
+    with torch.no_grad():
+        for prm in conv.parameters():
+            prm.add_(0.02 * torch.randn_like(prm))
+    x, cot = torch.randn(2, 141, 141, 32), torch.randn(2, 141, 141, 32)
+    sd = {k: v.clone() for k, v in conv.state_dict().items()}
+    ref, (ref_dx,), ref_dp = O.grads_of(lambda s, xx: O.spectral_conv2d(s, xx, modes=12), sd, [x], cot)
+    conv = conv.to(gpu_device)
+    xg = x.to(gpu_device).requires_grad_(True)
+    y = conv(xg)
+    y.backward(cot.to(gpu_device))
+    errs = {"out": rel_l2(y, ref), "dx": rel_l2(xg.grad, ref_dx)}
+    for k, v in dict(conv.named_parameters()).items():
+        errs[k] = rel_l2(v.grad, ref_dp[k])
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
+def test_galerkin_attention_equivariances_at_bench_batch(gpu_device):
+    """Size-independent properties at the bench's per-GPU batch (128 x 1849 tokens, 236 672 tokens in all),
+    attention dropout off: (i) samples are independent -- permuting the batch permutes the output;
+    (ii) Galerkin attention is permutation-equivariant over tokens (K^T V is a sum over tokens, the rows of Q
+    are independent) -- permuting tokens together with their coordinates permutes the output rows."""
+    import galerkin_transformer as gt
+    B, n, d, h, p = 128, 1849, 128, 4, 2
+    torch.manual_seed(3)
+    attn = gt.SimpleAttention(h, d, pos_dim=p, attention_type="galerkin", norm=True, eps=1e-7,
+                              dropout=0.0).to(gpu_device)
+    x = torch.randn(B, n, d, device=gpu_device)
+    pos = torch.rand(B, n, p, device=gpu_device)
+    gt.set_attention_dropout("off")
+    try:
+        with torch.no_grad():
+            y, _ = attn(x, x, x, pos=pos)
+            bp = torch.randperm(B, device=gpu_device)
+            xb = x[bp]
+            yb, _ = attn(xb, xb, xb, pos=pos[bp])
+            tp = torch.randperm(n, device=gpu_device)
+            xt = x[:, tp].contiguous()
+            yt, _ = attn(xt, xt, xt, pos=pos[:, tp].contiguous())
+    finally:
+        gt.set_attention_dropout("reference")
+    assert torch.isfinite(y).all()
+    assert torch.equal(yb, y[bp])                      # same kernels, same per-sample arithmetic: bitwise
+    assert rel_l2(yt, y[:, tp]) < TOL                  # summation order over tokens changes: fp32 noise only
