@@ -392,6 +392,104 @@ static bool head_geom(int T, int h, int dk, int p, int norm_mask, int max_blocks
     return true;
 }
 
+// ------------------------------------------------------------------------------------------ galerkin K^T V
+// M[b,h] = K'^T V' over the tokens of one sample (layers.py:723), K', V' in the head-tile layout
+// [T][h][DP] = [pos(p) | values(dk) | pad].  Streaming kernel: every token row is read exactly once,
+// straight from HBM into MFMA operand registers (no LDS): lane (i = lane&15, k = lane>>4) of a wave holds
+// K'[t0+k][p+16a+i] and V'[t0+k][p+16b+i] for 4 tokens per step, i.e. the A = K^T (16 x 4) and B = V
+// (4 x 16) fragments of v_mfma_f32_16x16x4_f32.  The dk x dk core accumulates on the matrix pipe, the p-wide
+// coordinate borders (P^T P, P^T V, K^T P) on the VALU beside it.  A block = 4 waves = 4 heads (looped if
+// h > 4) of one token chunk of one sample; chunks write partial slabs that gt_galerkin_finalize_fwd sums.
+template <int NB>
+__global__ __launch_bounds__(256) void galerkin_ktv_kernel(const float* __restrict__ Kp, const float* __restrict__ Vp,
+                                                           int n, int h, int DP, int p, int chunk,
+                                                           float* __restrict__ slabs, int B) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int t_lo = ch * chunk, t_hi = min(n, t_lo + chunk);
+    const int64_t hD = (int64_t)h * DP;
+    for (int head = wave; head < h; head += 4) {
+        f32x4 acc[NB][NB];
+        float kp[NB][2], pv[NB][2], pp[2][2];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kp[a][0] = kp[a][1] = pv[a][0] = pv[a][1] = 0.f;
+        }
+        pp[0][0] = pp[0][1] = pp[1][0] = pp[1][1] = 0.f;
+        const float* kb = Kp + ((int64_t)b * n) * hD + (int64_t)head * DP;
+        const float* vb = Vp + ((int64_t)b * n) * hD + (int64_t)head * DP;
+        for (int tb = t_lo; tb < t_hi; tb += 16) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {                       // 4 independent 4-token steps in flight
+            const int t0 = tb + 4 * u;
+            const int t = t0 + kq;
+            const bool ok = t < t_hi;
+            const float* kr = kb + (int64_t)t * hD;
+            const float* vr = vb + (int64_t)t * hD;
+            float a[NB], v[NB], pk[2] = {0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                a[c] = ok ? kr[p + 16 * c + i] : 0.f;
+                v[c] = ok ? vr[p + 16 * c + i] : 0.f;
+            }
+            if (p > 0) pk[0] = ok ? kr[0] : 0.f;
+            if (p > 1) pk[1] = ok ? kr[1] : 0.f;
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+#pragma unroll
+                for (int e = 0; e < NB; ++e) acc[c][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], v[e], acc[c][e], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                kp[c][0] = fmaf(a[c], pk[0], kp[c][0]); kp[c][1] = fmaf(a[c], pk[1], kp[c][1]);
+                pv[c][0] = fmaf(pk[0], v[c], pv[c][0]); pv[c][1] = fmaf(pk[1], v[c], pv[c][1]);
+            }
+            pp[0][0] = fmaf(pk[0], pk[0], pp[0][0]); pp[0][1] = fmaf(pk[0], pk[1], pp[0][1]);
+            pp[1][0] = fmaf(pk[1], pk[0], pp[1][0]); pp[1][1] = fmaf(pk[1], pk[1], pp[1][1]);
+          }
+        }
+        // borders: combine the 4 token lanes
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                kp[c][e] += __shfl_xor(kp[c][e], 16, 64); kp[c][e] += __shfl_xor(kp[c][e], 32, 64);
+                pv[c][e] += __shfl_xor(pv[c][e], 16, 64); pv[c][e] += __shfl_xor(pv[c][e], 32, 64);
+            }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { pp[c][e] += __shfl_xor(pp[c][e], 16, 64); pp[c][e] += __shfl_xor(pp[c][e], 32, 64); }
+
+        float* M = slabs + ((((int64_t)ch * B + b) * h + head) * DP) * DP;
+        const int Dr = p + 16 * NB;
+        // core: D layout of the 16x16 tile: row = 4*kq + r, col = i
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int e = 0; e < NB; ++e)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) M[(int64_t)(p + 16 * c + 4 * kq + r) * DP + p + 16 * e + i] = acc[c][e][r];
+        if (kq == 0) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                for (int e = 0; e < p; ++e) {
+                    M[(int64_t)(p + 16 * c + i) * DP + e] = kp[c][e];         // K^T P
+                    M[(int64_t)e * DP + p + 16 * c + i] = pv[c][e];           // P^T V
+                }
+            if (i == 0)
+                for (int c = 0; c < p; ++c)
+                    for (int e = 0; e < p; ++e) M[(int64_t)c * DP + e] = pp[c][e];
+        }
+        for (int e = lane; e < DP * DP; e += 64) {               // zero padding rows / columns
+            const int rr = e / DP, cc = e % DP;
+            if (rr >= Dr || cc >= Dr) M[e] = 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ galerkin finalize
 __global__ __launch_bounds__(256) void galerkin_fin_fwd_kernel(
     const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int h, int DP, int Dr, int d,
@@ -898,6 +996,34 @@ extern "C" int gt_modemix_bwd(const float* X, const float* W, const float* dY, i
     if (int rc = allow_big_lds(modemix_bwd_kernel, lds)) return rc;
     hipLaunchKernelGGL(modemix_bwd_kernel, dim3(Q), dim3(256), lds, (hipStream_t)stream, X, W, dY, B, Q, Cin,
                        Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, dX, dW);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int32_t gt_galerkin_ktv_slabs(int32_t B, int32_t n) {
+    // token chunks per sample: enough blocks to fill the chip (~4 per CU), at least 64 tokens per chunk
+    int chunks = std::max(1, std::min(ceil_div(1024, std::max(B, 1)), ceil_div(n, 64)));
+    return chunks;
+}
+
+extern "C" int gt_galerkin_ktv(const float* Kp, const float* Vp, int32_t B, int32_t n, int32_t h, int32_t dk,
+                               int32_t p, float* slabs, int32_t n_slabs, void* stream) {
+    if (!Kp || !Vp || !slabs || B <= 0 || n <= 0 || h <= 0 || dk <= 0 || p < 0 || n_slabs <= 0) return GT_EINVAL;
+    if ((dk & 15) || dk > 96 || p > 2) return GT_ENOTSUP;
+    if (B > 65535) return GT_EINVAL;
+    const int DP = round4(dk + p);
+    const int chunk = ((ceil_div(n, n_slabs) + 3) / 4) * 4;
+    if ((int64_t)chunk * n_slabs < n) return GT_EINVAL;
+    dim3 grid((unsigned)n_slabs, (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dk / 16) {
+        case 1: hipLaunchKernelGGL(galerkin_ktv_kernel<1>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B); break;
+        case 2: hipLaunchKernelGGL(galerkin_ktv_kernel<2>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B); break;
+        case 3: hipLaunchKernelGGL(galerkin_ktv_kernel<3>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B); break;
+        case 4: hipLaunchKernelGGL(galerkin_ktv_kernel<4>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B); break;
+        case 6: hipLaunchKernelGGL(galerkin_ktv_kernel<6>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B); break;
+        default: return GT_ENOTSUP;
+    }
     GT_LAUNCH_CHECK();
     return 0;
 }

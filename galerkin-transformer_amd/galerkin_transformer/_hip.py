@@ -78,6 +78,8 @@ _PROTOS = {
     "gt_headnorm_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p] * 4 + [C.c_int64,
                                                                                         C.c_void_p]),
     "gt_headnorm_bwd_ws_bytes": (C.c_int64, [C.c_int32] * 3),
+    "gt_galerkin_ktv_slabs": (C.c_int32, [C.c_int32, C.c_int32]),
+    "gt_galerkin_ktv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
     "gt_galerkin_finalize_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64] + [C.c_int32] * 6 +
                                  [C.c_void_p, C.POINTER(GtDropout), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
@@ -576,3 +578,18 @@ def conv3x3_resize_bwd(g: torch.Tensor, y: torch.Tensor, x: torch.Tensor, w: tor
                                                      ws.data_ptr(), ws.numel(), stream_ptr()),
                  shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_bwd")
     return dw
+
+
+def galerkin_ktv(Kp: torch.Tensor, Vp: torch.Tensor, B: int, n: int, h: int, dk: int, p: int):
+    """K'^T V' partial slabs [n_slabs, B, h, DP, DP] from head tiles [B*n, h, DP]; None if the streaming kernel
+    does not cover this head size (caller falls back to the batched GEMM)."""
+    need_f32_cuda(Kp, Vp)
+    if dk % 16 or dk > 96 or dk // 16 == 5 or p > 2:
+        return None
+    DP = round4(dk + p)
+    ns = lib().gt_galerkin_ktv_slabs(B, n)
+    slabs = torch.empty(ns, B, h, DP, DP, dtype=torch.float32, device=Kp.device)
+    check(_timed("gt_galerkin_ktv", 2.0 * B * h * n * DP * DP, 8.0 * B * n * h * DP,
+                 lambda: lib().gt_galerkin_ktv(Kp.data_ptr(), Vp.data_ptr(), B, n, h, dk, p, slabs.data_ptr(), ns,
+                                               stream_ptr()), shape=(B, n, h, dk, p)), "gt_galerkin_ktv")
+    return slabs

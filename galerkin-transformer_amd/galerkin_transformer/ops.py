@@ -457,10 +457,13 @@ class SimpleAttentionFn(Function):
         d_attn = H.dropout_desc(p_attn, salt, dev) if (p_attn > 0 and mask is None) else None
         d_out = H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None
         if kind == "galerkin":
-            mraw = torch.empty(B, h, DP, DP, dtype=torch.float32, device=dev)
-            H.gemm(Kp, Vp, mraw, DP, DP, n, layout_a=1, layout_b=1, lda=hD, ldb=hD, ldc=DP, batch=(B, h),
-                   a_bs=(n * hD, DP), b_bs=(n * hD, DP), c_bs=(h * DP * DP, DP * DP), split_k=0)
-            Mt, P = H.galerkin_finalize_fwd(mraw, 1, B * h * DP * DP, B, h, DP, Dr, d, n, mask, d_attn, wf)
+            slabs = H.galerkin_ktv(Kp, Vp, B, n, h, dk, p)          # streaming MFMA kernel, token chunks
+            if slabs is None:                                       # head sizes it does not cover
+                slabs = torch.empty(1, B, h, DP, DP, dtype=torch.float32, device=dev)
+                H.gemm(Kp, Vp, slabs, DP, DP, n, layout_a=1, layout_b=1, lda=hD, ldb=hD, ldc=DP, batch=(B, h),
+                       a_bs=(n * hD, DP), b_bs=(n * hD, DP), c_bs=(h * DP * DP, DP * DP), split_k=0)
+            Mt, P = H.galerkin_finalize_fwd(slabs, slabs.shape[0], B * h * DP * DP, B, h, DP, Dr, d, n, mask,
+                                            d_attn, wf)
             H.gemm(Qp, P, out, n, d, hD, layout_b=1, lda=hD, ldb=d, ldc=d, batch=(B, 1), a_bs=(n * hD, 0),
                    b_bs=(hD * d, 0), c_bs=(n * d, 0), bias=bfc, drop=d_out, res=rc, ldr=d, r_bs=(n * d, 0),
                    out_scale=sign)

@@ -188,6 +188,14 @@ int64_t gt_headnorm_bwd_ws_bytes(int32_t T, int32_t h, int32_t dk);
  * Backward: from dPt[b][c][h*DP+j] (= d attn_out^T Q') produce
  *   dM[b,h]  = mask .* (dP_h Wfc_h) / n        and      dWfc slabs [B][d][h*Dr].
  * ------------------------------------------------------------------------------------------- */
+/* K'^T V' (layers.py:723) as a streaming kernel on the head-tile layout [B*n][h][DP] (what
+ * gt_headnorm_fwd writes): token rows go from HBM straight into MFMA operand registers, the dk x dk core
+ * accumulates on the matrix pipe and the p-wide coordinate borders on the VALU.  Writes n_slabs partial
+ * [B,h,DP,DP] slabs (token chunks) that gt_galerkin_finalize_fwd sums.  dk % 16 == 0, dk <= 96, p <= 2
+ * (else GT_ENOTSUP: use gt_gemm).  gt_galerkin_ktv_slabs suggests n_slabs. */
+int32_t gt_galerkin_ktv_slabs(int32_t B, int32_t n);
+int gt_galerkin_ktv(const float* Kp, const float* Vp, int32_t B, int32_t n, int32_t h, int32_t dk, int32_t p,
+                    float* slabs, int32_t n_slabs, void* stream);
 int gt_galerkin_finalize_fwd(const float* slabs, int32_t n_slabs, int64_t slab_stride,
                              int32_t B, int32_t h, int32_t DP, int32_t Dr, int32_t d, int32_t n_tokens,
                              const float* mask, const gt_dropout* drop, const float* Wfc,
