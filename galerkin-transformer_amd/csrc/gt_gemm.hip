@@ -931,8 +931,8 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
     if (pl.stream)
         snprintf(buf, n, "void gt::gemm_stream_kernel<%d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b, c.mt);
     else
-        snprintf(buf, n, "void gt::gemm_kernel<%d, %d, %d, %d, %d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b,
-                 c.mt, c.nt, c.wm, c.wn, pl.bk);
+        snprintf(buf, n, "void gt::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b,
+                 c.mt, c.nt, c.wm, c.wn, pl.bk, d->ep_mode == GT_EP_NORMAL ? 0 : (d->n_out == 1 ? 1 : 4));
     return 0;
 }
 

@@ -33,8 +33,19 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     const int ox = threadIdx.x & 15, sy = threadIdx.x >> 4;
     const int64_t i = (int64_t)blockIdx.x * 16 + ox;
     float s = 0.f;
-    if (i < n)
-        for (int k = sy; k < n_slabs; k += 16) s += slabs[k * stride + i];
+    if (i < n) {
+        // 4 independent partial sums per lane keep 4 loads in flight; combined in a fixed order
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = sy;
+        for (; k + 48 < n_slabs; k += 64) {
+            s0 += slabs[(int64_t)k * stride + i];
+            s1 += slabs[(int64_t)(k + 16) * stride + i];
+            s2 += slabs[(int64_t)(k + 32) * stride + i];
+            s3 += slabs[(int64_t)(k + 48) * stride + i];
+        }
+        for (; k < n_slabs; k += 16) s0 += slabs[(int64_t)k * stride + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[sy][ox] = s;
     __syncthreads();
     if (sy == 0 && i < n) {
