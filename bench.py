@@ -33,23 +33,55 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f3
 PEAK_HBM_GBS = 8000.0
 
 
-def darcy_config():
+# name -> (config.yml section, fine subsample, coarse subsample, config overrides, where the target lives)
+# The headline (BASELINE.json configs[1]) is ex2_darcy141; the others are informational end-to-end runs of
+# the remaining 2-D configurations through the same training step.
+WORKLOADS = {
+    "ex2_darcy141": ("ex2_darcy", 3, 10, dict(), "fine"),
+    "ex2_darcy211_fourier": ("ex2_darcy", 2, 7, dict(attention_type="fourier", xavier_init=0.001), "fine"),
+    "ex3_darcy_inv": ("ex3_darcy_inv", 3, 12, dict(), "coarse"),
+}
+
+
+WORKLOAD_TEXT = {
+    "ex2_darcy141": "ex2_darcy FourierTransformer2D 141x141 fine / 43x43 coarse, galerkin, "
+                    "6 layers d=128 h=4 ffn=256, 2x SpectralConv2d(32, modes 12)",
+    "ex2_darcy211_fourier": "ex2_darcy FourierTransformer2D 211x211 fine / 61x61 coarse, fourier (QK^T)V, "
+                            "6 layers d=128 h=4 ffn=256, 2x SpectralConv2d(32, modes 12) [informational]",
+    "ex3_darcy_inv": "ex3_darcy_inv FourierTransformer2D 141x141 -> 36x36, galerkin, 6 layers d=192 h=4 ffn=384, "
+                     "pointwise decoder [informational]",
+}
+
+
+def _n(sub):
+    return (421 - 1) // sub + 1
+
+
+def darcy_config(workload="ex2_darcy141"):
     import yaml
     from galerkin_transformer.ft import DarcyDataset
+    section, sf, sc, over, where = WORKLOADS[workload]
     with open(os.path.join(ROOT, "galerkin-transformer_amd", "config.yml")) as f:
-        cfg = yaml.full_load(f)["ex2_darcy"]
-    down, up = DarcyDataset.get_scaler_sizes(N_FINE, N_COARSE)
+        cfg = yaml.full_load(f)[section]
+    n_f, n_c = _n(sf), _n(sc)
+    down, up = DarcyDataset.get_scaler_sizes(n_f, n_c)
+    if where == "coarse":                      # ex3: the decoder works on the coarse grid (ex3_darcy_inv.py)
+        up = ((n_c, n_c), (n_c, n_c))
     cfg.update(downscaler_size=down, upscaler_size=up, attn_norm=True, norm_eps=1e-7, normalizer=None)
+    cfg.update(over)
     return cfg
 
 
-def synthetic_batch(B, device, seed):
+def synthetic_batch(B, device, seed, workload="ex2_darcy141"):
     from galerkin_transformer.ft import DarcyDataset
+    _, sf, sc, _, where = WORKLOADS[workload]
+    n_f, n_t = _n(sf), (_n(sf) if where == "fine" else _n(sc))
     g = torch.Generator().manual_seed(seed)
-    node = torch.randn(B, N_FINE, N_FINE, 1, generator=g)
-    target = torch.randn(B, N_FINE, N_FINE, 1, generator=g)
-    pos = torch.from_numpy(DarcyDataset.get_grid(421, subsample=10, return_elem=False)).float()
-    grid = torch.from_numpy(DarcyDataset.get_grid(421, subsample=3, return_elem=False)).float()
+    node = torch.randn(B, n_f, n_f, 1, generator=g)
+    target = torch.randn(B, n_t, n_t, 1, generator=g)
+    pos = torch.from_numpy(DarcyDataset.get_grid(421, subsample=sc, return_elem=False)).float()
+    grid = torch.from_numpy(DarcyDataset.get_grid(421, subsample=(sf if where == "fine" else sc),
+                                                  return_elem=False)).float()
     pos = pos.reshape(1, -1, 2).repeat(B, 1, 1)
     grid = grid.unsqueeze(0).repeat(B, 1, 1, 1)
     return [t.to(device).contiguous() for t in (node, pos, grid, target)]
@@ -219,6 +251,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--workload", default="ex2_darcy141", choices=sorted(WORKLOADS),
+                    help="ex2_darcy141 is the headline metric; the others are informational")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets the "
                     "multi-rank path be exercised with several ranks on one GPU in tests)")
@@ -245,7 +279,7 @@ def main():
     import galerkin_transformer as gt
     from galerkin_transformer import _hip
     _hip.lib()                                           # fail loudly if the HIP library is missing
-    cfg = darcy_config()
+    cfg = darcy_config(a.workload)
     torch.manual_seed(1127802)                           # identical init on every rank
     model = gt.FourierTransformer2D(**cfg)
     cpu_sd = {k: v.clone() for k, v in model.state_dict().items()}
@@ -253,7 +287,7 @@ def main():
     gt.set_attention_dropout("reference")
     from galerkin_transformer.distributed import rank_seed
     _hip.set_seed(rank_seed(1127802, rank), dev)         # per-rank dropout streams
-    batch = synthetic_batch(a.batch, dev, seed=1000 + rank)
+    batch = synthetic_batch(a.batch, dev, seed=1000 + rank, workload=a.workload)
     tr = Trainer(model, batch, world, use_graph=not a.no_graph)
     graphed = tr.capture()
 
@@ -283,7 +317,7 @@ def main():
         except Exception as e:
             print(f"[bench] roofline leg failed: {type(e).__name__}: {e}", file=sys.stderr)
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "ex2_darcy141":
         try:
             cpu = cpu_baseline_leg(cpu_sd, cfg)
         except Exception as e:
@@ -295,13 +329,14 @@ def main():
         gb = a.batch * world
         value = gb * a.steps / elapsed
         out = {
-            "metric": "training samples/s, Darcy 141x141 Galerkin encoder (fwd+loss+bwd+clip+Adam)",
+            "metric": ("training samples/s, Darcy 141x141 Galerkin encoder (fwd+loss+bwd+clip+Adam)"
+                       if a.workload == "ex2_darcy141" else
+                       f"training samples/s, {a.workload} (informational, not the headline metric)"),
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (randn node/target of the Darcy shapes, true 43^2/141^2 grids, random init)",
-            "config": {"workload": "ex2_darcy FourierTransformer2D 141x141 fine / 43x43 coarse, galerkin, "
-                                   "6 layers d=128 h=4 ffn=256, 2x SpectralConv2d(32, modes 12)",
+            "config": {"workload": WORKLOAD_TEXT[a.workload],
                        "params": sum(p.numel() for p in model.parameters()),
                        "global_batch": gb, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "hip_graph": bool(graphed), "optimizer": tr.opt_kind,
