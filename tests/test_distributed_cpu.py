@@ -43,8 +43,10 @@ def _worker(rank, world, port, q):
     red = FlatGradAllReducer(model.parameters())
     red.reduce()
     norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.05)
-    q.put((rank, [p.detach().clone() for p in model.parameters()],
-           [p.grad.clone() for p in model.parameters()], float(norm), red.nbytes))
+    # numpy arrays travel through the queue by value (torch tensors would be shared through a file descriptor
+    # served by this process, which may exit before the parent reads them)
+    q.put((rank, [p.detach().numpy().copy() for p in model.parameters()],
+           [p.grad.numpy().copy() for p in model.parameters()], float(norm), red.nbytes))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,6 +70,8 @@ def test_flat_allreduce_two_ranks_gloo():
     ((ref(X) - Y) ** 2).mean().backward()
     ref_norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
     for rank, params, grads, norm, nbytes in res:
+        params = [torch.from_numpy(a) for a in params]
+        grads = [torch.from_numpy(a) for a in grads]
         for p, rp in zip(params, ref.parameters()):
             assert torch.equal(p, rp.detach())                    # broadcast made the ranks identical
         for gr, rp in zip(grads, ref.parameters()):
