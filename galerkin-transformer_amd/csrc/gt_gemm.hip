@@ -39,6 +39,8 @@ struct GemmP {
     float out_scale;
     int ep_mode, n_out; const float* w2; int64_t ldw2; const float* b2; float* out2; const float* g2;
     float* dw2_partial;      // MLP_BWD: [tiles_m * WM][n_out][N]
+    int K2; const float* A2; int64_t lda2, a2_bs0, a2_bs1; const float* B2; int64_t ldb2, b2_bs0, b2_bs1;
+    int a2_vec, b2_vec;
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------
@@ -379,7 +381,8 @@ __device__ __forceinline__ void head_epilogue(const GemmP& p, const f32x4 (&acc)
 // HEAD: instance with the fused two-layer-head epilogues instead of the general one (kept out of the
 // general instances: its register footprint would cost them occupancy)
 template <int LA, int LB, int MT, int NT, int WM, int WN, int BK, int HEAD = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
+// (4 waves per SIMD requested for the 16-deep general instances: keeps the register allocation at <= 128)
+__global__ __launch_bounds__(WM* WN * 64, ((HEAD == 0 && BK == 16) ? 4 : 1)) void gemm_kernel(const GemmP p) {
     constexpr int BM = WM * 16 * MT, BN = WN * 16 * NT, T = WM * WN * 64;
     constexpr int FA = BM * BK / 4, FB = BN * BK / 4;          // float4 per stage
     constexpr int NVA = (FA + T - 1) / T, NVB = (FB + T - 1) / T;
@@ -405,8 +408,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int kbeg = blockIdx.y * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
 
-    const float* __restrict__ A = p.A + b0 * p.a_bs0 + b1 * p.a_bs1;
-    const float* __restrict__ Bm = p.B + b0 * p.b_bs0 + b1 * p.b_bs1;
+    // operands of the K segment being loaded (uniform values; switched once when a second product follows)
+    const float* A = p.A + b0 * p.a_bs0 + b1 * p.a_bs1;
+    const float* Bm = p.B + b0 * p.b_bs0 + b1 * p.b_bs1;
+    int64_t lda_c = p.lda, ldb_c = p.ldb;
+    int kend_c = min(p.K, (int)blockIdx.y * p.k_chunk + p.k_chunk), avec_c = p.a_vec, bvec_c = p.b_vec;
     const uint32_t akey = drop_key_dev(p.a_drop);
     const int64_t adoff = (int64_t)z * p.a_drop_bstride;
     const DropDev nodrop{0u, 0u, 1.f, nullptr};
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         for (int i = 0; i < NVA; ++i) {
             const int idx = tid + i * T;
             if (FA % T == 0 || idx < FA) {
-                ra[i] = gload<LA, BM, BK>(A, p.lda, m0, p.M, k0, kend, idx, p.a_vec, p.a_drop, akey,
+                ra[i] = gload<LA, BM, BK>(A, lda_c, m0, p.M, k0, kend_c, idx, avec_c, p.a_drop, akey,
                                           p.a_drop_ld, adoff);
                 if (LA == 1 && do_acs) asum += ra[i];
             }
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         for (int i = 0; i < NVB; ++i) {
             const int idx = tid + i * T;
             if (FB % T == 0 || idx < FB)
-                rb[i] = gload<LB, BN, BK>(Bm, p.ldb, n0, p.N, k0, kend, idx, p.b_vec, nodrop, 0u, 0, 0);
+                rb[i] = gload<LB, BN, BK>(Bm, ldb_c, n0, p.N, k0, kend_c, idx, bvec_c, nodrop, 0u, 0, 0);
         }
     };
     auto r2s = [&](int buf) {
@@ -452,16 +458,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         }
     };
 
-    const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    const int nk1 = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    const int nk = nk1 + (p.K2 > 0 ? (p.K2 + BK - 1) / BK : 0);
+    auto enter_seg2 = [&]() {
+        A = p.A2 + b0 * p.a2_bs0 + b1 * p.a2_bs1;
+        Bm = p.B2 + b0 * p.b2_bs0 + b1 * p.b2_bs1;
+        lda_c = p.lda2; ldb_c = p.ldb2; kend_c = p.K2; avec_c = p.a2_vec; bvec_c = p.b2_vec;
+    };
     if (nk > 0) {
-        g2r(kbeg);
+        if (nk1 == 0) { enter_seg2(); g2r(0); }
+        else g2r(kbeg);
         r2s(0);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
 #ifndef GT_ABL_NOLOAD
-        if (kt + 1 < nk) g2r(kbeg + (kt + 1) * BK);
+        if (kt + 1 < nk) {
+            if (kt + 1 == nk1) enter_seg2();
+            g2r(kt + 1 < nk1 ? kbeg + (kt + 1) * BK : (kt + 1 - nk1) * BK);
+        }
 #endif
         const float* __restrict__ cA = sA + buf * BK * BM;
         const float* __restrict__ cB = sB + buf * BK * BN;
@@ -819,7 +835,7 @@ static inline bool m4(int64_t v) { return (v & 3) == 0; }
 
 static bool has_epilogue(const gt_gemm_desc* d) {
     return d->bias || d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res ||
-           d->out_scale != 1.f || d->ep_mode != GT_EP_NORMAL;
+           d->out_scale != 1.f || d->ep_mode != GT_EP_NORMAL || d->K2 > 0;
 }
 
 static int make_plan(const gt_gemm_desc* d, Plan* pl) {
@@ -860,6 +876,7 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
                  (d->layout_a == 0 || (d->M & 3) == 0) && (d->layout_b == 0 || (d->N & 3) == 0);
     if (const char* e = getenv("GT_GEMM_STREAM")) pl->stream = pl->stream && atoi(e) != 0;
     if (d->ep_mode != GT_EP_NORMAL) { pl->stream = 0; pl->bk = 16; }
+    if (d->K2 > 0) pl->stream = 0;
     if (pl->stream) pl->bk = 32;
     pl->bm = kCfgs[c].wm * 16 * kCfgs[c].mt;
     pl->bn = kCfgs[c].wn * 16 * kCfgs[c].nt;
@@ -982,6 +999,13 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     p.a_drop = make_drop(&d->a_drop, d->a_drop_sign);
     p.a_drop_ld = d->a_drop_ld; p.a_drop_bstride = d->a_drop_bstride;
 
+    if (d->K2 > 0) {
+        if (!d->A2 || !d->B2 || d->a_drop.p > 0.f || d->a_colsum || pl.split != 1) return GT_ENOTSUP;
+        p.K2 = d->K2; p.A2 = d->A2; p.lda2 = d->lda2; p.a2_bs0 = d->a2_bs0; p.a2_bs1 = d->a2_bs1;
+        p.B2 = d->B2; p.ldb2 = d->ldb2; p.b2_bs0 = d->b2_bs0; p.b2_bs1 = d->b2_bs1;
+        p.a2_vec = al16(d->A2) && m4(d->lda2) && m4(d->a2_bs0) && m4(d->a2_bs1);
+        p.b2_vec = al16(d->B2) && m4(d->ldb2) && m4(d->b2_bs0) && m4(d->b2_bs1);
+    }
     const int64_t mn = (int64_t)d->M * d->N;
     float* dw2_partial = nullptr;
     const int dw2_slabs = pl.tiles_m * kCfgs[pl.cfg].wm;

@@ -52,6 +52,8 @@ class GtGemmDesc(C.Structure):
         ("out_scale", C.c_float),
         ("ep_mode", C.c_int32), ("n_out", C.c_int32), ("w2", C.c_void_p), ("ldw2", C.c_int64),
         ("b2", C.c_void_p), ("out2", C.c_void_p), ("g2", C.c_void_p), ("dw2", C.c_void_p),
+        ("K2", C.c_int32), ("A2", C.c_void_p), ("lda2", C.c_int64), ("a2_bs0", C.c_int64), ("a2_bs1", C.c_int64),
+        ("B2", C.c_void_p), ("ldb2", C.c_int64), ("b2_bs0", C.c_int64), ("b2_bs1", C.c_int64),
     ]
 
 
@@ -132,7 +134,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.gt_abi_version() != 3:
+        if handle.gt_abi_version() != 4:
             raise RuntimeError("libgt_hip ABI version mismatch")
         _lib = handle
     return _lib
@@ -295,7 +297,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          res: Optional[torch.Tensor] = None, ldr: int = 0, r_bs=(0, 0), out_scale: float = 1.0,
          ep_mode: int = 0, w2: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None,
          out2: Optional[torch.Tensor] = None, g2: Optional[torch.Tensor] = None,
-         dw2: Optional[torch.Tensor] = None):
+         dw2: Optional[torch.Tensor] = None,
+         K2: int = 0, A2: Optional[torch.Tensor] = None, lda2: int = 0, a2_bs=(0, 0),
+         B2: Optional[torch.Tensor] = None, ldb2: int = 0, b2_bs=(0, 0)):
     """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics)."""
     need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, a_colsum)
     L = lib()
@@ -335,6 +339,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         need_f32_cuda(w2, b2, out2, g2, dw2)
         d.ep_mode, d.n_out, d.w2, d.ldw2 = ep_mode, w2.shape[0], w2.data_ptr(), w2.stride(0)
         d.b2, d.out2, d.g2, d.dw2 = ptr(b2), ptr(out2), ptr(g2), ptr(dw2)
+    if K2:
+        need_f32_cuda(A2, B2)
+        d.K2, d.A2, d.lda2, d.a2_bs0, d.a2_bs1 = K2, A2.data_ptr(), lda2, a2_bs[0], a2_bs[1]
+        d.B2, d.ldb2, d.b2_bs0, d.b2_bs1 = B2.data_ptr(), ldb2, b2_bs[0], b2_bs[1]
     need = L.gt_gemm_ws_bytes(C.byref(d))
     wsp, wsn = None, 0
     if need > 0:
@@ -349,7 +357,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         nm = C.create_string_buffer(160)
         L.gt_gemm_kernel_name(C.byref(d), nm, 160)
         key = nm.value.decode().replace("void gt::", "").replace("(gt::GemmP)", "") + ("+splitk" if sp.value > 1 else "")
-        flops = 2.0 * M * N * K * nb
+        flops = 2.0 * M * N * (K + K2) * nb
         nbytes = 4.0 * nb * (M * K + K * N + M * N * (1 + (res is not None) + (aux is not None) +
                                                       (add is not None) + (pre is not None)))
         keep = (A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, d)

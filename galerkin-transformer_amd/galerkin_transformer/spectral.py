@@ -99,8 +99,7 @@ class SpectralConv2dFn(Function):
         xc, wl, w0c, w1c = _c(x), _c(wlin), _c(w0), _c(w1)
         T = B * n * n
         f32 = dict(dtype=torch.float32, device=dev)
-        lin = torch.empty(T, Co, **f32)
-        H.gemm(xc, wl, lin, T, Co, C, lda=C, ldb=C, ldc=Co, bias=blin)
+        wlT = wl.t().contiguous()          # [C, Co]: second-product operand of the last stage (tiny)
         X1 = torch.empty(B * n, 2 * m, C, **f32)
         H.gemm(F1, xc, X1, 2 * m, C, n, layout_a=1, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B * n, 1),
                b_bs=(n * C, 0), c_bs=(2 * m * C, 0))
@@ -116,9 +115,10 @@ class SpectralConv2dFn(Function):
                b_bs=(2 * Q * Co, 0), c_bs=(2 * n * m * Co, 0))
         out = torch.empty(B, n, n, Co, **f32)
         pre = torch.empty(B, n, n, Co, **f32) if act != H.ACT_NONE else None
+        # out = act( c2r-stage(Z) + x Wl^T + b ): the residual Linear is the second product of the same launch
         H.gemm(F4, Z, out, n, Co, 2 * m, layout_b=1, lda=2 * m, ldb=Co, ldc=Co, batch=(B * n, 1),
-               b_bs=(2 * m * Co, 0), c_bs=(n * Co, 0), add=lin, ldadd=Co, add_bs=(n * Co, 0), act=act,
-               pre=pre, ldpre=Co)
+               b_bs=(2 * m * Co, 0), c_bs=(n * Co, 0), bias=blin, act=act, pre=pre, ldpre=Co,
+               K2=C, A2=xc, lda2=C, a2_bs=(n * C, 0), B2=wlT, ldb2=Co)
         ctx.save_for_backward(xc, wl, w0c, w1c, X2, pre)
         ctx.cfg = (B, n, C, Co, m, act, blin is not None)
         return out
@@ -146,11 +146,11 @@ class SpectralConv2dFn(Function):
         dX1 = torch.empty(B * n, 2 * m, C, **f32)
         H.gemm(G2, dX2, dX1, 2 * n, m * C, 4 * m, layout_b=1, lda=4 * m, ldb=m * C, ldc=m * C, batch=(B, 1),
                b_bs=(2 * Q * C, 0), c_bs=(2 * n * m * C, 0))
-        dxl = torch.empty(T, C, **f32)
-        H.gemm(dpre, wl, dxl, T, C, Co, layout_b=1, lda=Co, ldb=C, ldc=C)
+        # dx = r2c-stage^T(dX1) + dpre Wl  (second product of the same launch)
         dx = torch.empty(B, n, n, C, **f32)
         H.gemm(F1, dX1, dx, n, C, 2 * m, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B * n, 1),
-               b_bs=(2 * m * C, 0), c_bs=(n * C, 0), res=dxl, ldr=C, r_bs=(n * C, 0))
+               b_bs=(2 * m * C, 0), c_bs=(n * C, 0),
+               K2=Co, A2=dpre, lda2=Co, a2_bs=(n * Co, 0), B2=wl, ldb2=C)
         dwl = torch.empty(Co, C, **f32)
         dbl = torch.empty(Co, **f32) if has_b else None
         H.gemm(dpre, xc, dwl, Co, C, T, layout_a=1, layout_b=1, lda=Co, ldb=C, ldc=C, split_k=0, a_colsum=dbl)
@@ -168,8 +168,7 @@ class SpectralConv1dFn(Function):
         xc, wl, wc = _c(x), _c(wlin), _c(w)
         T = B * n
         f32 = dict(dtype=torch.float32, device=dev)
-        lin = torch.empty(T, Co, **f32)
-        H.gemm(xc, wl, lin, T, Co, C, lda=C, ldb=C, ldc=Co, bias=blin)
+        wlT = wl.t().contiguous()
         X = torch.empty(B, 2, m, C, **f32)
         H.gemm(F1, xc, X, 2 * m, C, n, layout_a=1, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B, 1),
                b_bs=(n * C, 0), c_bs=(2 * m * C, 0), split_k=0)
@@ -178,8 +177,8 @@ class SpectralConv1dFn(Function):
         out = torch.empty(B, n, Co, **f32)
         pre = torch.empty(B, n, Co, **f32) if act != H.ACT_NONE else None
         H.gemm(F4, Y, out, n, Co, 2 * m, layout_b=1, lda=2 * m, ldb=Co, ldc=Co, batch=(B, 1),
-               b_bs=(2 * m * Co, 0), c_bs=(n * Co, 0), add=lin, ldadd=Co, add_bs=(n * Co, 0), act=act,
-               pre=pre, ldpre=Co)
+               b_bs=(2 * m * Co, 0), c_bs=(n * Co, 0), bias=blin, act=act, pre=pre, ldpre=Co,
+               K2=C, A2=xc, lda2=C, a2_bs=(n * C, 0), B2=wlT, ldb2=Co)
         ctx.save_for_backward(xc, wl, wc, X, pre)
         ctx.cfg = (B, n, C, Co, m, act, blin is not None)
         return out
@@ -200,11 +199,10 @@ class SpectralConv1dFn(Function):
         dX = torch.empty(B, 2, m, C, **f32)
         dw = torch.empty_like(wc)
         H.modemix_bwd(X, wc, dY, dX, dw, B, m, C, Co, m, 0)
-        dxl = torch.empty(T, C, **f32)
-        H.gemm(dpre, wl, dxl, T, C, Co, layout_b=1, lda=Co, ldb=C, ldc=C)
         dx = torch.empty(B, n, C, **f32)
         H.gemm(F1, dX, dx, n, C, 2 * m, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B, 1),
-               b_bs=(2 * m * C, 0), c_bs=(n * C, 0), res=dxl, ldr=C, r_bs=(n * C, 0))
+               b_bs=(2 * m * C, 0), c_bs=(n * C, 0),
+               K2=Co, A2=dpre, lda2=Co, a2_bs=(n * Co, 0), B2=wl, ldb2=C)
         dwl = torch.empty(Co, C, **f32)
         dbl = torch.empty(Co, **f32) if has_b else None
         H.gemm(dpre, xc, dwl, Co, C, T, layout_a=1, layout_b=1, lda=Co, ldb=C, ldc=C, split_k=0, a_colsum=dbl)

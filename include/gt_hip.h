@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 3
+#define GT_ABI_VERSION 4
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -133,6 +133,15 @@ typedef struct gt_gemm_desc {
     float* out2;            /* ROWDOT: [M, n_out] */
     const float* g2;        /* MLP_BWD: [M, n_out] */
     float* dw2;             /* MLP_BWD: [n_out, N] (row stride N) */
+
+    /* Optional second product accumulated into the same tile before the epilogue:
+     *     acc += sum_{k < K2} A2_z(m,k) * B2_z(k,n)          (same layout_a / layout_b as the first product)
+     * SpectralConv's  act(irfft-stage(Z) + Linear(x))  (layers.py:1172-1189, 1087-1098) becomes one launch:
+     * first product = c2r DFT stage, second = the residual Linear on the block's own input rows; likewise
+     * its backward  dx = rfft-stage^T(dX1) + dpre W.  No split-K, no A dropout, v1 kernel only. */
+    int32_t K2;
+    const float* A2; int64_t lda2, a2_bs0, a2_bs1;
+    const float* B2; int64_t ldb2, b2_bs0, b2_bs1;
 } gt_gemm_desc;
 
 #define GT_EP_NORMAL  0

@@ -506,3 +506,23 @@ def test_mlp_head_fused(H, gpu_device, T, K, N, no, act):
     assert rel_l2(out, ref) < KTOL
     for t, gref in zip(ins, grads):
         assert rel_l2(t.grad, gref) < 5e-6
+
+
+@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])
+def test_gemm_second_product(H, gpu_device, la, lb):
+    """C = act(A1 B1 + A2 B2 + bias) in one launch (K2 segment), batched, ragged K1 / K2."""
+    dev = gpu_device
+    nb, M, N, K1, K2 = 3, 141, 32, 24, 20
+    A1 = rnd(nb, *((M, K1) if la == 0 else (K1, M)), dev=dev, seed=80)
+    A2 = rnd(nb, *((M, K2) if la == 0 else (K2, M)), dev=dev, seed=81)
+    B1 = rnd(nb, *((N, K1) if lb == 0 else (K1, N)), dev=dev, seed=82)
+    B2 = rnd(*((N, K2) if lb == 0 else (K2, N)), dev=dev, seed=83)          # shared across the batch
+    bias = rnd(N, dev=dev, seed=84)
+    Cc = torch.empty(nb, M, N, device=dev)
+    H.gemm(A1, B1, Cc, M, N, K1, layout_a=la, layout_b=lb, lda=A1.shape[2], ldb=B1.shape[2], ldc=N, batch=(nb, 1),
+           a_bs=(A1.shape[1] * A1.shape[2], 0), b_bs=(B1.shape[1] * B1.shape[2], 0), c_bs=(M * N, 0), bias=bias,
+           act=H.ACT_RELU, K2=K2, A2=A2, lda2=A2.shape[2], a2_bs=(A2.shape[1] * A2.shape[2], 0), B2=B2,
+           ldb2=B2.shape[1])
+    torch.cuda.synchronize()
+    ref = torch.relu(ref_mm(A1, B1, la, lb) + ref_mm(A2, B2.expand(nb, *B2.shape), la, lb) + bias.double())
+    assert rel_l2(Cc, ref) < KTOL
