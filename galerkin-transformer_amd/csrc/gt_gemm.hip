@@ -41,6 +41,7 @@ struct GemmP {
     float* dw2_partial;      // MLP_BWD: [tiles_m * WM][n_out][N]
     int K2; const float* A2; int64_t lda2, a2_bs0, a2_bs1; const float* B2; int64_t ldb2, b2_bs0, b2_bs1;
     int a2_vec, b2_vec;
+    int light_wait;          // streamed kernel: counted vmcnt after full-tile epilogues (see kernel)
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------
@@ -630,6 +631,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : 3)) void gemm_stream_kernel(con
     };
 
     SItem cur, nxt;
+    bool light_wait = false;
     bool have = decode(jpos, cur);
     int g = 0;                                                 // running stage counter -> LDS buffer g&1
     if (have) issue(cur, cur.kbeg, 0);
@@ -649,8 +651,18 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : 3)) void gemm_stream_kernel(con
 
         for (int kt = 0; kt < cur.nk; ++kt, ++g) {
             // stage g has landed for this wave (vmcnt) and for everybody (barrier); everybody is also done
-            // reading the other buffer, which the next request overwrites
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            // reading the other buffer, which the next request overwrites.
+            // Right after the epilogue of a FULL tile this wave has issued >= 4*MT output stores AFTER the
+            // stage-g request; VMEM operations retire in order on gfx9-class counters, so "at most 4*MT
+            // outstanding" already implies the (older) stage loads have landed -- the stores may drain under
+            // the next MFMAs instead of stalling the first stage of every tile.
+            if (light_wait) {
+                if (MT == 4) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                light_wait = false;
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
 #ifndef GT_ABL_NOLOAD
             if (kt + 1 < cur.nk) issue(cur, cur.kbeg + (kt + 1) * BK, (g + 1) & 1);
             else if (have_next) issue(nxt, nxt.kbeg, (g + 1) & 1);
@@ -713,6 +725,9 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : 3)) void gemm_stream_kernel(con
         }
         gemm_epilogue<MT, NT>(p, acc, cur.m0 + wm * 16 * MT, cur.n0 + wn * 16 * NT + NT * li, cur.z, cur.b0, cur.b1,
                               cur.sidx, kq);
+        // every row and column of this wave's sub-tile was in range => exactly 4*MT (or more, with `pre`)
+        // store instructions were issued by the epilogue
+        light_wait = p.light_wait && (cur.m0 + BM <= p.M) && (cur.n0 + BN <= p.N) && cur.nk > 0;
         cur = nxt;
         have = have_next;
     }
@@ -822,10 +837,13 @@ static void launch_stream(hipStream_t st, const GemmP& p) {
     int nblk = std::min(p.n_work, num_cus() * per_cu);
     if (const char* e = getenv("GT_GEMM_BLOCKS")) nblk = std::min(p.n_work, std::max(1, atoi(e)));
     nblk = ((nblk + 7) / 8) * 8;
+    GemmP q = p;
+    q.light_wait = 1;
+    if (const char* e = getenv("GT_GEMM_LIGHTWAIT")) q.light_wait = atoi(e) != 0;
     if (getenv("GT_GEMM_DEBUG"))
         fprintf(stderr, "[gt_gemm] stream<%d,%d,%d> M=%d N=%d K=%d work=%d per_cu=%d grid=%d\n", LA, LB, MT, p.M, p.N,
                 p.K, p.n_work, per_cu, nblk);
-    hipLaunchKernelGGL((gemm_stream_kernel<LA, LB, MT>), dim3(nblk), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_stream_kernel<LA, LB, MT>), dim3(nblk), dim3(256), 0, st, q);
 }
 
 struct Plan { int cfg, bm, bn, bk, tiles_m, tiles_n, split, k_chunk, stream; };

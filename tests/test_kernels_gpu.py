@@ -526,3 +526,26 @@ def test_gemm_second_product(H, gpu_device, la, lb):
     torch.cuda.synchronize()
     ref = torch.relu(ref_mm(A1, B1, la, lb) + ref_mm(A2, B2.expand(nb, *B2.shape), la, lb) + bias.double())
     assert rel_l2(Cc, ref) < KTOL
+
+
+@pytest.mark.parametrize("la,lb,M,N,K", [(0, 0, 4096 + 40, 256, 256), (0, 1, 8192, 128, 384), (1, 1, 384, 128, 40000)])
+def test_gemm_stream_many_tiles_per_block(H, gpu_device, la, lb, M, N, K, monkeypatch):
+    """Streamed kernel with a tiny persistent grid, so that every block walks many tiles back to back: exercises
+    the cross-tile prefetch and the counted s_waitcnt after full-tile epilogues (edge tiles take the full wait)."""
+    monkeypatch.setenv("GT_GEMM_BLOCKS", "16")
+    A = rnd(*((M, K) if la == 0 else (K, M)), dev=gpu_device, seed=90)
+    B = rnd(*((N, K) if lb == 0 else (K, N)), dev=gpu_device, seed=91)
+    bias, res = rnd(N, dev=gpu_device, seed=92), rnd(M, N, dev=gpu_device, seed=93)
+    ref = ref_mm(A, B, la, lb) + bias.double() + res.double()
+    for _ in range(3):                                 # repeat: a race would not reproduce identically
+        Cc = torch.empty(M, N, device=gpu_device)
+        split = 0 if la == 1 else 1
+        if split == 0:
+            H.gemm(A, B, Cc, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1], ldb=B.shape[1], ldc=N, split_k=0)
+            torch.cuda.synchronize()
+            assert rel_l2(Cc, ref_mm(A, B, la, lb)) < KTOL
+        else:
+            H.gemm(A, B, Cc, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1], ldb=B.shape[1], ldc=N, bias=bias,
+                   res=res, ldr=N)
+            torch.cuda.synchronize()
+            assert rel_l2(Cc, ref) < KTOL
