@@ -217,6 +217,8 @@ def roofline_leg(trainer):
                 includes_splitk_reduce=dom.endswith("+splitk"), launches_per_step=len(recs),
                 share_of_hip_path=round(table[dom]["ms"] / sum(v["ms"] for v in table.values()), 3),
                 avg_launch_us=round(dur_s * 1e6, 2),
+                # all launch shapes of this kernel symbol in one step (what a profiler's per-kernel average mixes)
+                symbol_avg_launch_us_all_shapes=round(table[dom]["ms"] / table[dom]["calls"] * 1e3, 2),
                 achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=tsrc,
                 algorithmic_flops_per_launch=best[1], algorithmic_bytes_per_launch=best[2])
