@@ -107,3 +107,41 @@ def test_galerkin_attention_equivariances_at_bench_batch(gpu_device):
     assert torch.isfinite(y).all()
     assert torch.equal(yb, y[bp])                      # same kernels, same per-sample arithmetic: bitwise
     assert rel_l2(yt, y[:, tp]) < TOL                  # summation order over tokens changes: fp32 noise only
+
+
+EDGE = {
+    # degenerate / ragged shapes: a single token, token counts that are not multiples of any tile, batch 1,
+    # one head, one coordinate, head size not covered by the streaming K^T V kernel (d_k = 24)
+    "one_token": dict(B=2, n=1, d=32, h=2, p=2, ff=64, kind="galerkin", layer_norm=False, attn_norm=True, eps=1e-5),
+    "ragged_7": dict(B=1, n=7, d=48, h=2, p=1, ff=40, kind="galerkin", layer_norm=True, attn_norm=False, eps=1e-5),
+    "ragged_131_fourier": dict(B=3, n=131, d=64, h=4, p=2, ff=128, kind="fourier", layer_norm=False, attn_norm=True, eps=1e-7),
+    "dk24_h3": dict(B=2, n=333, d=72, h=3, p=2, ff=100, kind="galerkin", layer_norm=False, attn_norm=True, eps=1e-7),
+    "dk8_p1": dict(B=2, n=65, d=32, h=4, p=1, ff=36, kind="galerkin", layer_norm=False, attn_norm=True, eps=1e-5),
+}
+
+
+@pytest.mark.parametrize("name", list(EDGE))
+def test_encoder_layer_edge_shapes(gpu_device, name):
+    import galerkin_transformer as gt
+    from oracle import galerkin_oracle as O
+    errs = _layer_case(gt, O, gpu_device, seed=23, **EDGE[name])
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
+def test_errors_match_reference_conventions(gpu_device):
+    """Error behaviour of the module boundary: shape asserts, masks on linear attention,
+    unsupported variants -- raised as the reference raises them, never silently computed elsewhere."""
+    import galerkin_transformer as gt
+    with pytest.raises(AssertionError):
+        gt.SimpleAttention(3, 64)                                        # d_model % n_head (layers.py:805)
+    attn = gt.SimpleAttention(2, 32, pos_dim=2, attention_type="galerkin").to(gpu_device)
+    x = torch.randn(1, 9, 32, device=gpu_device)
+    with pytest.raises(AssertionError):
+        attn(x, x, x, pos=torch.rand(1, 9, 3, device=gpu_device))       # pos.size(-1) == pos_dim (layers.py:870)
+    with pytest.raises(RuntimeError):
+        attn(x, x, x, pos=torch.rand(1, 9, 2, device=gpu_device), mask=torch.ones(1, 9, 9, device=gpu_device))
+    with pytest.raises(NotImplementedError):
+        gt.SimpleTransformerEncoderLayer(d_model=32, n_head=2, attention_type="softmax")(x)
+    with pytest.raises((RuntimeError, TypeError)):
+        attn.cpu()(x.cpu(), x.cpu(), x.cpu(), pos=torch.rand(1, 9, 2))   # no CPU fallback
