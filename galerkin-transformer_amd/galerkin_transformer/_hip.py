@@ -82,6 +82,8 @@ _PROTOS = {
     "gt_headnorm_bwd_ws_bytes": (C.c_int64, [C.c_int32] * 3),
     "gt_galerkin_ktv_slabs": (C.c_int32, [C.c_int32, C.c_int32]),
     "gt_galerkin_ktv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
+    "gt_fourier_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.POINTER(GtDropout),
+                                                                C.c_int32, C.c_void_p]),
     "gt_galerkin_finalize_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64] + [C.c_int32] * 6 +
                                  [C.c_void_p, C.POINTER(GtDropout), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
@@ -601,3 +603,24 @@ def galerkin_ktv(Kp: torch.Tensor, Vp: torch.Tensor, B: int, n: int, h: int, dk:
                  lambda: lib().gt_galerkin_ktv(Kp.data_ptr(), Vp.data_ptr(), B, n, h, dk, p, slabs.data_ptr(), ns,
                                                stream_ptr()), shape=(B, n, h, dk, p)), "gt_galerkin_ktv")
     return slabs
+
+
+FOURIER_DP = (20, 36, 52)
+
+
+def fourier_attn(F1, F2, T1, T2, B: int, n: int, h: int, DP: int, scale: float, mask, drop, owner_is_key: bool,
+                 O1=None, O2=None):
+    """One pass of gt_fourier_attn on head tiles [B*n, h, DP]; returns O1 (and O2 when F2 is given).  O1 / O2 may
+    be preallocated dense [B*n, h, DP] tensors (e.g. slices of the head-tile gradient buffer)."""
+    need_f32_cuda(F1, F2, T1, T2, mask, O1, O2)
+    if O1 is None:
+        O1 = torch.empty(B * n, h, DP, dtype=torch.float32, device=F1.device)
+    if O2 is None and F2 is not None:
+        O2 = torch.empty_like(O1)
+    dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
+    nprod = 2 if F2 is not None else 1
+    check(_timed("gt_fourier_attn", 4.0 * nprod * B * h * n * n * DP, 4.0 * (3 + nprod) * B * n * h * DP,
+                 lambda: lib().gt_fourier_attn(F1.data_ptr(), ptr(F2), T1.data_ptr(), T2.data_ptr(), O1.data_ptr(),
+                                               ptr(O2), B, n, h, DP, scale, ptr(mask), dp, int(owner_is_key),
+                                               stream_ptr()), shape=(B, n, h, DP, nprod)), "gt_fourier_attn")
+    return (O1, O2) if F2 is not None else O1

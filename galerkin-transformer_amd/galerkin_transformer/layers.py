@@ -293,8 +293,9 @@ class SimpleAttention(nn.Module):
             beta = beta.view(2, self.n_head, self.d_k)
         return wqkv, bqkv, gamma, beta, mask
 
-    def fused_forward(self, x, pos=None, residual=None, sign=1.0, p_out=0.0):
-        """res + sign*dropout(attention(x)); the encoder layer's entry point."""
+    def fused_forward(self, x, pos=None, residual=None, sign=1.0, p_out=0.0, need_weights=True):
+        """res + sign*dropout(attention(x)); the encoder layer's entry point.  ``need_weights=False`` lets the
+        Fourier type run fused (no n x n matrix in HBM; the returned weight is None)."""
         if self.attention_type not in _HIP_ATTENTION:
             raise NotImplementedError(f"attention_type={self.attention_type!r} is outside the HIP hot path "
                                       "(galerkin / fourier only)")
@@ -308,7 +309,7 @@ class SimpleAttention(nn.Module):
         kind = "galerkin" if self.attention_type == "galerkin" else "fourier"
         out, w = ops.simple_attention(x, pos, wqkv, bqkv, gamma, beta, self.fc.weight, self.fc.bias,
                                       kind=kind, n_head=self.n_head, norm_mask=mask, eps=self.eps,
-                                      res=residual, sign=sign, p_out=p_out)
+                                      res=residual, sign=sign, p_out=p_out, need_weights=need_weights)
         self.attn_weight = w
         return out, w
 

@@ -79,7 +79,8 @@ class SimpleTransformerEncoderLayer(nn.Module):
         sign = 1.0 if (self.residual_type in ['add', 'plus'] or self.residual_type is None) else -1.0
         p1 = self.dropout1.p if self.training else 0.0
         p2 = self.dropout2.p if self.training else 0.0
-        x, attn_weight = self.attn.fused_forward(x, pos, residual=x, sign=sign, p_out=p1)
+        x, attn_weight = self.attn.fused_forward(x, pos, residual=x, sign=sign, p_out=p1,
+                                                 need_weights=bool(self.attn_weight))
         if self.add_layer_norm:
             x = ops.layer_norm(x, self.layer_norm1.weight, self.layer_norm1.bias, self.norm_eps)
         x = self.ff.fused_forward(x, residual=x, p_out=p2)

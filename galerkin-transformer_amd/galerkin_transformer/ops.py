@@ -435,7 +435,7 @@ class SimpleAttentionFn(Function):
 
     @staticmethod
     def forward(ctx, x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, res, cfg, mask):
-        (kind, h, norm_mask, eps, sign, p_attn, p_out) = cfg
+        (kind, h, norm_mask, eps, sign, p_attn, p_out, need_w) = cfg
         H.need_f32_cuda(x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, res, mask)
         B, n, d = x.shape
         dk = d // h
@@ -471,21 +471,27 @@ class SimpleAttentionFn(Function):
             attn_w = Mt[:, :, :Dr, :Dr]
         else:
             scale = 1.0 / math.sqrt(Dr) / n
-            S = torch.empty(B, h, n, n, dtype=torch.float32, device=dev)
-            H.gemm(Qp, Kp, S, n, n, DP, lda=hD, ldb=hD, ldc=n, batch=(B, h), a_bs=(n * hD, DP),
-                   b_bs=(n * hD, DP), c_bs=(h * n * n, n * n), alpha=scale, drop=d_attn,
-                   aux_op=H.AUX_MUL if mask is not None else H.AUX_NONE, aux=mask, ldaux=n,
-                   aux_bs=(h * n * n, n * n))
-            att = torch.empty(T, hD, dtype=torch.float32, device=dev)
-            H.gemm(S, Vp, att, n, DP, n, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
-                   a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
             wpad = torch.zeros(d, h, DP, dtype=torch.float32, device=dev)
             wpad[:, :, :Dr] = wf.reshape(d, h, Dr)
             wpad = wpad.reshape(d, hD)
+            flash = (not need_w) and DP in H.FOURIER_DP
+            if flash:
+                # fused (Q'K'^T * scale .* mask) V': the n x n matrix never reaches HBM
+                att = H.fourier_attn(Qp, None, Kp, Vp, B, n, h, DP, scale, mask, d_attn, False).reshape(T, hD)
+                S = None
+            else:
+                S = torch.empty(B, h, n, n, dtype=torch.float32, device=dev)
+                H.gemm(Qp, Kp, S, n, n, DP, lda=hD, ldb=hD, ldc=n, batch=(B, h), a_bs=(n * hD, DP),
+                       b_bs=(n * hD, DP), c_bs=(h * n * n, n * n), alpha=scale, drop=d_attn,
+                       aux_op=H.AUX_MUL if mask is not None else H.AUX_NONE, aux=mask, ldaux=n,
+                       aux_bs=(h * n * n, n * n))
+                att = torch.empty(T, hD, dtype=torch.float32, device=dev)
+                H.gemm(S, Vp, att, n, DP, n, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
+                       a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
             H.gemm(att, wpad, out, T, d, hD, lda=hD, ldb=hD, ldc=d, bias=bfc, drop=d_out, res=rc, ldr=d,
                    out_scale=sign)
             ctx.save_for_backward(xc, wq, gamma, wpad, qkv, stats, out3, S, att, mask)
-            attn_w = S
+            attn_w = S if S is not None else torch.empty(0, device=dev)
         ctx.cfg = cfg
         ctx.dims = (B, n, d, h, dk, p, Dr, DP, salt, bqkv is not None, bfc is not None, res is not None,
                     x.shape)
@@ -495,7 +501,7 @@ class SimpleAttentionFn(Function):
 
     @staticmethod
     def backward(ctx, gy, _gw):
-        (kind, h, norm_mask, eps, sign, p_attn, p_out) = ctx.cfg
+        (kind, h, norm_mask, eps, sign, p_attn, p_out, need_w) = ctx.cfg
         B, n, d, h, dk, p, Dr, DP, salt, hbq, hbf, has_res, xshape = ctx.dims
         T, hD = B * n, h * DP
         dev = gy.device
@@ -543,18 +549,24 @@ class SimpleAttentionFn(Function):
             datt = torch.empty(T, hD, dtype=torch.float32, device=dev)
             H.gemm(g, wpad, datt, T, hD, d, layout_b=1, lda=d, ldb=hD, ldc=hD, a_drop=d_out,
                    a_drop_sign=sign, a_drop_ld=d, alpha=asc)
-            dS = torch.empty(B, h, n, n, dtype=torch.float32, device=dev)
-            H.gemm(datt, Vp, dS, n, n, DP, lda=hD, ldb=hD, ldc=n, batch=(B, h), a_bs=(n * hD, DP),
-                   b_bs=(n * hD, DP), c_bs=(h * n * n, n * n), alpha=scale, drop=d_attn,
-                   aux_op=H.AUX_MUL if mask is not None else H.AUX_NONE, aux=mask, ldaux=n,
-                   aux_bs=(h * n * n, n * n))
-            # dV' = S^T datt ; dQ' = dS K' ; dK' = dS^T Q'
-            H.gemm(S, datt, dO3[2], n, DP, n, layout_a=1, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
-                   a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
-            H.gemm(dS, Kp, dO3[0], n, DP, n, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
-                   a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
-            H.gemm(dS, Qp, dO3[1], n, DP, n, layout_a=1, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
-                   a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
+            if S is None:
+                # fused passes: dQ' = (dO V'^T .* m) K' ;  dV' = (S .* m)^T dO, dK' = (dO V'^T .* m)^T Q'
+                datt3 = datt.reshape(T, h, DP)
+                H.fourier_attn(datt3, None, Vp, Kp, B, n, h, DP, scale, mask, d_attn, False, O1=dO3[0])
+                H.fourier_attn(Kp, Vp, Qp, datt3, B, n, h, DP, scale, mask, d_attn, True, O1=dO3[2], O2=dO3[1])
+            else:
+                dS = torch.empty(B, h, n, n, dtype=torch.float32, device=dev)
+                H.gemm(datt, Vp, dS, n, n, DP, lda=hD, ldb=hD, ldc=n, batch=(B, h), a_bs=(n * hD, DP),
+                       b_bs=(n * hD, DP), c_bs=(h * n * n, n * n), alpha=scale, drop=d_attn,
+                       aux_op=H.AUX_MUL if mask is not None else H.AUX_NONE, aux=mask, ldaux=n,
+                       aux_bs=(h * n * n, n * n))
+                # dV' = S^T datt ; dQ' = dS K' ; dK' = dS^T Q'
+                H.gemm(S, datt, dO3[2], n, DP, n, layout_a=1, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
+                       a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
+                H.gemm(dS, Kp, dO3[0], n, DP, n, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
+                       a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
+                H.gemm(dS, Qp, dO3[1], n, DP, n, layout_a=1, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
+                       a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
         dqkv, dgamma, dbeta = H.headnorm_bwd(dO3, qkv, gamma, stats, T, h, dk, p, norm_mask)
         dwqkv = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
         dbqkv = torch.empty(3 * d, dtype=torch.float32, device=dev) if hbq else None
@@ -570,8 +582,10 @@ class SimpleAttentionFn(Function):
 
 
 def simple_attention(x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, *, kind: str, n_head: int, norm_mask: int,
-                     eps: float, res=None, sign: float = 1.0, p_out: float = 0.0):
-    """Self-attention block; ``res`` must be ``x`` (or None).  Returns (out, attn_weight)."""
+                     eps: float, res=None, sign: float = 1.0, p_out: float = 0.0, need_weights: bool = True):
+    """Self-attention block; ``res`` must be ``x`` (or None).  Returns (out, attn_weight).  For the Fourier
+    type ``need_weights=False`` selects the fused kernel that never materialises the n x n matrix
+    (attn_weight is then None); the Galerkin matrix is small and always returned."""
     mode = _attn_mode
     mask, p_attn = None, 0.0
     if mode == "reference":
@@ -587,5 +601,7 @@ def simple_attention(x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, *, kind: str, n_
             mask[..., :Dr, :Dr] = m
         else:
             mask = _c(m)
-    cfg = (kind, int(n_head), int(norm_mask), float(eps), float(sign), float(p_attn), float(p_out))
-    return SimpleAttentionFn.apply(x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, res, cfg, mask)
+    cfg = (kind, int(n_head), int(norm_mask), float(eps), float(sign), float(p_attn), float(p_out),
+           bool(need_weights))
+    out, w = SimpleAttentionFn.apply(x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, res, cfg, mask)
+    return out, (w if w.numel() else None)

@@ -215,6 +215,20 @@ int gt_galerkin_finalize_bwd(const float* dPt, const float* Mt, const float* mas
                              float* dM, float* dWfc_slabs, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused Fourier-type attention (layers.py:672-705):  out = ((Q' K'^T) * scale .* mask) V'  on the head-tile
+ * layout [B*n][h][DP], without writing the n x n score matrix: score tiles are scaled, masked (stateless
+ * dropout with mask index ((b*h+head)*n + query)*n + key -- the index the materialising gt_gemm path uses --
+ * or an explicit [B,h,n,n] mask) and consumed in registers.  One entry point, three uses:
+ *     forward        F1 = Q',  F2 = NULL, T1 = K', T2 = V',  owner_is_key = 0  ->  O1 = out
+ *     d/dQ'          F1 = dO,  F2 = NULL, T1 = V', T2 = K',  owner_is_key = 0  ->  O1 = dQ'
+ *     d/dV', d/dK'   F1 = K',  F2 = V',   T1 = Q', T2 = dO,  owner_is_key = 1  ->  O1 = dV', O2 = dK'
+ * DP in {20, 36, 52} (else GT_ENOTSUP: materialise through gt_gemm).
+ * ------------------------------------------------------------------------------------------- */
+int gt_fourier_attn(const float* F1, const float* F2, const float* T1, const float* T2, float* O1, float* O2,
+                    int32_t B, int32_t n, int32_t h, int32_t DP, float scale, const float* mask,
+                    const gt_dropout* drop, int32_t owner_is_key, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Row LayerNorm over the feature axis (model.py:128-129,134-135 when layer_norm=True).
  * ------------------------------------------------------------------------------------------- */
 int gt_layernorm_fwd(const float* x, const float* gamma, const float* beta, int32_t T, int32_t d,

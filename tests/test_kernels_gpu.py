@@ -549,3 +549,39 @@ def test_gemm_stream_many_tiles_per_block(H, gpu_device, la, lb, M, N, K, monkey
                    res=res, ldr=N)
             torch.cuda.synchronize()
             assert rel_l2(Cc, ref) < KTOL
+
+
+@pytest.mark.parametrize("B,n,d,h,p", [(2, 200, 128, 4, 2), (1, 77, 64, 4, 2), (2, 131, 96, 2, 2)])
+@pytest.mark.parametrize("mode", ["off", "reference"])
+def test_fourier_fused_equals_materialised(H, gpu_device, B, n, d, h, p, mode):
+    """gt_fourier_attn (no n x n matrix in HBM) == the materialising GEMM path of the same operator: outputs and
+    every gradient, with the attention dropout off and with the reference's p = 0.5 mask (same seed and salt =>
+    the fused kernel regenerates exactly the mask the GEMM epilogue draws)."""
+    from galerkin_transformer import ops
+    import galerkin_transformer as gt
+    dev = gpu_device
+    torch.manual_seed(1)
+    attn = gt.SimpleAttention(h, d, pos_dim=p, attention_type="fourier", norm=True, eps=1e-7, dropout=0.0).to(dev)
+    with torch.no_grad():
+        for prm in attn.parameters():
+            prm.add_(0.05 * torch.randn_like(prm))
+    x0 = torch.randn(B, n, d, device=dev)
+    pos = torch.rand(B, n, p, device=dev)
+    cot = torch.randn(B, n, d, device=dev)
+    res = []
+    gt.set_attention_dropout(mode)
+    try:
+        for need_w in (True, False):
+            H.set_seed(4242, dev)
+            ops._salt[0] = 3
+            for prm in attn.parameters():
+                prm.grad = None
+            x = x0.clone().requires_grad_(True)
+            y, w = attn.fused_forward(x, pos, residual=x, need_weights=need_w)
+            assert (w is None) == (not need_w)
+            y.backward(cot)
+            res.append([y.detach(), x.grad.detach()] + [prm.grad.detach().clone() for prm in attn.parameters()])
+    finally:
+        gt.set_attention_dropout("reference")
+    for a, b_ in zip(*res):
+        assert rel_l2(b_, a) < 5e-6
