@@ -57,10 +57,19 @@ __device__ inline float drop_mul(const DropDev& d, uint32_t key, uint32_t idx) {
     return (drop_hash(key, idx) >= d.thresh) ? d.scale : 0.f;
 }
 
-__device__ inline float silu_f(float x) { return x / (1.f + expf(-x)); }
+// SiLU on the hardware exp2 / rcp units (1 ulp each; 5 VALU ops instead of ~27 for expf + IEEE division).
+__device__ inline float sigmoid_f(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ inline float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ inline float dsilu_f(float x) {
-    float s = 1.f / (1.f + expf(-x));
+    const float s = sigmoid_f(x);
     return s * (1.f + x * (1.f - s));
+}
+__device__ inline void silu_both(float x, float& a, float& da) {   // value and derivative from one sigmoid
+    const float s = sigmoid_f(x);
+    a = x * s;
+    da = s * (1.f + x * (1.f - s));
 }
 
 __device__ inline float wave_sum(float v) {

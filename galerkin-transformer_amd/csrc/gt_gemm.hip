@@ -350,7 +350,7 @@ __device__ __forceinline__ void head_epilogue(const GemmP& p, const f32x4 (&acc)
 #pragma unroll
                     for (int o = 0; o < NO; ++o) gw = fmaf(g[o], w2v[o][t], gw);
                     float a, da;
-                    if (p.act == GT_ACT_SILU) { a = silu_f(h); da = dsilu_f(h); }
+                    if (p.act == GT_ACT_SILU) silu_both(h, a, da);
                     else if (p.act == GT_ACT_RELU) { a = fmaxf(h, 0.f); da = h > 0.f ? 1.f : 0.f; }
                     else { a = h; da = 1.f; }
                     outv[t] = gw * da;
@@ -869,6 +869,8 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     for (int i = 0; i < kNumCfg; ++i) {
         const int bm = kCfgs[i].wm * 16 * kCfgs[i].mt, bn = kCfgs[i].wn * 16 * kCfgs[i].nt;
         if (d->ep_mode != GT_EP_NORMAL && bn < d->N) continue;      // the fused head needs whole rows per block
+        // the 128x128 head instance needs > 256 registers (one block per CU): the 64x128 one runs two
+        if (d->ep_mode != GT_EP_NORMAL && i == 0 && d->N <= 128) continue;
         const double tiles = (double)ceil_div(d->M, bm) * ceil_div(d->N, bn) * (double)batch;
         // under-filled grids: with split-K available the K-slices fill the chip (time ~ total padded work),
         // otherwise every block has a CU to itself (time ~ one tile)

@@ -84,6 +84,9 @@ _PROTOS = {
     "gt_galerkin_ktv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
     "gt_fourier_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.POINTER(GtDropout),
                                                                 C.c_int32, C.c_void_p]),
+    "gt_dft_analysis": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p]),
+    "gt_dft_synthesis": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                                     C.c_int32, C.c_void_p, C.c_void_p]),
     "gt_galerkin_finalize_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64] + [C.c_int32] * 6 +
                                  [C.c_void_p, C.POINTER(GtDropout), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
@@ -136,7 +139,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.gt_abi_version() != 4:
+        if handle.gt_abi_version() != 5:
             raise RuntimeError("libgt_hip ABI version mismatch")
         _lib = handle
     return _lib
@@ -603,6 +606,31 @@ def galerkin_ktv(Kp: torch.Tensor, Vp: torch.Tensor, B: int, n: int, h: int, dk:
                  lambda: lib().gt_galerkin_ktv(Kp.data_ptr(), Vp.data_ptr(), B, n, h, dk, p, slabs.data_ptr(), ns,
                                                stream_ptr()), shape=(B, n, h, dk, p)), "gt_galerkin_ktv")
     return slabs
+
+
+def dft_supported(n: int, P: int, C_: int, Co: int) -> bool:
+    """Shapes gt_dft_analysis / gt_dft_synthesis implement (anything else goes through gt_gemm)."""
+    return C_ == 32 and Co == 32 and P <= 32 and P % 4 == 0 and n <= 224
+
+
+def dft_analysis(F, X, Y, nb: int, n: int, P: int, C_: int):
+    """Y[b] (P x C) = F^T X[b] for nb grid lines (gt_dft_analysis)."""
+    need_f32_cuda(F, X, Y)
+    check(_timed("gt_dft_analysis", 2.0 * nb * n * P * C_, 4.0 * nb * (n + P) * C_,
+                 lambda: lib().gt_dft_analysis(F.data_ptr(), X.data_ptr(), Y.data_ptr(), nb, n, P, C_, stream_ptr()),
+                 shape=(nb, n, P, C_)), "gt_dft_analysis")
+    return Y
+
+
+def dft_synthesis(F, Z, Y, nb: int, n: int, P: int, Co: int, X2, W2, C2: int, bias=None, act: int = 0, pre=None):
+    """Y[b] (n x Co) = act(F Z[b] + X2[b] W2 + bias) for nb grid lines (gt_dft_synthesis)."""
+    need_f32_cuda(F, Z, Y, X2, W2, bias, pre)
+    check(_timed("gt_dft_synthesis", 2.0 * nb * n * (P + C2) * Co,
+                 4.0 * nb * (n * (C2 + Co * (2 if pre is not None else 1)) + P * Co),
+                 lambda: lib().gt_dft_synthesis(F.data_ptr(), Z.data_ptr(), Y.data_ptr(), nb, n, P, Co, X2.data_ptr(),
+                                                W2.data_ptr(), C2, ptr(bias), act, ptr(pre), stream_ptr()),
+                 shape=(nb, n, P, Co, C2)), "gt_dft_synthesis")
+    return Y
 
 
 FOURIER_DP = (20, 36, 52)

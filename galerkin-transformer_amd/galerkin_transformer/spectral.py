@@ -101,8 +101,12 @@ class SpectralConv2dFn(Function):
         f32 = dict(dtype=torch.float32, device=dev)
         wlT = wl.t().contiguous()          # [C, Co]: second-product operand of the last stage (tiny)
         X1 = torch.empty(B * n, 2 * m, C, **f32)
-        H.gemm(F1, xc, X1, 2 * m, C, n, layout_a=1, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B * n, 1),
-               b_bs=(n * C, 0), c_bs=(2 * m * C, 0))
+        line = H.dft_supported(n, 2 * m, C, Co)      # per-grid-line stages on the dedicated streaming kernels
+        if line:
+            H.dft_analysis(F1, xc, X1, B * n, n, 2 * m, C)
+        else:
+            H.gemm(F1, xc, X1, 2 * m, C, n, layout_a=1, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B * n, 1),
+                   b_bs=(n * C, 0), c_bs=(2 * m * C, 0))
         Q = 2 * m * m
         X2 = torch.empty(B, 2, Q, C, **f32)
         H.gemm(G2, X1, X2, 4 * m, m * C, 2 * n, layout_a=1, layout_b=1, lda=4 * m, ldb=m * C, ldc=m * C,
@@ -116,9 +120,12 @@ class SpectralConv2dFn(Function):
         out = torch.empty(B, n, n, Co, **f32)
         pre = torch.empty(B, n, n, Co, **f32) if act != H.ACT_NONE else None
         # out = act( c2r-stage(Z) + x Wl^T + b ): the residual Linear is the second product of the same launch
-        H.gemm(F4, Z, out, n, Co, 2 * m, layout_b=1, lda=2 * m, ldb=Co, ldc=Co, batch=(B * n, 1),
-               b_bs=(2 * m * Co, 0), c_bs=(n * Co, 0), bias=blin, act=act, pre=pre, ldpre=Co,
-               K2=C, A2=xc, lda2=C, a2_bs=(n * C, 0), B2=wlT, ldb2=Co)
+        if line:
+            H.dft_synthesis(F4, Z, out, B * n, n, 2 * m, Co, xc, wlT, C, bias=blin, act=act, pre=pre)
+        else:
+            H.gemm(F4, Z, out, n, Co, 2 * m, layout_b=1, lda=2 * m, ldb=Co, ldc=Co, batch=(B * n, 1),
+                   b_bs=(2 * m * Co, 0), c_bs=(n * Co, 0), bias=blin, act=act, pre=pre, ldpre=Co,
+                   K2=C, A2=xc, lda2=C, a2_bs=(n * C, 0), B2=wlT, ldb2=Co)
         ctx.save_for_backward(xc, wl, w0c, w1c, X2, pre)
         ctx.cfg = (B, n, C, Co, m, act, blin is not None)
         return out
@@ -134,8 +141,12 @@ class SpectralConv2dFn(Function):
         g = _c(gy)
         dpre = H.act_bwd(g, pre, act) if act != H.ACT_NONE else g
         dZ = torch.empty(B * n, 2 * m, Co, **f32)
-        H.gemm(F4, dpre, dZ, 2 * m, Co, n, layout_a=1, layout_b=1, lda=2 * m, ldb=Co, ldc=Co,
-               batch=(B * n, 1), b_bs=(n * Co, 0), c_bs=(2 * m * Co, 0))
+        line = H.dft_supported(n, 2 * m, C, Co)
+        if line:
+            H.dft_analysis(F4, dpre, dZ, B * n, n, 2 * m, Co)
+        else:
+            H.gemm(F4, dpre, dZ, 2 * m, Co, n, layout_a=1, layout_b=1, lda=2 * m, ldb=Co, ldc=Co,
+                   batch=(B * n, 1), b_bs=(n * Co, 0), c_bs=(2 * m * Co, 0))
         dY = torch.empty(B, 2, Q, Co, **f32)
         H.gemm(G3, dZ, dY, 4 * m, m * Co, 2 * n, layout_a=1, layout_b=1, lda=4 * m, ldb=m * Co, ldc=m * Co,
                batch=(B, 1), b_bs=(2 * n * m * Co, 0), c_bs=(2 * Q * Co, 0))
@@ -148,9 +159,12 @@ class SpectralConv2dFn(Function):
                b_bs=(2 * Q * C, 0), c_bs=(2 * n * m * C, 0))
         # dx = r2c-stage^T(dX1) + dpre Wl  (second product of the same launch)
         dx = torch.empty(B, n, n, C, **f32)
-        H.gemm(F1, dX1, dx, n, C, 2 * m, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B * n, 1),
-               b_bs=(2 * m * C, 0), c_bs=(n * C, 0),
-               K2=Co, A2=dpre, lda2=Co, a2_bs=(n * Co, 0), B2=wl, ldb2=C)
+        if line:
+            H.dft_synthesis(F1, dX1, dx, B * n, n, 2 * m, C, dpre, wl, Co)
+        else:
+            H.gemm(F1, dX1, dx, n, C, 2 * m, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B * n, 1),
+                   b_bs=(2 * m * C, 0), c_bs=(n * C, 0),
+                   K2=Co, A2=dpre, lda2=Co, a2_bs=(n * Co, 0), B2=wl, ldb2=C)
         dwl = torch.empty(Co, C, **f32)
         dbl = torch.empty(Co, **f32) if has_b else None
         H.gemm(dpre, xc, dwl, Co, C, T, layout_a=1, layout_b=1, lda=Co, ldb=C, ldc=C, split_k=0, a_colsum=dbl)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 4
+#define GT_ABI_VERSION 5
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -227,6 +227,23 @@ int gt_galerkin_finalize_bwd(const float* dPt, const float* Mt, const float* mas
 int gt_fourier_attn(const float* F1, const float* F2, const float* T1, const float* T2, float* O1, float* O2,
                     int32_t B, int32_t n, int32_t h, int32_t DP, float scale, const float* mask,
                     const gt_dropout* drop, int32_t owner_is_key, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Truncated-DFT stages along the contiguous grid axis of SpectralConv2d (layers.py:1176 rfft2 and :1187
+ * irfft2 restricted to the kept modes; the residual nn.Linear of :1128 / :1196 rides on the synthesis).
+ * One batch item = one grid line; all tensors dense fp32:
+ *     analysis    Y[b] (P x C)  = F^T X[b]                 F [n, P],  X [nb, n, C],  Y [nb, P, C]
+ *     synthesis   Y[b] (n x Co) = act( F Z[b] + X2[b] W2 + bias ),   pre (optional) = the argument of act
+ *                 F [n, P], Z [nb, P, Co], X2 [nb, n, C2], W2 [C2, Co], bias [Co] or NULL, Y / pre [nb, n, Co]
+ * The backward of one is the other with the transposed basis (spectral.py).  Implemented for C = Co = C2 =
+ * 32 channels, P = 2*modes <= 32 (synthesis: P % 4 == 0), n <= 224; anything else returns GT_ENOTSUP and the
+ * caller runs the same product through gt_gemm.
+ * ------------------------------------------------------------------------------------------- */
+int gt_dft_analysis(const float* F, const float* X, float* Y, int32_t nb, int32_t n, int32_t P, int32_t C,
+                    void* stream);
+int gt_dft_synthesis(const float* F, const float* Z, float* Y, int32_t nb, int32_t n, int32_t P, int32_t Co,
+                     const float* X2, const float* W2, int32_t C2, const float* bias, int32_t act, float* pre,
+                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row LayerNorm over the feature axis (model.py:128-129,134-135 when layer_norm=True).

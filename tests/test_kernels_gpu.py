@@ -585,3 +585,45 @@ def test_fourier_fused_equals_materialised(H, gpu_device, B, n, d, h, p, mode):
         gt.set_attention_dropout("reference")
     for a, b_ in zip(*res):
         assert rel_l2(b_, a) < 5e-6
+
+
+@pytest.mark.parametrize("nb,n,P", [(37, 141, 24), (1500, 141, 24), (700, 211, 24), (9, 64, 32), (1, 30, 8), (523, 99, 20)])
+def test_dft_line_stages(H, gpu_device, nb, n, P):
+    """gt_dft_analysis / gt_dft_synthesis (persistent per-grid-line kernels, direct-to-LDS prefetch, clamped
+    edges) against fp64 einsums; more lines than resident blocks so every block walks several lines."""
+    dev = gpu_device
+    C = 32
+    assert H.dft_supported(n, P, C, C)
+    g = torch.Generator().manual_seed(nb * 1000 + n)
+    F = torch.randn(n, P, generator=g).to(dev)
+    X = torch.randn(nb, n, C, generator=g).to(dev)
+    Y = torch.full((nb, P, C), float("nan"), device=dev)
+    H.dft_analysis(F, X, Y, nb, n, P, C)
+    ref = torch.einsum("rp,brc->bpc", F.double(), X.double())
+    assert rel_l2(Y, ref) < 2e-6
+    Z = torch.randn(nb, P, C, generator=g).to(dev)
+    W2 = (torch.randn(C, C, generator=g) / 6).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    lin = torch.einsum("rp,bpc->brc", F.double(), Z.double()) + X.double() @ W2.double()
+    for act, b_, want_pre in ((H.ACT_NONE, None, False), (H.ACT_CODE["silu"], bias, True), (H.ACT_CODE["relu"], bias, False)):
+        out = torch.full((nb, n, C), float("nan"), device=dev)
+        pre = torch.full((nb, n, C), float("nan"), device=dev) if want_pre else None
+        H.dft_synthesis(F, Z, out, nb, n, P, C, X, W2, C, bias=b_, act=act, pre=pre)
+        r = lin + (b_.double() if b_ is not None else 0.0)
+        if want_pre:
+            assert rel_l2(pre, r) < 2e-6
+        if act == H.ACT_CODE["silu"]:
+            r = torch.nn.functional.silu(r)
+        elif act == H.ACT_CODE["relu"]:
+            r = torch.relu(r)
+        assert rel_l2(out, r) < 2e-6
+
+
+def test_dft_line_stages_unsupported_shapes_fall_back(H, gpu_device):
+    """Channel counts other than 32 are GT_ENOTSUP at the C ABI; SpectralConv2d routes them through gt_gemm."""
+    dev = gpu_device
+    assert not H.dft_supported(64, 24, 20, 20)
+    F = torch.randn(64, 24, device=dev)
+    X = torch.randn(4, 64, 20, device=dev)
+    with pytest.raises(H.GtNotSupported):
+        H.dft_analysis(F, X, torch.empty(4, 24, 20, device=dev), 4, 64, 24, 20)
