@@ -80,6 +80,12 @@ __device__ inline float wave_sum(float v) {
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// tall-skinny weight-gradient path of gt_gemm (gt_tsmm.hip)
+bool tsmm_eligible(const gt_gemm_desc* d);
+int64_t tsmm_ws_bytes(const gt_gemm_desc* d);
+const char* tsmm_kernel_name(const gt_gemm_desc* d);
+int tsmm_run(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream);
+
 #define GT_LAUNCH_CHECK()                         \
     do {                                          \
         hipError_t e__ = hipGetLastError();       \

@@ -962,6 +962,10 @@ static int64_t acs_parts(const gt_gemm_desc* d, const Plan& pl) {
 extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) {
     Plan pl;
     if (!d || !buf || n <= 0) return GT_EINVAL;
+    if (!getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) {
+        snprintf(buf, n, "%s", tsmm_kernel_name(d));
+        return 0;
+    }
     int rc = make_plan(d, &pl);
     if (rc) return rc;
     const Cfg& c = kCfgs[pl.cfg];
@@ -975,6 +979,7 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
 
 extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
     Plan pl;
+    if (d && !getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return tsmm_ws_bytes(d);
     if (make_plan(d, &pl)) return 0;
     const int64_t parts = acs_parts(d, pl);
     if (d->ep_mode == GT_EP_MLP_BWD)
@@ -995,6 +1000,7 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
         if (d->a_colsum || d->a_drop.p > 0.f) return GT_ENOTSUP;
     }
     if ((d->layout_a | d->layout_b) & ~1) return GT_EINVAL;
+    if (d->C && !getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return tsmm_run(d, ws, ws_bytes, stream);
     if (d->rp < 0 || d->rp > 8) return GT_EINVAL;
     if ((d->a_drop.p > 0.f && !d->a_drop.seed) || (d->drop.p > 0.f && !d->drop.seed)) return GT_EINVAL;
     if (d->a_drop.p >= 1.f || d->drop.p >= 1.f || d->a_drop.p < 0.f || d->drop.p < 0.f) return GT_EINVAL;

@@ -361,7 +361,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         L.gt_gemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(sp))
         nm = C.create_string_buffer(160)
         L.gt_gemm_kernel_name(C.byref(d), nm, 160)
-        key = nm.value.decode().replace("void gt::", "").replace("(gt::GemmP)", "") + ("+splitk" if sp.value > 1 else "")
+        key = nm.value.decode().replace("void gt::", "").replace("(gt::GemmP)", "").replace("(gt::TsmmP)", "")
+        key += "+splitk" if (sp.value > 1 and "tsmm" not in key) else ""
         flops = 2.0 * M * N * (K + K2) * nb
         nbytes = 4.0 * nb * (M * K + K * N + M * N * (1 + (res is not None) + (aux is not None) +
                                                       (add is not None) + (pre is not None)))
@@ -370,6 +371,17 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         call = lambda: L.gt_gemm(C.byref(d), wsp, wsn, st)
         check(_timed(key, flops, nbytes, call, replay=(call, keep), shape=(M, N, K, nb)), "gt_gemm")
     return Cout
+
+
+def gemm_kernel_name(A, B, M, N, K, *, layout_a=0, layout_b=0, lda, ldb, ldc, split_k=1) -> str:
+    """Symbol of the kernel gt_gemm launches for a plain (epilogue-free, unbatched) product."""
+    d = GtGemmDesc()
+    lib().gt_gemm_desc_init(C.byref(d))
+    d.M, d.N, d.K, d.layout_a, d.layout_b, d.split_k = M, N, K, layout_a, layout_b, split_k
+    d.A, d.lda, d.B, d.ldb, d.ldc = A.data_ptr(), lda, B.data_ptr(), ldb, ldc
+    nm = C.create_string_buffer(160)
+    check(lib().gt_gemm_kernel_name(C.byref(d), nm, 160), "gt_gemm_kernel_name")
+    return nm.value.decode()
 
 
 def gemm_plan(M, N, K, batch=(1, 1), split_k=1):

@@ -627,3 +627,26 @@ def test_dft_line_stages_unsupported_shapes_fall_back(H, gpu_device):
     X = torch.randn(4, 64, 20, device=dev)
     with pytest.raises(H.GtNotSupported):
         H.dft_analysis(F, X, torch.empty(4, 24, 20, device=dev), 4, 64, 24, 20)
+
+
+@pytest.mark.parametrize("M,N,K,sign,colsum", [(32, 2, 100003, 1.0, False), (32, 32, 131077, -1.0, True),
+                                               (128, 32, 70000, 1.0, True), (64, 16, 65536, 1.0, True),
+                                               (96, 32, 65540, -1.0, False)])
+def test_gemm_tall_skinny_wgrad(H, gpu_device, M, N, K, sign, colsum):
+    """gt_gemm routes C = A^T B with K in the 1e5+ range and M <= 128, N <= 32 (the decoder's pointwise-layer
+    weight gradients) to the streaming tsmm kernel: same results as the tiled split-K path and as fp64, with
+    the bias-gradient by-product, ragged K tails and the sign convention of a_colsum."""
+    dev = gpu_device
+    A = rnd(K, M, dev=dev, seed=50)
+    Bm = rnd(K, N, dev=dev, seed=51)
+    name = H.gemm_kernel_name(A, Bm, M, N, K, layout_a=1, layout_b=1, lda=M, ldb=N, ldc=N, split_k=0)
+    assert "tsmm_kernel" in name
+    Cc = torch.full((M, N), float("nan"), device=dev)
+    cs = torch.full((M,), float("nan"), device=dev) if colsum else None
+    H.gemm(A, Bm, Cc, M, N, K, layout_a=1, layout_b=1, lda=M, ldb=N, ldc=N, split_k=0, alpha=sign,
+           a_drop_sign=sign, a_colsum=cs)
+    torch.cuda.synchronize()
+    ref = sign * (A.double().t() @ Bm.double())
+    assert rel_l2(Cc, ref) < KTOL
+    if colsum:
+        assert rel_l2(cs, sign * A.double().sum(0)) < KTOL
