@@ -84,6 +84,11 @@ _PROTOS = {
     "gt_galerkin_ktv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
     "gt_fourier_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.POINTER(GtDropout),
                                                                 C.c_int32, C.c_void_p]),
+    "gt_mlp_head_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 4 +
+                        [C.c_int32, C.c_void_p, C.c_void_p]),
+    "gt_mlp_head_bwd_ws_bytes": (C.c_int64, [C.c_int64]),
+    "gt_mlp_head_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 3 +
+                        [C.c_int32] + [C.c_void_p] * 7 + [C.c_int64, C.c_void_p]),
     "gt_dft_analysis": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p]),
     "gt_dft_synthesis": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                                                      C.c_int32, C.c_void_p, C.c_void_p]),
@@ -618,6 +623,35 @@ def galerkin_ktv(Kp: torch.Tensor, Vp: torch.Tensor, B: int, n: int, h: int, dk:
                  lambda: lib().gt_galerkin_ktv(Kp.data_ptr(), Vp.data_ptr(), B, n, h, dk, p, slabs.data_ptr(), ns,
                                                stream_ptr()), shape=(B, n, h, dk, p)), "gt_galerkin_ktv")
     return slabs
+
+
+def mlp_head_supported(K: int, N: int, n_out: int) -> bool:
+    """Shapes of the dedicated gt_mlp_head_* kernels (others: gt_gemm's fused-head epilogues)."""
+    return K == 32 and N == 128 and n_out == 1
+
+
+def mlp_head_fwd(x2, w1, b1, w2, b2, act: int, out):
+    need_f32_cuda(x2, w1, b1, w2, b2, out)
+    T, K = x2.shape
+    N, no = w1.shape[0], w2.shape[0]
+    check(_timed("gt_mlp_head_fwd", 2.0 * T * N * (K + no), 4.0 * T * (K + no),
+                 lambda: lib().gt_mlp_head_fwd(x2.data_ptr(), T, K, N, no, w1.data_ptr(), ptr(b1), w2.data_ptr(), ptr(b2),
+                                               act, out.data_ptr(), stream_ptr()), shape=(T, K, N, no)),
+          "gt_mlp_head_fwd")
+    return out
+
+
+def mlp_head_bwd(x2, w1, b1, w2, act: int, g, dx, dw1, db1, dw2, db2):
+    need_f32_cuda(x2, w1, b1, w2, g, dx, dw1, db1, dw2, db2)
+    T, K = x2.shape
+    N, no = w1.shape[0], w2.shape[0]
+    need = lib().gt_mlp_head_bwd_ws_bytes(T)
+    ws = workspace(x2.device, need)
+    check(_timed("gt_mlp_head_bwd", 2.0 * T * N * (3 * K + 2 * no), 4.0 * T * (2 * K + no),
+                 lambda: lib().gt_mlp_head_bwd(x2.data_ptr(), T, K, N, no, w1.data_ptr(), ptr(b1), w2.data_ptr(), act,
+                                               g.data_ptr(), ptr(dx), dw1.data_ptr(), ptr(db1), ptr(dw2), ptr(db2),
+                                               ws.data_ptr(), ws.numel(), stream_ptr()), shape=(T, K, N, no)),
+          "gt_mlp_head_bwd")
 
 
 def dft_supported(n: int, P: int, C_: int, Co: int) -> bool:

@@ -295,8 +295,11 @@ class MlpHeadFn(Function):
         T = x2.shape[0]
         w1c, w2c = _c(w1), _c(w2)
         out = torch.empty(T, no, dtype=torch.float32, device=x.device)
-        H.gemm(x2, w1c, None, T, N, K, lda=K, ldb=K, ldc=N, bias=b1, act=act, ep_mode=H.EP_ROWDOT, w2=w2c, b2=b2,
-               out2=out)
+        if H.mlp_head_supported(K, N, no):       # dedicated one-pass kernel (gt_mlp_head_fwd)
+            H.mlp_head_fwd(x2, w1c, b1, w2c, b2, act, out)
+        else:
+            H.gemm(x2, w1c, None, T, N, K, lda=K, ldb=K, ldc=N, bias=b1, act=act, ep_mode=H.EP_ROWDOT, w2=w2c,
+                   b2=b2, out2=out)
         ctx.save_for_backward(x2, w1c, b1, w2c)
         ctx.cfg = (act, K, N, no, b1 is not None, b2 is not None, x.shape)
         return out.reshape(*x.shape[:-1], no)
@@ -308,6 +311,13 @@ class MlpHeadFn(Function):
         dev, T = gy.device, x2.shape[0]
         g = _c(gy).reshape(T, no)
         f32 = dict(dtype=torch.float32, device=dev)
+        if H.mlp_head_supported(K, N, no):       # everything in one pass over x (gt_mlp_head_bwd)
+            dx = torch.empty(T, K, **f32) if ctx.needs_input_grad[0] else None
+            dw1, dw2 = torch.empty(N, K, **f32), torch.empty(no, N, **f32)
+            db1 = torch.empty(N, **f32) if hb1 else None
+            db2 = torch.empty(no, **f32) if hb2 else None
+            H.mlp_head_bwd(x2, w1c, b1, w2c, act, g, dx, dw1, db1, dw2, db2)
+            return (dx.reshape(xshape) if dx is not None else None), dw1, db1, dw2, db2, None
         dh, dw2 = torch.empty(T, N, **f32), torch.empty(no, N, **f32)
         H.gemm(x2, w1c, dh, T, N, K, lda=K, ldb=K, ldc=N, bias=b1, act=act, ep_mode=H.EP_MLP_BWD, w2=w2c, g2=g,
                dw2=dw2)

@@ -246,6 +246,23 @@ int gt_dft_synthesis(const float* F, const float* Z, float* Y, int32_t nb, int32
                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused pointwise regression head  out[t] = w2 . act(W1 x[t] + b1) + b2  (model.py:575-580, 625-629: the
+ * Linear(K -> N), activation, Linear(N -> n_out) tail of SpectralRegressor at every fine-grid point) and its
+ * complete backward in one pass over x: the [T, N] hidden activation and dL/dh never reach HBM.
+ *     X [T, K] dense, W1 [N, K], b1 [N] or NULL, w2 [n_out, N], b2 [n_out] or NULL, out [T, n_out]
+ *     backward: g [T, n_out] = dL/dout  ->  dX [T, K] (or NULL), dW1 [N, K], db1 [N] / dw2 [n_out, N] /
+ *     db2 [n_out] (each may be NULL); ws >= gt_mlp_head_bwd_ws_bytes(T) bytes of scratch (deterministic
+ *     fixed-order reduction).  Implemented for K = 32, N = 128, n_out = 1 (else GT_ENOTSUP: use gt_gemm's
+ *     ep_mode GT_EP_ROWDOT / GT_EP_MLP_BWD path, which covers N <= 128, n_out <= 4).
+ * ------------------------------------------------------------------------------------------- */
+int gt_mlp_head_fwd(const float* X, int64_t T, int32_t K, int32_t N, int32_t n_out, const float* W1,
+                    const float* b1, const float* w2, const float* b2, int32_t act, float* out, void* stream);
+int64_t gt_mlp_head_bwd_ws_bytes(int64_t T);
+int gt_mlp_head_bwd(const float* X, int64_t T, int32_t K, int32_t N, int32_t n_out, const float* W1,
+                    const float* b1, const float* w2, int32_t act, const float* g, float* dX, float* dW1,
+                    float* db1, float* dw2, float* db2, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Row LayerNorm over the feature axis (model.py:128-129,134-135 when layer_norm=True).
  * ------------------------------------------------------------------------------------------- */
 int gt_layernorm_fwd(const float* x, const float* gamma, const float* beta, int32_t T, int32_t d,

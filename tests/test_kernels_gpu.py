@@ -485,7 +485,9 @@ def test_conv3x3_resize_fused_equals_unfused(H, gpu_device, B, Cin, Cout, n, siz
         assert rel_l2(outs[0][0], ref) < 1e-5 and rel_l2(outs[0][1], gw) < 1e-5
 
 
-@pytest.mark.parametrize("T,K,N,no,act", [(1000, 32, 128, 1, "silu"), (777, 20, 96, 3, "relu"), (130, 48, 48, 1, "silu")])
+@pytest.mark.parametrize("T,K,N,no,act", [(1000, 32, 128, 1, "silu"), (777, 20, 96, 3, "relu"), (130, 48, 48, 1, "silu"),
+                                          (70003, 32, 128, 1, "silu"), (33, 32, 128, 1, "relu"), (5, 32, 128, 1, "silu"),
+                                          (20000, 32, 128, 1, "none")])
 def test_mlp_head_fused(H, gpu_device, T, K, N, no, act):
     """ops.mlp_head (row-dot epilogue forward, recompute + by-product backward) against fp64 torch."""
     import torch.nn.functional as F
@@ -495,7 +497,7 @@ def test_mlp_head_fused(H, gpu_device, T, K, N, no, act):
     b1 = rnd(N, dev="cpu", seed=72).double().requires_grad_(True)
     w2 = rnd(no, N, dev="cpu", seed=73, scale=0.3).double().requires_grad_(True)
     b2 = rnd(no, dev="cpu", seed=74).double().requires_grad_(True)
-    fn = F.silu if act == "silu" else torch.relu
+    fn = F.silu if act == "silu" else (torch.relu if act == "relu" else (lambda v: v))
     ref = F.linear(fn(F.linear(x, w1, b1)), w2, b2)
     cot = rnd(T, no, dev="cpu", seed=75).double()
     grads = torch.autograd.grad(ref, (x, w1, b1, w2, b2), cot)
@@ -650,3 +652,28 @@ def test_gemm_tall_skinny_wgrad(H, gpu_device, M, N, K, sign, colsum):
     assert rel_l2(Cc, ref) < KTOL
     if colsum:
         assert rel_l2(cs, sign * A.double().sum(0)) < KTOL
+
+
+def test_mlp_head_dedicated_kernels_without_optional_outputs(H, gpu_device):
+    """gt_mlp_head_fwd / gt_mlp_head_bwd with no biases and no input gradient (the x.requires_grad == False
+    case), against the GEMM-epilogue implementation of the same head."""
+    dev = gpu_device
+    T = 4099
+    x = rnd(T, 32, dev=dev, seed=80)
+    w1 = rnd(128, 32, dev=dev, seed=81, scale=0.3)
+    w2 = rnd(1, 128, dev=dev, seed=82, scale=0.3)
+    g = rnd(T, 1, dev=dev, seed=83)
+    assert H.mlp_head_supported(32, 128, 1)
+    out = torch.full((T, 1), float("nan"), device=dev)
+    H.mlp_head_fwd(x, w1, None, w2, None, H.ACT_SILU, out)
+    h = torch.nn.functional.silu(x.double() @ w1.double().t())
+    assert rel_l2(out, h @ w2.double().t()) < KTOL
+    dw1 = torch.full((128, 32), float("nan"), device=dev)
+    dw2 = torch.full((1, 128), float("nan"), device=dev)
+    H.mlp_head_bwd(x, w1, None, w2, H.ACT_SILU, g, None, dw1, None, dw2, None)
+    xd = x.double().requires_grad_(False)
+    w1d, w2d = w1.double().requires_grad_(True), w2.double().requires_grad_(True)
+    ref = torch.nn.functional.silu(xd @ w1d.t()) @ w2d.t()
+    gw1, gw2 = torch.autograd.grad(ref, (w1d, w2d), g.double())
+    assert rel_l2(dw1, gw1) < 5e-6
+    assert rel_l2(dw2, gw2) < 5e-6
