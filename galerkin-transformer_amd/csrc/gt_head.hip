@@ -269,20 +269,27 @@ __global__ __launch_bounds__(256, 2) void head_bwd_kernel(const HeadP p) {
     for (int e = tid; e < HSLAB; e += 256) out[e] = red[e];
 }
 
-// dst = sum over slabs, fixed order (4 interleaved partial sums); one thread per element of the slab
-__global__ void head_reduce_kernel(const float* slabs, int nslab, float* dW1, float* dw2, float* db1, float* db2) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= HSLAB) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= nslab; s += 4) {
-        s0 += slabs[(int64_t)(s + 0) * HSLAB + e];
-        s1 += slabs[(int64_t)(s + 1) * HSLAB + e];
-        s2 += slabs[(int64_t)(s + 2) * HSLAB + e];
-        s3 += slabs[(int64_t)(s + 3) * HSLAB + e];
+// dst = sum over slabs in a fixed order (8 interleaved slab lanes, then the 8 partials in order)
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ slabs, int nslab, float* dW1,
+                                                         float* dw2, float* db1, float* db2) {
+    __shared__ float part[8][32];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    float a0 = 0.f, a1 = 0.f;
+    if (e < HSLAB) {
+        int s = sl;
+        for (; s + 8 < nslab; s += 16) {
+            a0 += slabs[(int64_t)s * HSLAB + e];
+            a1 += slabs[(int64_t)(s + 8) * HSLAB + e];
+        }
+        if (s < nslab) a0 += slabs[(int64_t)s * HSLAB + e];
     }
-    for (; s < nslab; ++s) s0 += slabs[(int64_t)s * HSLAB + e];
-    const float v = (s0 + s1) + (s2 + s3);
+    part[sl][el] = a0 + a1;
+    __syncthreads();
+    if (sl != 0 || e >= HSLAB) return;
+    float v = part[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v += part[k][el];
     if (e < HN * HK) dW1[e] = v;
     else if (e < HN * HK + HN) { if (dw2) dw2[e - HN * HK] = v; }
     else if (e < HN * HK + 2 * HN) { if (db1) db1[e - HN * HK - HN] = v; }
@@ -342,7 +349,7 @@ extern "C" int gt_mlp_head_bwd(const float* X, int64_t T, int32_t K, int32_t N, 
     else if (act == GT_ACT_RELU) hipLaunchKernelGGL((head_bwd_kernel<GT_ACT_RELU>), dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((head_bwd_kernel<GT_ACT_NONE>), dim3(blocks), dim3(256), 0, st, p);
     GT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_reduce_kernel, dim3((HSLAB + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(ws),
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((HSLAB + 31) / 32), dim3(256), 0, st, reinterpret_cast<const float*>(ws),
                        blocks, dW1, dw2, db1, db2);
     GT_LAUNCH_CHECK();
     return 0;

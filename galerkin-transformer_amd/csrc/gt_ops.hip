@@ -296,26 +296,37 @@ __global__ void headnorm_fwd_v2_kernel(const float* __restrict__ qkv, const floa
     const int d3 = 3 * g.h * g.dk;
     const float inv = 1.f / (float)g.dk;
     const int t_end = min(g.T, (int)(blockIdx.x + 1) * g.tpb);
-    for (int t = blockIdx.x * g.tpb + r; t < t_end; t += g.R) {
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (active) x = *reinterpret_cast<const f32x4*>(qkv + (int64_t)t * d3 + seg * g.dk + 4 * q);
-        f32x4 y = x;
-        if (normed) {
-            const float mu = group_sum(x[0] + x[1] + x[2] + x[3], g.G) * inv;
-            f32x4 c = x - mu;
-            if (!active) c = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float var = group_sum(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3], g.G) * inv;
-            const float rstd = 1.f / sqrtf(var + eps);
-            y = c * rstd * gm + bt;
-            if (q == 0)
-                *reinterpret_cast<f32x2*>(stats + (((int64_t)ni * g.T + t) * g.h + head) * 2) = f32x2{mu, rstd};
+    // two tokens per trip: both loads are requested before either is consumed
+    for (int t = blockIdx.x * g.tpb + r; t < t_end; t += 2 * g.R) {
+        const bool two = t + g.R < t_end;
+        f32x4 xx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (active) {
+            xx[0] = *reinterpret_cast<const f32x4*>(qkv + (int64_t)t * d3 + seg * g.dk + 4 * q);
+            if (two) xx[1] = *reinterpret_cast<const f32x4*>(qkv + (int64_t)(t + g.R) * d3 + seg * g.dk + 4 * q);
         }
-        float* row = out + (((int64_t)stream * g.T + t) * g.h + head) * g.DP;
-        if (active) tile_store4(row + g.p + 4 * q, g.p, y);
-        if (q == 0)
-            for (int j = 0; j < g.p; ++j) row[j] = pos[(int64_t)t * g.p + j];
-        if (q == Q4 - 1)
-            for (int j = g.p + g.dk; j < g.DP; ++j) row[j] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const int tt = t + u * g.R;
+            const f32x4 x = xx[u];
+            f32x4 y = x;
+            if (normed) {
+                const float mu = group_sum(x[0] + x[1] + x[2] + x[3], g.G) * inv;
+                f32x4 c = x - mu;
+                if (!active) c = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float var = group_sum(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3], g.G) * inv;
+                const float rstd = 1.f / sqrtf(var + eps);
+                y = c * rstd * gm + bt;
+                if (q == 0)
+                    *reinterpret_cast<f32x2*>(stats + (((int64_t)ni * g.T + tt) * g.h + head) * 2) = f32x2{mu, rstd};
+            }
+            float* row = out + (((int64_t)stream * g.T + tt) * g.h + head) * g.DP;
+            if (active) tile_store4(row + g.p + 4 * q, g.p, y);
+            if (q == 0)
+                for (int j = 0; j < g.p; ++j) row[j] = pos[(int64_t)tt * g.p + j];
+            if (q == Q4 - 1)
+                for (int j = g.p + g.dk; j < g.DP; ++j) row[j] = 0.f;
+        }
     }
 }
 
@@ -338,26 +349,39 @@ __global__ void headnorm_bwd_v2_kernel(const float* __restrict__ d_out, const fl
         const int d3 = 3 * hd;
         const float inv = 1.f / (float)g.dk;
         const int t_end = min(g.T, (int)(blockIdx.x + 1) * g.tpb);
-        for (int t = blockIdx.x * g.tpb + r; t < t_end; t += g.R) {
-            f32x4 gy = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
-            if (active) {
-                gy = tile_load4(d_out + (((int64_t)stream * g.T + t) * g.h + head) * g.DP + g.p + 4 * q, g.p);
-                if (normed) x = *reinterpret_cast<const f32x4*>(qkv + (int64_t)t * d3 + seg * g.dk + 4 * q);
+        for (int t = blockIdx.x * g.tpb + r; t < t_end; t += 2 * g.R) {      // two tokens per trip (see forward)
+            const bool two = t + g.R < t_end;
+            f32x4 gyy[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, xx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            f32x2 stt[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+                const int tt = t + u * g.R;
+                if (active) {
+                    gyy[u] = tile_load4(d_out + (((int64_t)stream * g.T + tt) * g.h + head) * g.DP + g.p + 4 * q, g.p);
+                    if (normed) xx[u] = *reinterpret_cast<const f32x4*>(qkv + (int64_t)tt * d3 + seg * g.dk + 4 * q);
+                }
+                if (normed) stt[u] = *reinterpret_cast<const f32x2*>(stats + (((int64_t)ni * g.T + tt) * g.h + head) * 2);
             }
-            f32x4 dx = gy;
-            if (normed) {
-                const f32x2 st = *reinterpret_cast<const f32x2*>(stats + (((int64_t)ni * g.T + t) * g.h + head) * 2);
-                const float mu = st[0], rstd = st[1];
-                f32x4 xh = (x - mu) * rstd;
-                if (!active) xh = f32x4{0.f, 0.f, 0.f, 0.f};
-                const f32x4 gg = gy * gm;
-                const float m1 = group_sum(gg[0] + gg[1] + gg[2] + gg[3], g.G) * inv;
-                const float m2 = group_sum(gg[0] * xh[0] + gg[1] * xh[1] + gg[2] * xh[2] + gg[3] * xh[3], g.G) * inv;
-                dx = rstd * (gg - m1 - xh * m2);
-                dg += gy * xh;
-                db += gy;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+                const int tt = t + u * g.R;
+                const f32x4 gy = gyy[u], x = xx[u];
+                f32x4 dx = gy;
+                if (normed) {
+                    const float mu = stt[u][0], rstd = stt[u][1];
+                    f32x4 xh = (x - mu) * rstd;
+                    if (!active) xh = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 gg = gy * gm;
+                    const float m1 = group_sum(gg[0] + gg[1] + gg[2] + gg[3], g.G) * inv;
+                    const float m2 = group_sum(gg[0] * xh[0] + gg[1] * xh[1] + gg[2] * xh[2] + gg[3] * xh[3], g.G) * inv;
+                    dx = rstd * (gg - m1 - xh * m2);
+                    dg += gy * xh;
+                    db += gy;
+                }
+                if (active) *reinterpret_cast<f32x4*>(d_qkv + (int64_t)tt * d3 + seg * g.dk + 4 * q) = dx;
             }
-            if (active) *reinterpret_cast<f32x4*>(d_qkv + (int64_t)t * d3 + seg * g.dk + 4 * q) = dx;
         }
         float* me = lds + ((size_t)r * g.PT + l) * 8;
 #pragma unroll
@@ -390,7 +414,10 @@ static bool head_geom(int T, int h, int dk, int p, int norm_mask, int max_blocks
     if (G > 64) return false;
     const int PT = 3 * h * G;
     if (PT > 1024) return false;
-    int thr = std::max(256, ((PT + 63) / 64) * 64);
+    // whole waves with no idle lanes when PT and the wave size have a small common multiple (PT = 96 -> 384)
+    int lcm = PT;
+    while (lcm % 64) lcm += PT;
+    int thr = lcm <= 512 ? lcm * std::max(1, 384 / lcm) : std::max(256, ((PT + 63) / 64) * 64);
     const int R = thr / PT;
     int nblk = std::min(max_blocks, ceil_div(T, R * 8));
     nblk = std::max(nblk, 1);

@@ -122,6 +122,35 @@ __global__ __launch_bounds__(256, MP >= 3 ? 2 : 3) void tsmm_kernel(const TsmmP 
     for (int e = tid; e < tot; e += 256) out[e] = red[e];
 }
 
+// C[m][n] = alpha * sum over slabs (fixed order: 8 interleaved slab lanes, then the 8 partials in order);
+// elements >= M*N of a slab are the column sums of A.
+__global__ __launch_bounds__(256) void tsmm_reduce_kernel(const float* __restrict__ slabs, int nslab, int M, int N,
+                                                         int64_t ldc, float alpha, float* __restrict__ C,
+                                                         float cs_scale, float* __restrict__ colsum) {
+    __shared__ float part[8][32];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int MN = M * N, stride = MN + M, tot = MN + (colsum ? M : 0);
+    const int e = blockIdx.x * 32 + el;
+    float a0 = 0.f, a1 = 0.f;
+    if (e < tot) {
+        int s = sl;
+        for (; s + 8 < nslab; s += 16) {
+            a0 += slabs[(int64_t)s * stride + e];
+            a1 += slabs[(int64_t)(s + 8) * stride + e];
+        }
+        if (s < nslab) a0 += slabs[(int64_t)s * stride + e];
+    }
+    part[sl][el] = a0 + a1;
+    __syncthreads();
+    if (sl == 0 && e < tot) {
+        float v = part[0][el];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v += part[k][el];
+        if (e < MN) C[(int64_t)(e / N) * ldc + e % N] = alpha * v;
+        else colsum[e - MN] = cs_scale * v;
+    }
+}
+
 // rows per wave: a multiple of 16 that spreads K over ~4 blocks per CU
 static void tsmm_geometry(int K, int* blocks, int* rows_per_wave) {
     const int64_t waves = 4096;
@@ -137,7 +166,7 @@ bool tsmm_eligible(const gt_gemm_desc* d) {
     if (d->a_drop.p > 0.f || d->bias || d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f ||
         d->res || d->out_scale != 1.f || d->ep_mode != GT_EP_NORMAL || d->K2 > 0)
         return false;
-    if ((d->lda & 1) || (d->ldb & 1) || d->ldc != d->N) return false;
+    if ((d->lda & 1) || (d->ldb & 1) || d->ldc < d->N) return false;
     if ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B)) & 7) return false;
     return true;
 }
@@ -171,13 +200,11 @@ int tsmm_run(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream) {
         default: hipLaunchKernelGGL((tsmm_kernel<4, 2>), dim3(blocks), dim3(256), 0, st, p); break;
     }
     GT_LAUNCH_CHECK();
-    const int64_t mn = (int64_t)d->M * d->N, stride = mn + d->M;
-    int rc = gt_slab_reduce(reinterpret_cast<const float*>(ws), stride, blocks, mn, d->alpha, d->C, stream);
-    if (rc) return rc;
-    if (d->a_colsum)
-        rc = gt_slab_reduce(reinterpret_cast<const float*>(ws) + mn, stride, blocks, d->M, d->a_drop_sign, d->a_colsum,
-                            stream);
-    return rc;
+    const int tot = d->M * d->N + (d->a_colsum ? d->M : 0);
+    hipLaunchKernelGGL(tsmm_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, reinterpret_cast<const float*>(ws),
+                       blocks, d->M, d->N, d->ldc, d->alpha, d->C, d->a_drop_sign, d->a_colsum);
+    GT_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace gt

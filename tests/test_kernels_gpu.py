@@ -677,3 +677,20 @@ def test_mlp_head_dedicated_kernels_without_optional_outputs(H, gpu_device):
     gw1, gw2 = torch.autograd.grad(ref, (w1d, w2d), g.double())
     assert rel_l2(dw1, gw1) < 5e-6
     assert rel_l2(dw2, gw2) < 5e-6
+
+
+def test_gemm_tall_skinny_wgrad_into_column_slice(H, gpu_device):
+    """The tsmm path writes through ldc (the grid columns of SpectralRegressor.fc's weight gradient are a column
+    slice of the [N, K + p] weight) and leaves the other columns alone."""
+    dev = gpu_device
+    M, N, K, ld = 32, 2, 70001, 34
+    A = rnd(K, M, dev=dev, seed=60)
+    Bm = rnd(K, N, dev=dev, seed=61)
+    W = torch.full((M, ld), 7.0, device=dev)
+    cs = torch.empty(M, device=dev)
+    Cv = W[:, ld - N:]
+    H.gemm(A, Bm, Cv, M, N, K, layout_a=1, layout_b=1, lda=M, ldb=N, ldc=ld, split_k=0, a_colsum=cs)
+    torch.cuda.synchronize()
+    assert rel_l2(W[:, ld - N:], A.double().t() @ Bm.double()) < KTOL
+    assert torch.all(W[:, :ld - N] == 7.0)
+    assert rel_l2(cs, A.double().sum(0)) < KTOL
