@@ -24,6 +24,48 @@ __global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restr
         out[i] = x[i] * (d.thresh ? drop_mul(d, key, (uint32_t)i) : d.scale);
 }
 
+// y = act2(drop2(act1(drop1(x)))) in one pass (BWD: gx = gy * dy/dx, recomputed from x): the elementwise tail
+// of Conv2dResBlock (layers.py:88-150) and of Interp2dUpsample's conv branch (layers.py:658-668), where the
+// reference runs up to four separate elementwise kernels over a [B, C, H, W] map.  Mask index = element index.
+__device__ __forceinline__ void act_pair(int act, float v, float& a, float& da) {
+    if (act == GT_ACT_SILU) silu_both(v, a, da);
+    else if (act == GT_ACT_RELU) { a = fmaxf(v, 0.f); da = v > 0.f ? 1.f : 0.f; }
+    else { a = v; da = 1.f; }
+}
+template <bool BWD>
+__device__ __forceinline__ float dropact_one(float x, float gy, uint32_t idx, const DropDev& d1, uint32_t k1, int a1,
+                                             const DropDev& d2, uint32_t k2, int a2) {
+    const float m1 = d1.thresh ? drop_mul(d1, k1, idx) : d1.scale;
+    const float m2 = d2.thresh ? drop_mul(d2, k2, idx) : d2.scale;
+    float a, da, b, db;
+    act_pair(a1, x * m1, a, da);
+    act_pair(a2, a * m2, b, db);
+    return BWD ? gy * db * m2 * da * m1 : b;
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void dropact_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      float* __restrict__ out, int64_t n, DropDev d1, int a1,
+                                                      DropDev d2, int a2, int vec) {
+    const uint32_t k1 = drop_key_dev(d1), k2 = drop_key_dev(d2);
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nth) {
+            const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f}, o;
+            if (BWD) gv = reinterpret_cast<const f32x4*>(gy)[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = dropact_one<BWD>(xv[j], gv[j], (uint32_t)(4 * i + j), d1, k1, a1, d2, k2, a2);
+            reinterpret_cast<f32x4*>(out)[i] = o;
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nth)
+            out[i] = dropact_one<BWD>(x[i], BWD ? gy[i] : 0.f, (uint32_t)i, d1, k1, a1, d2, k2, a2);
+    } else {
+        for (int64_t i = tid; i < n; i += nth)
+            out[i] = dropact_one<BWD>(x[i], BWD ? gy[i] : 0.f, (uint32_t)i, d1, k1, a1, d2, k2, a2);
+    }
+}
+
 // out[i] = alpha * sum_k slabs[k*stride + i].  A block owns 16 consecutive outputs; its 16 slab
 // lanes each walk every 16th slab (fixed order -> deterministic), then a fixed LDS tree combines.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t stride,
@@ -824,6 +866,30 @@ extern "C" int gt_dropout_apply(const float* x, float* out, int64_t n, const gt_
                        n, make_drop(d));
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+static int dropact_launch(bool bwd, const float* x, const float* gy, float* out, int64_t n, const gt_dropout* d1,
+                          int32_t act1, const gt_dropout* d2, int32_t act2, void* stream) {
+    if (!x || !out || n < 0 || (bwd && !gy)) return GT_EINVAL;
+    if ((d1 && d1->p > 0.f && !d1->seed) || (d2 && d2->p > 0.f && !d2->seed)) return GT_EINVAL;
+    if (act1 < GT_ACT_NONE || act1 > GT_ACT_SILU || act2 < GT_ACT_NONE || act2 > GT_ACT_SILU) return GT_EINVAL;
+    if (n == 0) return 0;
+    const int vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const int grid = grid_for((n + 3) / 4, 256, 8192);
+    if (bwd) hipLaunchKernelGGL(dropact_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gy, out, n,
+                                make_drop(d1), act1, make_drop(d2), act2, vec);
+    else hipLaunchKernelGGL(dropact_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gy, out, n,
+                            make_drop(d1), act1, make_drop(d2), act2, vec);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gt_dropact_fwd(const float* x, float* y, int64_t n, const gt_dropout* d1, int32_t act1,
+                              const gt_dropout* d2, int32_t act2, void* stream) {
+    return dropact_launch(false, x, nullptr, y, n, d1, act1, d2, act2, stream);
+}
+extern "C" int gt_dropact_bwd(const float* x, const float* gy, float* gx, int64_t n, const gt_dropout* d1,
+                              int32_t act1, const gt_dropout* d2, int32_t act2, void* stream) {
+    return dropact_launch(true, x, gy, gx, n, d1, act1, d2, act2, stream);
 }
 
 extern "C" int gt_slab_reduce(const float* slabs, int64_t stride, int32_t n_slabs, int64_t n, float alpha,

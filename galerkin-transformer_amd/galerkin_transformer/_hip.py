@@ -84,6 +84,10 @@ _PROTOS = {
     "gt_galerkin_ktv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
     "gt_fourier_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.POINTER(GtDropout),
                                                                 C.c_int32, C.c_void_p]),
+    "gt_dropact_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(GtDropout), C.c_int32, C.POINTER(GtDropout),
+                                 C.c_int32, C.c_void_p]),
+    "gt_dropact_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(GtDropout), C.c_int32,
+                                 C.POINTER(GtDropout), C.c_int32, C.c_void_p]),
     "gt_mlp_head_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 4 +
                         [C.c_int32, C.c_void_p, C.c_void_p]),
     "gt_mlp_head_bwd_ws_bytes": (C.c_int64, [C.c_int64]),
@@ -432,6 +436,31 @@ def dropout_apply(x: torch.Tensor, d: GtDropout) -> torch.Tensor:
     out = torch.empty_like(x)
     check(_timed("gt_dropout_apply", 0, 0, lambda: lib().gt_dropout_apply(x.data_ptr(), out.data_ptr(), x.numel(), C.byref(d), stream_ptr())), "gt_dropout_apply")
     return out
+
+
+def _dref(d):
+    return C.byref(d) if (d is not None and d.p > 0) else None
+
+
+def dropact_fwd(x: torch.Tensor, d1, act1: int, d2, act2: int) -> torch.Tensor:
+    """act2(drop2(act1(drop1(x)))) elementwise (gt_dropact_fwd)."""
+    need_f32_cuda(x)
+    y = torch.empty_like(x)
+    n = x.numel()
+    check(_timed("gt_dropact_fwd", 0, 8.0 * n, lambda: lib().gt_dropact_fwd(x.data_ptr(), y.data_ptr(), n, _dref(d1), act1,
+                                                                         _dref(d2), act2, stream_ptr()), shape=(n,)),
+          "gt_dropact_fwd")
+    return y
+
+
+def dropact_bwd(x: torch.Tensor, gy: torch.Tensor, d1, act1: int, d2, act2: int) -> torch.Tensor:
+    need_f32_cuda(x, gy)
+    gx = torch.empty_like(x)
+    n = x.numel()
+    check(_timed("gt_dropact_bwd", 0, 12.0 * n, lambda: lib().gt_dropact_bwd(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), n,
+                                                                          _dref(d1), act1, _dref(d2), act2, stream_ptr()),
+                 shape=(n,)), "gt_dropact_bwd")
+    return gx
 
 
 def round4(v: int) -> int:

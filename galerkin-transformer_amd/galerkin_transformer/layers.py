@@ -104,10 +104,21 @@ class Conv2dResBlock(nn.Module):
         # nn.Dropout members are kept for the module tree / state_dict; the masks come from the
         # library's stateless RNG (ops.dropout) so the whole step shares one graph-safe seed.
         h = self.res(x) if self.add_res else None
-        x = ops.dropout(self.conv[0](x), self.conv[1].p, self.training)
-        if self.basic_block:
-            x = ops.dropout(self.conv1[1](self.activation(x)), self.conv1[2].p, self.training)
-        return self.activation(x + h) if self.add_res else self.activation(x)
+        act = _act_name(self.activation)
+        if self.basic_block:      # activation(dropout(conv(x))) is one elementwise pass (ops.drop_act)
+            x = self.conv1[1](ops.drop_act(self.conv[0](x), self.conv[1].p, act, self.training))
+            if not self.add_res:
+                return ops.drop_act(x, self.conv1[2].p, act, self.training)
+            x = ops.dropout(x, self.conv1[2].p, self.training)
+        elif not self.add_res:
+            return ops.drop_act(self.conv[0](x), self.conv[1].p, act, self.training)
+        else:
+            x = ops.dropout(self.conv[0](x), self.conv[1].p, self.training)
+        return self.activation(x + h)
+
+    def plain(self) -> bool:
+        """conv -> dropout -> activation and nothing else (lets a caller fuse its own dropout/activation on)."""
+        return not self.basic_block and not self.add_res
 
 
 class _Shortcut2d(nn.Module):
@@ -211,7 +222,12 @@ class Interp2dUpsample(nn.Module):
             raise NotImplementedError(f"interp_mode={self.interp_mode!r}: only bilinear has a HIP path")
         x = _resize(x, self.interp_size[0], None, in_nhwc=in_nhwc)
         if self.conv_block:
-            x = self.activation(ops.dropout(self.conv[0](x), self.dropout.p, self.training))
+            blk = self.conv[0]
+            if blk.plain():       # conv -> drop -> act -> drop -> act: the four elementwise stages in one pass
+                x = ops.drop_act(blk.conv[0](x), blk.conv[1].p, _act_name(blk.activation), self.training,
+                                 self.dropout.p, _act_name(self.activation))
+            else:
+                x = ops.drop_act(blk(x), self.dropout.p, _act_name(self.activation), self.training)
         return x
 
     def forward(self, x, in_nhwc=False, out_nhwc=False):

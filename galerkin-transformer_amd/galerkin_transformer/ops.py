@@ -77,6 +77,33 @@ def dropout(x, p: float, training: bool = True):
     return DropoutFn.apply(x, float(p))
 
 
+class DropActFn(Function):
+    """y = act2(drop2(act1(drop1(x)))) in one elementwise pass; backward recomputes from x (gt_dropact_*)."""
+
+    @staticmethod
+    def forward(ctx, x, p1: float, act1: int, p2: float, act2: int):
+        xc = _c(x)
+        ctx.cfg = (p1, _next_salt(1) if p1 > 0 else 0, act1, p2, _next_salt(1) if p2 > 0 else 0, act2)
+        ctx.save_for_backward(xc)
+        dev = x.device
+        return H.dropact_fwd(xc, H.dropout_desc(p1, ctx.cfg[1], dev), act1, H.dropout_desc(p2, ctx.cfg[4], dev), act2)
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        p1, s1, act1, p2, s2, act2 = ctx.cfg
+        dev = g.device
+        gx = H.dropact_bwd(xc, _c(g), H.dropout_desc(p1, s1, dev), act1, H.dropout_desc(p2, s2, dev), act2)
+        return gx, None, None, None, None
+
+
+def drop_act(x, p1: float, act1: str, training: bool = True, p2: float = 0.0, act2: str = "none"):
+    """act2(dropout(act1(dropout(x, p1)), p2)) -- the dropout -> activation tails of the conv blocks, fused."""
+    if not training:
+        p1 = p2 = 0.0
+    return DropActFn.apply(x, float(p1), H.ACT_CODE[act1], float(p2), H.ACT_CODE[act2])
+
+
 # ----------------------------------------------------------------------------------- bilinear resize
 class ResizeFn(Function):
     """act(F.interpolate(x, size, mode='bilinear', align_corners=True)) with the layout change of the

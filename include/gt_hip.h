@@ -64,6 +64,14 @@ int gt_seed_advance(uint64_t* seed, uint64_t inc, void* stream);
 /* out[i] = x[i] * keepscale(i)   -- standalone elementwise dropout, n elements, used by tests */
 int gt_dropout_apply(const float* x, float* out, int64_t n, const gt_dropout* d, void* stream);
 
+/* y[i] = act2(drop2(act1(drop1(x[i]))))  in one elementwise pass (mask index = i, the index gt_dropout_apply uses;
+ * d1 / d2 may be NULL or p = 0, act* = GT_ACT_*): the tail of Conv2dResBlock (layers.py:88-150) and of
+ * Interp2dUpsample's conv branch (layers.py:658-668).  Backward recomputes from x:  gx[i] = gy[i] * dy/dx. */
+int gt_dropact_fwd(const float* x, float* y, int64_t n, const gt_dropout* d1, int32_t act1, const gt_dropout* d2,
+                   int32_t act2, void* stream);
+int gt_dropact_bwd(const float* x, const float* gy, float* gx, int64_t n, const gt_dropout* d1, int32_t act1,
+                   const gt_dropout* d2, int32_t act2, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batched fp32 GEMM on the MFMA pipe (v_mfma_f32_16x16x4_f32) with fused prologue/epilogue.
  *

@@ -694,3 +694,34 @@ def test_gemm_tall_skinny_wgrad_into_column_slice(H, gpu_device):
     assert rel_l2(W[:, ld - N:], A.double().t() @ Bm.double()) < KTOL
     assert torch.all(W[:, :ld - N] == 7.0)
     assert rel_l2(cs, A.double().sum(0)) < KTOL
+
+
+@pytest.mark.parametrize("n", [4096 * 3 + 1, 64 * 77 * 77])
+@pytest.mark.parametrize("p1,a1,p2,a2", [(0.1, "relu", 0.0, "none"), (0.05, "silu", 0.05, "silu"), (0.0, "silu", 0.3, "relu"),
+                                         (0.0, "none", 0.0, "silu")])
+def test_drop_act_fused_equals_chain(H, gpu_device, n, p1, a1, p2, a2):
+    """ops.drop_act == activation(dropout(activation(dropout(x)))) built from the separate operators with the same
+    seed and salts (identical masks), forward and backward; also in eval mode."""
+    from galerkin_transformer import ops
+    import torch.nn.functional as F
+    dev = gpu_device
+    act = {"relu": torch.relu, "silu": F.silu, "none": lambda v: v}
+    x0 = rnd(n, dev=dev, seed=90)
+    cot = rnd(n, dev=dev, seed=91)
+    for training in (True, False):
+        res = []
+        for fused in (True, False):
+            H.set_seed(77, dev)
+            ops._salt[0] = 11
+            x = x0.clone().requires_grad_(True)
+            if fused:
+                y = ops.drop_act(x, p1, a1, training, p2, a2)
+            else:
+                y = act[a2](ops.dropout(act[a1](ops.dropout(x, p1, training)), p2, training))
+            y.backward(cot)
+            res.append((y.detach(), x.grad.detach()))
+        assert rel_l2(res[0][0], res[1][0]) < 1e-6
+        assert rel_l2(res[0][1], res[1][1]) < 1e-6
+    if p1 > 0:
+        kept = (ops.drop_act(torch.ones(n, device=dev), p1, "none") != 0).float().mean().item()
+        assert abs(kept - (1 - p1)) < 0.02
