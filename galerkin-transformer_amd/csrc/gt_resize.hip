@@ -614,6 +614,83 @@ static int check_resize(const void* x, const void* y, int B, int C, int Hi, int 
     if (out_nhwc && (reinterpret_cast<uintptr_t>(y) & 15)) return GT_EALIGN;
     return 0;
 }
+// ---- channels-last on both sides (the fine-grid resize of the regressor input): one thread per (pixel, 4
+// channels), flat over a row, so narrow channel counts (C = 32) keep every lane busy; RPT output rows per thread
+// put 4*RPT independent float4 loads in flight.
+constexpr int RN_RPT = 4;
+__global__ __launch_bounds__(256) void resize_nhwc_fwd_kernel(const ResizeP p) {
+    const int C4 = p.C >> 2;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.Wo * C4) return;
+    const int ox = e / C4, c = (e - ox * C4) * 4;
+    const int oy0 = blockIdx.y * RN_RPT, b = blockIdx.z;
+    const Axis ax = axis_of(ox, p.sx, p.Wi);
+    Axis ay[RN_RPT];
+    f32x4 v[RN_RPT][4];
+#pragma unroll
+    for (int r = 0; r < RN_RPT; ++r) {
+        const int oy = min(oy0 + r, p.Ho - 1);
+        ay[r] = axis_of(oy, p.sy, p.Hi);
+        v[r][0] = *reinterpret_cast<const f32x4*>(p.x + addr<true>(b, c, ay[r].i0, ax.i0, p.C, p.Hi, p.Wi));
+        v[r][1] = *reinterpret_cast<const f32x4*>(p.x + addr<true>(b, c, ay[r].i0, ax.i1, p.C, p.Hi, p.Wi));
+        v[r][2] = *reinterpret_cast<const f32x4*>(p.x + addr<true>(b, c, ay[r].i1, ax.i0, p.C, p.Hi, p.Wi));
+        v[r][3] = *reinterpret_cast<const f32x4*>(p.x + addr<true>(b, c, ay[r].i1, ax.i1, p.C, p.Hi, p.Wi));
+    }
+#pragma unroll
+    for (int r = 0; r < RN_RPT; ++r) {
+        const int oy = oy0 + r;
+        if (oy < p.Ho) {
+            f32x4 o = ay[r].l0 * (ax.l0 * v[r][0] + ax.l1 * v[r][1]) + ay[r].l1 * (ax.l0 * v[r][2] + ax.l1 * v[r][3]);
+            o = resize_affine(p, o, b, c, oy, ox);
+            if (p.act == GT_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(p.y + addr<true>(b, c, oy, ox, p.C, p.Ho, p.Wo)) = o;
+        }
+    }
+}
+
+// gather form of the backward (no atomics), same thread mapping over an input row; falls back to the tiled
+// kernel's generic loop when an axis has more than RS_MAXT contributing outputs
+__global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
+    const int C4 = p.C >> 2;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.Wi * C4) return;
+    const int ix = e / C4, c = (e - ix * C4) * 4;
+    const int iy = blockIdx.y, b = blockIdx.z;
+    const Taps ty = taps_of(iy, p.sy, p.Hi, p.Ho);
+    const Taps tx = taps_of(ix, p.sx, p.Wi, p.Wo);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jy = 0; jy < RS_MAXT; ++jy) {
+        if (jy < ty.n) {
+            f32x4 racc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jx = 0; jx < RS_MAXT; ++jx) {
+                if (jx < tx.n) {
+                    const int64_t o = addr<true>(b, c, ty.lo + jy, tx.lo + jx, p.C, p.Ho, p.Wo);
+                    f32x4 g = *reinterpret_cast<const f32x4*>(p.x + o);
+                    if (p.gate) {
+                        const f32x4 y = *reinterpret_cast<const f32x4*>(p.gate + o);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) g[j] = 0.f;
+                    }
+                    racc += tx.w[jx] * g;
+                }
+            }
+            acc += ty.w[jy] * racc;
+        }
+    }
+    *reinterpret_cast<f32x4*>(p.y + addr<true>(b, c, iy, ix, p.C, p.Hi, p.Wi)) = acc;
+}
+
+// true when no input index of the axis has more than RS_MAXT contributing outputs (host-side bound:
+// an input cell's support spans at most 2 * (no-1)/(ni-1) outputs)
+static inline bool taps_fit(int ni, int no) {
+    return ni <= 1 ? no <= RS_MAXT : 2.0 * (double)(no - 1) / (double)(ni - 1) + 2.0 <= (double)RS_MAXT;
+}
+
 static inline float scale_of(int ni, int no) { return (no > 1) ? (float)(ni - 1) / (float)(no - 1) : 0.f; }
 
 }  // namespace gt
@@ -639,7 +716,10 @@ extern "C" int gt_bilinear2d_fwd_affine(const float* x, float* y, int32_t B, int
     if (!in_nhwc && !out_nhwc) hipLaunchKernelGGL((resize_fwd_kernel<false, false>), grid, dim3(256), 0, st, p);
     else if (!in_nhwc && out_nhwc) hipLaunchKernelGGL((resize_fwd_kernel<false, true>), grid, dim3(256), 0, st, p);
     else if (in_nhwc && !out_nhwc) hipLaunchKernelGGL((resize_fwd_kernel<true, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((resize_fwd_kernel<true, true>), grid, dim3(256), 0, st, p);
+    else if ((C & 3) == 0 && ceil_div(Ho, RN_RPT) <= 65535) {
+        dim3 ng((unsigned)ceil_div((int64_t)Wo * (C / 4), 256), (unsigned)ceil_div(Ho, RN_RPT), (unsigned)B);
+        hipLaunchKernelGGL(resize_nhwc_fwd_kernel, ng, dim3(256), 0, st, p);
+    } else hipLaunchKernelGGL((resize_fwd_kernel<true, true>), grid, dim3(256), 0, st, p);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -669,7 +749,10 @@ extern "C" int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx
     }
     else if (!out_nhwc && in_nhwc) hipLaunchKernelGGL((resize_bwd_kernel<false, true>), grid, dim3(256), 0, st, p);
     else if (out_nhwc && !in_nhwc) hipLaunchKernelGGL((resize_bwd_kernel<true, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((resize_bwd_kernel<true, true>), grid, dim3(256), 0, st, p);
+    else if ((C & 3) == 0 && taps_fit(Hi, Ho) && taps_fit(Wi, Wo)) {
+        dim3 ng((unsigned)ceil_div((int64_t)Wi * (C / 4), 256), (unsigned)Hi, (unsigned)B);
+        hipLaunchKernelGGL(resize_nhwc_bwd_kernel, ng, dim3(256), 0, st, p);
+    } else hipLaunchKernelGGL((resize_bwd_kernel<true, true>), grid, dim3(256), 0, st, p);
     GT_LAUNCH_CHECK();
     return 0;
 }
