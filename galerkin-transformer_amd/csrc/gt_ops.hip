@@ -448,6 +448,83 @@ __global__ void headnorm_bwd_v2_kernel(const float* __restrict__ d_out, const fl
     }
 }
 
+// ------------------------------------------------------------------------------------------ galerkin dK', dV'
+// dK'[t] = V'[t] dM^T and dV'[t] = K'[t] dM for every token of one (batch, head)  -- the backward of
+// M = K'^T V' (layers.py:723) -- as one streaming pass: the two DP x DP operands live in registers as MFMA A
+// fragments, token rows go from HBM straight into B fragments.  A row of DP = 16G + 4 floats is G*4 + 1
+// float4: lane (row j, kq) loads float4 number kq + 4g (g < G) and the last one; k-step (g, c) contracts
+// k = 4(kq + 4g) + c (component c of the lane's g-th float4), the final step k = 16G + kq (component kq of the
+// shared last float4) -- every k exactly once, every load a full 64-byte run per row.  Result tiles come out
+// transposed (output column x row), i.e. one float4 of the output row per lane.
+struct DkvP {
+    const float* Kp; const float* Vp; const float* dM; float* dKp; float* dVp;
+    int n, h;
+};
+template <int G>
+__global__ __launch_bounds__(256, 2) void galerkin_dkv_kernel(const DkvP p) {
+    constexpr int DP = 16 * G + 4, NS = 4 * G + 1, NMT = G + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int head = blockIdx.x % p.h, b = blockIdx.x / p.h;
+    const int64_t hD = (int64_t)p.h * DP;
+    const int64_t base = ((int64_t)b * p.n) * hD + (int64_t)head * DP;
+    const float* dm = p.dM + ((int64_t)b * p.h + head) * DP * DP;
+    // A fragments: lane (i = output column 16mt + j, kq); a1 -> dK' (dM[col][k]), a2 -> dV' (dM[k][col])
+    float a1[NMT][NS], a2[NMT][NS];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+        const int col = 16 * mt + j, cc = min(col, DP - 1);
+        const float live = col < DP ? 1.f : 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int k = (s < 4 * G) ? 4 * (kq + 4 * (s >> 2)) + (s & 3) : 16 * G + kq;
+            a1[mt][s] = live * dm[cc * DP + k];
+            a2[mt][s] = live * dm[k * DP + cc];
+        }
+    }
+    const int ntile = (p.n + 15) >> 4;
+    for (int tile = wave; tile < ntile; tile += 4) {
+        const int t = 16 * tile + j, tc = min(t, p.n - 1);
+        const float* kr = p.Kp + base + (int64_t)tc * hD;
+        const float* vr = p.Vp + base + (int64_t)tc * hD;
+        f32x4 kk[G + 1], vv[G + 1];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            kk[g] = *reinterpret_cast<const f32x4*>(kr + 4 * (kq + 4 * g));
+            vv[g] = *reinterpret_cast<const f32x4*>(vr + 4 * (kq + 4 * g));
+        }
+        kk[G] = *reinterpret_cast<const f32x4*>(kr + 16 * G);
+        vv[G] = *reinterpret_cast<const f32x4*>(vr + 16 * G);
+        f32x4 acc1[NMT], acc2[NMT];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) acc1[mt] = acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float bv, bk;
+            if (s < 4 * G) { bv = vv[s >> 2][s & 3]; bk = kk[s >> 2][s & 3]; }
+            else {
+                bv = kq == 0 ? vv[G][0] : (kq == 1 ? vv[G][1] : (kq == 2 ? vv[G][2] : vv[G][3]));
+                bk = kq == 0 ? kk[G][0] : (kq == 1 ? kk[G][1] : (kq == 2 ? kk[G][2] : kk[G][3]));
+            }
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt][s], bv, acc1[mt], 0, 0, 0);
+                acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mt][s], bk, acc2[mt], 0, 0, 0);
+            }
+        }
+        if (t < p.n) {
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const int col = 16 * mt + 4 * kq;
+                if (col < DP) {
+                    *reinterpret_cast<f32x4*>(p.dKp + base + (int64_t)t * hD + col) = acc1[mt];
+                    *reinterpret_cast<f32x4*>(p.dVp + base + (int64_t)t * hD + col) = acc2[mt];
+                }
+            }
+        }
+    }
+}
+
 static bool head_geom(int T, int h, int dk, int p, int norm_mask, int max_blocks, HeadGeom* g, int* threads,
                       int* blocks) {
     if (dk & 3) return false;
@@ -1002,6 +1079,23 @@ extern "C" int gt_headnorm_bwd(const float* d_out, const float* qkv, const float
         rc = gt_slab_reduce(partial + 2 * hd, 4 * hd, nblk, 2 * hd, 1.f, dbeta, stream);
         if (rc) return rc;
     }
+    return 0;
+}
+
+extern "C" int gt_galerkin_dkv(const float* Kp, const float* Vp, const float* dM, float* dKp, float* dVp,
+                               int32_t B, int32_t n, int32_t h, int32_t DP, void* stream) {
+    if (!Kp || !Vp || !dM || !dKp || !dVp || B <= 0 || n <= 0 || h <= 0) return GT_EINVAL;
+    if (DP != 20 && DP != 36 && DP != 52) return GT_ENOTSUP;
+    if ((reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vp) | reinterpret_cast<uintptr_t>(dKp) |
+         reinterpret_cast<uintptr_t>(dVp)) & 15)
+        return GT_EALIGN;
+    DkvP p{Kp, Vp, dM, dKp, dVp, n, h};
+    dim3 grid((unsigned)(B * h));
+    hipStream_t st = (hipStream_t)stream;
+    if (DP == 20) hipLaunchKernelGGL(galerkin_dkv_kernel<1>, grid, dim3(256), 0, st, p);
+    else if (DP == 36) hipLaunchKernelGGL(galerkin_dkv_kernel<2>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(galerkin_dkv_kernel<3>, grid, dim3(256), 0, st, p);
+    GT_LAUNCH_CHECK();
     return 0;
 }
 

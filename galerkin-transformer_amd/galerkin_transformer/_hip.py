@@ -82,6 +82,7 @@ _PROTOS = {
     "gt_headnorm_bwd_ws_bytes": (C.c_int64, [C.c_int32] * 3),
     "gt_galerkin_ktv_slabs": (C.c_int32, [C.c_int32, C.c_int32]),
     "gt_galerkin_ktv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
+    "gt_galerkin_dkv": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
     "gt_fourier_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.POINTER(GtDropout),
                                                                 C.c_int32, C.c_void_p]),
     "gt_dropact_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(GtDropout), C.c_int32, C.POINTER(GtDropout),
@@ -652,6 +653,19 @@ def galerkin_ktv(Kp: torch.Tensor, Vp: torch.Tensor, B: int, n: int, h: int, dk:
                  lambda: lib().gt_galerkin_ktv(Kp.data_ptr(), Vp.data_ptr(), B, n, h, dk, p, slabs.data_ptr(), ns,
                                                stream_ptr()), shape=(B, n, h, dk, p)), "gt_galerkin_ktv")
     return slabs
+
+
+# kernels that exist and pass their CPU lane-model checks but have not been measured on hardware yet are opt-in:
+# GT_STAGED=dkv,...  (see include/gt_hip.h for each)
+STAGED = frozenset(x for x in os.environ.get("GT_STAGED", "").split(",") if x)
+
+
+def galerkin_dkv(Kp, Vp, dM, dKp, dVp, B: int, n: int, h: int, DP: int):
+    """dK' = V' dM^T, dV' = K' dM per (batch, head) in one streaming pass (gt_galerkin_dkv)."""
+    need_f32_cuda(Kp, Vp, dM, dKp, dVp)
+    check(_timed("gt_galerkin_dkv", 4.0 * B * h * n * DP * DP, 16.0 * B * n * h * DP,
+                 lambda: lib().gt_galerkin_dkv(Kp.data_ptr(), Vp.data_ptr(), dM.data_ptr(), dKp.data_ptr(), dVp.data_ptr(),
+                                               B, n, h, DP, stream_ptr()), shape=(B, n, h, DP)), "gt_galerkin_dkv")
 
 
 def mlp_head_supported(K: int, N: int, n_out: int) -> bool:

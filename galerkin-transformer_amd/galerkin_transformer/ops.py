@@ -568,10 +568,13 @@ class SimpleAttentionFn(Function):
             dwfc = torch.empty(d, h * Dr, dtype=torch.float32, device=dev)
             H.slab_reduce(dWs, B, d * h * Dr, d * h * Dr, dwfc)
             # dK' = V' dM^T ; dV' = K' dM          per (b, head)
-            H.gemm(Vp, dM, dO3[1], n, DP, DP, lda=hD, ldb=DP, ldc=hD, batch=(B, h), a_bs=(n * hD, DP),
-                   b_bs=(h * DP * DP, DP * DP), c_bs=(n * hD, DP))
-            H.gemm(Kp, dM, dO3[2], n, DP, DP, layout_b=1, lda=hD, ldb=DP, ldc=hD, batch=(B, h),
-                   a_bs=(n * hD, DP), b_bs=(h * DP * DP, DP * DP), c_bs=(n * hD, DP))
+            if "dkv" in H.STAGED and DP in H.FOURIER_DP:
+                H.galerkin_dkv(Kp, Vp, dM, dO3[1], dO3[2], B, n, h, DP)
+            else:
+                H.gemm(Vp, dM, dO3[1], n, DP, DP, lda=hD, ldb=DP, ldc=hD, batch=(B, h), a_bs=(n * hD, DP),
+                       b_bs=(h * DP * DP, DP * DP), c_bs=(n * hD, DP))
+                H.gemm(Kp, dM, dO3[2], n, DP, DP, layout_b=1, lda=hD, ldb=DP, ldc=hD, batch=(B, h),
+                       a_bs=(n * hD, DP), b_bs=(h * DP * DP, DP * DP), c_bs=(n * hD, DP))
         else:
             xc, wq, gamma, wpad, qkv, stats, out3, S, att, mask = ctx.saved_tensors
             d_attn = H.dropout_desc(p_attn, salt, dev) if (p_attn > 0 and mask is None) else None

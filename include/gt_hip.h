@@ -222,6 +222,14 @@ int gt_galerkin_finalize_bwd(const float* dPt, const float* Mt, const float* mas
                              int32_t B, int32_t h, int32_t DP, int32_t Dr, int32_t d, int32_t n_tokens,
                              float* dM, float* dWfc_slabs, void* stream);
 
+/* dK'[t] = V'[t] dM^T,  dV'[t] = K'[t] dM  for every token of every (batch, head): the backward of
+ * M = K'^T V' (layers.py:723) as one streaming pass over the head tiles [B*n][h][DP] (dM [B,h,DP,DP]).
+ * DP in {20, 36, 52}, else GT_ENOTSUP (two batched gt_gemm launches do the same).  STAGED: validated against a
+ * lane-accurate CPU model (tests/test_lane_models_cpu.py) but not yet measured on hardware; the Python mirror
+ * uses it only when GT_STAGED contains "dkv". */
+int gt_galerkin_dkv(const float* Kp, const float* Vp, const float* dM, float* dKp, float* dVp, int32_t B,
+                    int32_t n, int32_t h, int32_t DP, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused Fourier-type attention (layers.py:672-705):  out = ((Q' K'^T) * scale .* mask) V'  on the head-tile
  * layout [B*n][h][DP], without writing the n x n score matrix: score tiles are scaled, masked (stateless

@@ -1,6 +1,7 @@
 """Kernel-level parity: every C-ABI entry point of libgt_hip.so against a plain torch fp64
 restatement of the same op, on the GPU box.  (-m gpu)"""
 import ctypes
+import os
 import math
 
 import pytest
@@ -725,3 +726,19 @@ def test_drop_act_fused_equals_chain(H, gpu_device, n, p1, a1, p2, a2):
     if p1 > 0:
         kept = (ops.drop_act(torch.ones(n, device=dev), p1, "none") != 0).float().mean().item()
         assert abs(kept - (1 - p1)) < 0.02
+
+
+@pytest.mark.skipif("dkv" not in os.environ.get("GT_TEST_STAGED", ""), reason="staged kernel: set GT_TEST_STAGED=dkv")
+@pytest.mark.parametrize("B,n,h,DP", [(2, 100, 4, 36), (1, 37, 2, 20), (3, 1849, 4, 36), (1, 64, 1, 52)])
+def test_galerkin_dkv_staged(H, gpu_device, B, n, h, DP):
+    """gt_galerkin_dkv against fp64 (and thereby against the two batched GEMMs it would replace)."""
+    dev = gpu_device
+    Kp = rnd(B * n, h, DP, dev=dev, seed=100)
+    Vp = rnd(B * n, h, DP, dev=dev, seed=101)
+    dM = rnd(B, h, DP, DP, dev=dev, seed=102)
+    dK = torch.full_like(Kp, float("nan"))
+    dV = torch.full_like(Kp, float("nan"))
+    H.galerkin_dkv(Kp, Vp, dM, dK, dV, B, n, h, DP)
+    K4, V4 = Kp.reshape(B, n, h, DP).double(), Vp.reshape(B, n, h, DP).double()
+    assert rel_l2(dK.reshape(B, n, h, DP), torch.einsum("bnhk,bhck->bnhc", V4, dM.double())) < KTOL
+    assert rel_l2(dV.reshape(B, n, h, DP), torch.einsum("bnhk,bhkc->bnhc", K4, dM.double())) < KTOL
