@@ -42,6 +42,9 @@ struct GemmP {
     int K2; const float* A2; int64_t lda2, a2_bs0, a2_bs1; const float* B2; int64_t ldb2, b2_bs0, b2_bs1;
     int a2_vec, b2_vec;
     int light_wait;          // streamed kernel: counted vmcnt after full-tile epilogues (see kernel)
+    // GT_EP_HEADNORM: head-norm forward fused behind the QKV projection
+    const float* hn_gamma; const float* hn_beta; const float* hn_pos; float* hn_out; float* hn_stats;
+    int hn_h, hn_dk, hn_p, hn_DP, hn_mask; float hn_eps;
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------
@@ -153,7 +156,45 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 // Fused epilogue shared by both kernels.  The calling lane holds, for each of the MT x NT 16x16
 // accumulator tiles, rows  mw0 + MT*(4*kq + r) + s  (r = 0..3) and columns  nb + t.
-template <int MT, int NT>
+// HN: additionally run the per-head LayerNorm of gt_headnorm_fwd on the (biased) row segments this lane group
+// holds and scatter them into the head-tile layout (GT_EP_HEADNORM; NT == 4, dk/4 lanes per head segment).
+template <int NT>
+__device__ __forceinline__ void headnorm_scatter(const GemmP& p, const float (&v)[NT], int m, int nb) {
+    const int dk = p.hn_dk, G = dk >> 2;
+    const int stream = nb / (p.hn_h * dk), head = (nb / dk) % p.hn_h, dim = nb % dk;
+    const bool normed = (p.hn_mask >> stream) & 1;
+    float y[4] = {v[0], v[1 % NT], v[2 % NT], v[3 % NT]};
+    if (normed) {
+        const int ni = __popc(p.hn_mask & ((1 << stream) - 1));
+        const float inv = 1.f / (float)dk;
+        float sum = (y[0] + y[1]) + (y[2] + y[3]);
+        for (int o = G >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mu = sum * inv;
+        float c[4] = {y[0] - mu, y[1] - mu, y[2] - mu, y[3] - mu};
+        float ss = (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+        for (int o = G >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rstd = 1.f / sqrtf(ss * inv + p.hn_eps);
+        const float* gm = p.hn_gamma + (ni * p.hn_h + head) * dk + dim;
+        const float* bt = p.hn_beta + (ni * p.hn_h + head) * dk + dim;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) y[t] = c[t] * rstd * gm[t] + bt[t];
+        if (dim == 0)
+            *reinterpret_cast<f32x2*>(p.hn_stats + (((int64_t)ni * p.M + m) * p.hn_h + head) * 2) = f32x2{mu, rstd};
+    }
+    float* row = p.hn_out + (((int64_t)stream * p.M + m) * p.hn_h + head) * p.hn_DP;
+    float* dst = row + p.hn_p + dim;
+    if ((p.hn_p & 3) == 0) *reinterpret_cast<f32x4*>(dst) = f32x4{y[0], y[1], y[2], y[3]};
+    else if ((p.hn_p & 1) == 0) {
+        *reinterpret_cast<f32x2*>(dst) = f32x2{y[0], y[1]};
+        *reinterpret_cast<f32x2*>(dst + 2) = f32x2{y[2], y[3]};
+    } else { dst[0] = y[0]; dst[1] = y[1]; dst[2] = y[2]; dst[3] = y[3]; }
+    if (dim == 0)
+        for (int jj = 0; jj < p.hn_p; ++jj) row[jj] = p.hn_pos[(int64_t)m * p.hn_p + jj];
+    if (dim == dk - 4)
+        for (int jj = p.hn_p + dk; jj < p.hn_DP; ++jj) row[jj] = 0.f;
+}
+
+template <int MT, int NT, bool HN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const f32x4 (&acc)[MT][NT], int mw0, int nb,
                                               int z, int b0, int b1, int sidx, int kq) {
         if (nb >= p.N) return;
@@ -269,6 +310,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const f32x4 (&acc)
                 for (int t = 0; t < NT; ++t)
                     if (nb + t < p.N) cp[t] = v[t];
             }
+            if (HN) headnorm_scatter<NT>(p, v, m, nb);     // v = alpha*acc + bias (no other epilogue field is set)
         }
     }
 }
@@ -511,12 +553,13 @@ __global__ __launch_bounds__(WM* WN * 64, ((HEAD == 0 && BK == 16) ? 4 : 1)) voi
         }
     }
 
-    if (HEAD) {
+    if (HEAD > 0) {
         head_epilogue<MT, NT, WM, WN, (HEAD > 0 ? HEAD : 1)>(p, acc, smem, m0, wm, wn, li, kq, tm);
         return;
     }
     // ------------------------------- epilogue -------------------------------------------------
-    gemm_epilogue<MT, NT>(p, acc, m0 + wm * 16 * MT, n0 + wn * 16 * NT + NT * li, z, b0, b1, (int)blockIdx.y, kq);
+    gemm_epilogue<MT, NT, (HEAD < 0)>(p, acc, m0 + wm * 16 * MT, n0 + wn * 16 * NT + NT * li, z, b0, b1,
+                                      (int)blockIdx.y, kq);
 }
 
 // =================================================================================================
@@ -806,6 +849,11 @@ static void launch_head_no(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
         default: hipLaunchKernelGGL((gemm_kernel<0, 0, 2, 1, 4, 1, 16, NO>), grid, dim3(256), 0, st, p); break;
     }
 }
+// QKV projection + head norm (GT_EP_HEADNORM): 128-wide tile columns only (a head segment stays inside a wave)
+static void launch_hn(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
+    if (cfg == 0) hipLaunchKernelGGL((gemm_kernel<0, 0, 4, 4, 2, 2, 16, -1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<0, 0, 2, 4, 2, 2, 16, -1>), grid, dim3(256), 0, st, p);
+}
 static void launch_head(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
     if (p.n_out == 1) launch_head_no<1>(cfg, grid, st, p);
     else launch_head_no<4>(cfg, grid, st, p);
@@ -868,9 +916,11 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     double best = 0.0;
     for (int i = 0; i < kNumCfg; ++i) {
         const int bm = kCfgs[i].wm * 16 * kCfgs[i].mt, bn = kCfgs[i].wn * 16 * kCfgs[i].nt;
-        if (d->ep_mode != GT_EP_NORMAL && bn < d->N) continue;      // the fused head needs whole rows per block
+        const bool head_ep = d->ep_mode == GT_EP_ROWDOT || d->ep_mode == GT_EP_MLP_BWD;
+        if (head_ep && bn < d->N) continue;                         // the fused head needs whole rows per block
         // the 128x128 head instance needs > 256 registers (one block per CU): the 64x128 one runs two
-        if (d->ep_mode != GT_EP_NORMAL && i == 0 && d->N <= 128) continue;
+        if (head_ep && i == 0 && d->N <= 128) continue;
+        if (d->ep_mode == GT_EP_HEADNORM && i > 1) continue;         // head segments must stay inside a wave tile
         const double tiles = (double)ceil_div(d->M, bm) * ceil_div(d->N, bn) * (double)batch;
         // under-filled grids: with split-K available the K-slices fill the chip (time ~ total padded work),
         // otherwise every block has a CU to itself (time ~ one tile)
@@ -973,7 +1023,8 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
         snprintf(buf, n, "void gt::gemm_stream_kernel<%d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b, c.mt);
     else
         snprintf(buf, n, "void gt::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b,
-                 c.mt, c.nt, c.wm, c.wn, pl.bk, d->ep_mode == GT_EP_NORMAL ? 0 : (d->n_out == 1 ? 1 : 4));
+                 c.mt, c.nt, c.wm, c.wn, pl.bk,
+                 d->ep_mode == GT_EP_NORMAL ? 0 : (d->ep_mode == GT_EP_HEADNORM ? -1 : (d->n_out == 1 ? 1 : 4)));
     return 0;
 }
 
@@ -992,7 +1043,17 @@ extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
 static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int64_t ws_bytes, void* stream) {
     if (!d || !d->A || !d->B) return GT_EINVAL;
     if (!d->C && d->ep_mode != GT_EP_ROWDOT) return GT_EINVAL;
-    if (d->ep_mode != GT_EP_NORMAL) {
+    if (d->ep_mode == GT_EP_HEADNORM) {
+        if (d->layout_a || d->layout_b || d->batch0 * d->batch1 != 1 || d->K2 > 0) return GT_ENOTSUP;
+        if (d->hn_dk != 16 && d->hn_dk != 32 && d->hn_dk != 64) return GT_ENOTSUP;
+        if (d->hn_h <= 0 || d->hn_p < 0 || d->N != 3 * d->hn_h * d->hn_dk || (d->hn_norm_mask & ~7)) return GT_EINVAL;
+        if (!d->hn_out || (d->hn_p > 0 && !d->hn_pos)) return GT_EINVAL;
+        if (d->hn_norm_mask && (!d->hn_gamma || !d->hn_beta || !d->hn_stats)) return GT_EINVAL;
+        if (d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res || d->out_scale != 1.f ||
+            d->a_drop.p > 0.f || d->a_colsum)
+            return GT_ENOTSUP;
+        if ((reinterpret_cast<uintptr_t>(d->hn_out) | reinterpret_cast<uintptr_t>(d->hn_stats)) & 15) return GT_EALIGN;
+    } else if (d->ep_mode != GT_EP_NORMAL) {
         if (d->ep_mode != GT_EP_ROWDOT && d->ep_mode != GT_EP_MLP_BWD) return GT_EINVAL;
         if (d->N > 128 || d->batch0 * d->batch1 != 1 || d->n_out < 1 || d->n_out > 4 || !d->w2) return GT_ENOTSUP;
         if (d->ep_mode == GT_EP_ROWDOT && !d->out2) return GT_EINVAL;
@@ -1035,7 +1096,13 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     const int64_t mn = (int64_t)d->M * d->N;
     float* dw2_partial = nullptr;
     const int dw2_slabs = pl.tiles_m * kCfgs[pl.cfg].wm;
-    if (d->ep_mode != GT_EP_NORMAL) {
+    if (d->ep_mode == GT_EP_HEADNORM) {
+        if (pl.split != 1 || pl.cfg > 1) return GT_ENOTSUP;
+        p.ep_mode = d->ep_mode;
+        p.hn_gamma = d->hn_gamma; p.hn_beta = d->hn_beta; p.hn_pos = d->hn_pos; p.hn_out = d->hn_out;
+        p.hn_stats = d->hn_stats; p.hn_h = d->hn_h; p.hn_dk = d->hn_dk; p.hn_p = d->hn_p;
+        p.hn_DP = (d->hn_dk + d->hn_p + 3) & ~3; p.hn_mask = d->hn_norm_mask; p.hn_eps = d->hn_eps;
+    } else if (d->ep_mode != GT_EP_NORMAL) {
         if (pl.tiles_n != 1 || pl.split != 1) return GT_ENOTSUP;
         p.ep_mode = d->ep_mode; p.n_out = d->n_out; p.w2 = d->w2; p.ldw2 = d->ldw2; p.b2 = d->b2;
         p.out2 = d->out2; p.g2 = d->g2;
@@ -1093,7 +1160,9 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
 
     dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split, (unsigned)batch);
     const int lay = d->layout_a * 2 + d->layout_b;
-    if (d->ep_mode != GT_EP_NORMAL) {
+    if (d->ep_mode == GT_EP_HEADNORM) {
+        launch_hn(pl.cfg, grid, st, p);
+    } else if (d->ep_mode != GT_EP_NORMAL) {
         if (lay != 0) return GT_ENOTSUP;
         launch_head(pl.cfg, grid, st, p);
     } else if (pl.stream) {

@@ -485,8 +485,16 @@ class SimpleAttentionFn(Function):
         wq, wf = _c(wqkv), _c(wfc)
         salt = _next_salt(4)
         qkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
-        H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
-        out3, stats = H.headnorm_fwd(qkv, posc, gamma, beta, T, h, dk, p, norm_mask, eps)
+        if "qkvnorm" in H.STAGED and dk in (16, 32, 64):
+            # staged: the head norm rides on the projection's epilogue (GT_EP_HEADNORM), one pass less over [T, 3d]
+            out3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
+            stats = torch.empty(2, T, h, 2, dtype=torch.float32, device=dev)
+            H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv,
+                   hn=dict(gamma=gamma, beta=beta, pos=posc, out=out3, stats=stats, h=h, dk=dk, p=p,
+                           norm_mask=norm_mask, eps=eps))
+        else:
+            H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
+            out3, stats = H.headnorm_fwd(qkv, posc, gamma, beta, T, h, dk, p, norm_mask, eps)
         Qp, Kp, Vp = out3[0], out3[1], out3[2]
         hD = h * DP
         out = torch.empty(T, d, dtype=torch.float32, device=dev)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 5
+#define GT_ABI_VERSION 6
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -150,11 +150,23 @@ typedef struct gt_gemm_desc {
     int32_t K2;
     const float* A2; int64_t lda2, a2_bs0, a2_bs1;
     const float* B2; int64_t ldb2, b2_bs0, b2_bs1;
+
+    /* GT_EP_HEADNORM (STAGED, opt-in via GT_STAGED=qkvnorm in the Python mirror): the packed QKV projection
+     * (layers.py:838-840) with the per-head LayerNorm + position columns of gt_headnorm_fwd fused behind it
+     * (layers.py:841-874).  C [M, N = 3*h*dk] is written as usual (the backward reads the raw projection) and
+     * in the same pass every row's head segments go to hn_out [3][M][h][DP] (normalised where hn_norm_mask
+     * says so, coordinates in columns [0, hn_p), zero pad) and hn_stats [#normed][M][h][2] = (mean, rstd).
+     * dk in {16, 32, 64}, layout_a = layout_b = 0, no batching, no split-K, no other epilogue field but bias. */
+    const float* hn_gamma; const float* hn_beta; const float* hn_pos;
+    float* hn_out; float* hn_stats;
+    int32_t hn_h, hn_dk, hn_p, hn_norm_mask;
+    float hn_eps;
 } gt_gemm_desc;
 
 #define GT_EP_NORMAL  0
 #define GT_EP_ROWDOT  1
 #define GT_EP_MLP_BWD 2
+#define GT_EP_HEADNORM 3
 
 void    gt_gemm_desc_init(gt_gemm_desc* d);            /* zero + alpha=1, out_scale=1, batch=1 */
 int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d);

@@ -742,3 +742,34 @@ def test_galerkin_dkv_staged(H, gpu_device, B, n, h, DP):
     K4, V4 = Kp.reshape(B, n, h, DP).double(), Vp.reshape(B, n, h, DP).double()
     assert rel_l2(dK.reshape(B, n, h, DP), torch.einsum("bnhk,bhck->bnhc", V4, dM.double())) < KTOL
     assert rel_l2(dV.reshape(B, n, h, DP), torch.einsum("bnhk,bhkc->bnhc", K4, dM.double())) < KTOL
+
+
+@pytest.mark.skipif("qkvnorm" not in os.environ.get("GT_TEST_STAGED", ""), reason="staged kernel: set GT_TEST_STAGED=qkvnorm")
+@pytest.mark.parametrize("T,h,dk,p,mask", [(1000, 4, 32, 2, 0b110), (333, 2, 64, 1, 0b011), (4099, 8, 16, 2, 0b110),
+                                           (257, 4, 32, 0, 0b000)])
+def test_qkv_headnorm_epilogue_staged(H, gpu_device, T, h, dk, p, mask):
+    """GT_EP_HEADNORM: projection + per-head LayerNorm in one launch == gt_gemm followed by gt_headnorm_fwd."""
+    dev = gpu_device
+    d = h * dk
+    x = rnd(T, d, dev=dev, seed=110)
+    w = rnd(3 * d, d, dev=dev, seed=111, scale=0.2)
+    b = rnd(3 * d, dev=dev, seed=112)
+    gamma = 1 + 0.1 * rnd(2, h, dk, dev=dev, seed=113)
+    beta = 0.1 * rnd(2, h, dk, dev=dev, seed=114)
+    pos = rnd(T, p, dev=dev, seed=115) if p else None
+    eps = 1e-7
+    qkv = torch.empty(T, 3 * d, device=dev)
+    H.gemm(x, w, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b)
+    out_ref, st_ref = H.headnorm_fwd(qkv, pos, gamma, beta, T, h, dk, p, mask, eps)
+    DP = H.round4(dk + p)
+    qkv2 = torch.full_like(qkv, float("nan"))
+    out3 = torch.full((3, T, h, DP), float("nan"), device=dev)
+    stats = torch.zeros(2, T, h, 2, device=dev)
+    H.gemm(x, w, qkv2, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b,
+           hn=dict(gamma=gamma, beta=beta, pos=pos, out=out3, stats=stats, h=h, dk=dk, p=p, norm_mask=mask, eps=eps))
+    torch.cuda.synchronize()
+    assert torch.equal(qkv2, qkv)
+    assert rel_l2(out3, out_ref) < 1e-6
+    nn = bin(mask).count("1")
+    if nn:
+        assert rel_l2(stats[:nn], st_ref[:nn]) < 1e-6
