@@ -171,3 +171,26 @@ def test_synthetic_datasets_and_losses_cpu():
     t = it["target"][None, :, 0]
     l, r, o, m = l1(t * 0.9, t, targets_prime=it["target_grad"][None, :, 0])
     assert abs(float(l) - 0.1) < 1e-5
+
+
+def test_gemm_desc_layout_matches_header(tmp_path):
+    """The ctypes mirror of struct gt_gemm_desc has the size and field offsets the C header gives it (a silent
+    mismatch would let gt_gemm_desc_init write past the Python-side struct)."""
+    import ctypes
+    import shutil
+    import subprocess
+    from galerkin_transformer import _hip
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    fields = [name for name, _ in _hip.GtGemmDesc._fields_ if name not in ("a_drop", "drop")]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    body = "".join(f'printf("{f} %zu\\n", offsetof(gt_gemm_desc, {f}));\n' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gt_hip.h"\nint main(void) {\n'
+                   'printf("sizeof %zu\\n", sizeof(gt_gemm_desc));\n' + body + "return 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(got["sizeof"]) == ctypes.sizeof(_hip.GtGemmDesc)
+    for f in fields:
+        assert int(got[f]) == getattr(_hip.GtGemmDesc, f).offset, f
