@@ -131,3 +131,112 @@ def test_headnorm_epilogue_lane_map(h, dk, pp, mask):
         ref[st, :, :, :pp] = pos[:, None, :pp]
     assert not np.isnan(out).any()
     assert np.allclose(out, ref, atol=1e-10)
+
+
+@pytest.mark.parametrize("MP,N,K", [(1, 2, 37), (1, 32, 64), (4, 32, 23)])
+def test_tsmm_lane_map(MP, N, K):
+    """tsmm_kernel (gt_tsmm.hip): one float2 per lane feeds an even-column and an odd-column tile."""
+    M = 32 * MP
+    rng = np.random.default_rng(MP + N)
+    A, B = rng.standard_normal((K, M)), rng.standard_normal((K, N))
+    i, kq = S.X, S.KQ
+    acc = [[np.zeros((64, 4)) for _ in range(2)] for _ in range(2 * MP)]
+    cs = np.zeros((MP, 2, 64))
+    for k in range(0, K, 4):
+        ok = k + kq < K
+        row = np.minimum(k + kq, K - 1)
+        b2 = np.zeros((64, 2))
+        for f in range(2):
+            col = 2 * i + f
+            b2[:, f] = np.where(ok & (2 * i < N), B[row, np.minimum(col, N - 1)], 0.0)
+        for mp in range(MP):
+            a2 = np.stack([np.where(ok, A[row, 32 * mp + 2 * i + e], 0.0) for e in range(2)], 1)
+            cs[mp] += a2.T
+            for e in range(2):
+                for f in range(2):
+                    acc[2 * mp + e][f] = S.mfma(a2[:, e], b2[:, f], acc[2 * mp + e][f])
+    C = np.full((M, N), np.nan)
+    colsum = np.zeros(M)
+    for l in range(64):
+        for mp in range(MP):
+            for e in range(2):
+                if kq[l] == 0:
+                    colsum[32 * mp + 2 * i[l] + e] = sum(cs[mp, e, i[l] + 16 * q] for q in range(4))
+                for f in range(2):
+                    for r in range(4):
+                        m, n = 32 * mp + 2 * (4 * kq[l] + r) + e, 2 * i[l] + f
+                        if n < N:
+                            C[m, n] = acc[2 * mp + e][f][l, r]
+    assert np.allclose(C, A.T @ B, atol=1e-10)
+    assert np.allclose(colsum, A.sum(0), atol=1e-10)
+
+
+@pytest.mark.parametrize("T", [16, 29])
+def test_head_backward_lane_map(T):
+    """head_bwd_kernel (gt_head.hip), one 16-row tile of one wave pair: H^T = W1 X^T with k = 8kq + s, the
+    register-s trick for dX^T = W1^T dh^T, the LDS-staged dh for dW1 += dh^T X, and the pair's dX exchange."""
+    HK, HN = 32, 128
+    rng = np.random.default_rng(T)
+    X, W1 = rng.standard_normal((T, HK)), rng.standard_normal((HN, HK)) * 0.3
+    b1, w2, g = rng.standard_normal(HN), rng.standard_normal(HN), rng.standard_normal(T)
+    j, kq = S.X, S.KQ
+    dX = np.full((T, HK), np.nan)
+    dW1, dw2, db1 = np.zeros((HN, HK)), np.zeros(HN), np.zeros(HN)
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    for m0 in range(0, T, 16):
+        row = np.minimum(m0 + j, T - 1)
+        gv = np.where(m0 + j < T, g[row], 0.0)
+        xs = X[row[:, None], (8 * kq)[:, None] + np.arange(8)]                  # the lane's two float4
+        partial = {}
+        for half in range(2):                                                    # the two waves of the pair
+            hb = 64 * half
+            acc = []
+            for mt in range(4):
+                a = np.zeros((64, 4))
+                for s in range(8):
+                    a = S.mfma(W1[hb + 16 * mt + j, 8 * kq + s], xs[:, s], a)
+                acc.append(a)
+            dh_lds = np.zeros((16, 64))
+            for mt in range(4):
+                hid = hb + 16 * mt + 4 * kq[:, None] + np.arange(4)             # [64, 4]
+                hpre = acc[mt] + b1[hid]
+                sg = sig(hpre)
+                a_, da = hpre * sg, sg * (1 + hpre * (1 - sg))
+                d = gv[:, None] * w2[hid] * da
+                for l in range(64):
+                    dw2[hid[l]] += gv[l] * a_[l]
+                    db1[hid[l]] += d[l]
+                    dh_lds[j[l], 16 * mt + 4 * kq[l]:16 * mt + 4 * kq[l] + 4] = d[l]
+                acc[mt] = d
+            accX = [np.zeros((64, 4)), np.zeros((64, 4))]
+            for mt in range(4):
+                for s in range(4):
+                    for t in range(2):
+                        accX[t] = S.mfma(W1[hb + 16 * mt + 4 * kq + s, 16 * t + j], acc[mt][:, s], accX[t])
+            partial[half] = accX
+            accW = [[np.zeros((64, 4)) for _ in range(2)] for _ in range(4)]
+            for mt in range(4):
+                for s in range(4):
+                    a = dh_lds[4 * kq + s, 16 * mt + j]
+                    for t in range(2):
+                        xr = X[np.minimum(m0 + 4 * kq + s, T - 1), 16 * t + j]
+                        accW[mt][t] = S.mfma(a, xr, accW[mt][t])
+            for l in range(64):
+                for mt in range(4):
+                    for t in range(2):
+                        for r in range(4):
+                            dW1[hb + 16 * mt + 4 * kq[l] + r, 16 * t + j[l]] += accW[mt][t][l, r]
+        for half in range(2):                                                    # each wave stores its own t = half
+            tot = partial[half][half] + partial[half ^ 1][half]
+            for l in range(64):
+                if m0 + j[l] < T:
+                    dX[m0 + j[l], 16 * half + 4 * kq[l]:16 * half + 4 * kq[l] + 4] = tot[l]
+    # the row lanes hold duplicates of dw2 / db1 contributions per kq group: the kernel sums over the 16 j lanes of
+    # ONE kq group per hidden value; here every lane added its own row's term exactly once, which is the same sum
+    H = X @ W1.T + b1
+    sg = sig(H)
+    dh = g[:, None] * w2[None, :] * (sg * (1 + H * (1 - sg)))
+    assert np.allclose(dX, dh @ W1, atol=1e-9)
+    assert np.allclose(dW1, dh.T @ X, atol=1e-9)
+    assert np.allclose(db1, dh.sum(0), atol=1e-9)
+    assert np.allclose(dw2, (g[:, None] * H * sg).sum(0), atol=1e-9)
