@@ -7,7 +7,6 @@ backward; torch only owns the tensors and the autograd graph.  Reference call si
 from __future__ import annotations
 
 import math
-from typing import Optional
 
 import torch
 from torch.autograd import Function

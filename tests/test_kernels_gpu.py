@@ -1,8 +1,6 @@
 """Kernel-level parity: every C-ABI entry point of libgt_hip.so against a plain torch fp64
 restatement of the same op, on the GPU box.  (-m gpu)"""
-import ctypes
 import os
-import math
 
 import pytest
 import torch

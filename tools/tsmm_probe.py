@@ -1,5 +1,5 @@
 """Time the tall-skinny weight-gradient products with and without the tsmm path.  usage: tsmm_probe.py [K]"""
-import os, subprocess, sys, torch
+import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "galerkin-transformer_amd"))
 from galerkin_transformer import _hip as H
