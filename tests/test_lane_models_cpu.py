@@ -240,3 +240,80 @@ def test_head_backward_lane_map(T):
     assert np.allclose(dW1, dh.T @ X, atol=1e-9)
     assert np.allclose(db1, dh.sum(0), atol=1e-9)
     assert np.allclose(dw2, (g[:, None] * H * sg).sum(0), atol=1e-9)
+
+
+@pytest.mark.parametrize("KS,n", [(9, 50), (5, 64)])
+def test_fourier_core_lane_map(KS, n):
+    """fourier_core_kernel (gt_fourier.hip), one wave, one 64-row stream tile: S^T tile = T1 F1^T, then the second
+    product reads register s of the score tile as its k-step s (stream row 16mt + 4kq + s), last 4 columns on
+    the VALU with a kq reduction."""
+    DP, NF, XC = 4 * KS, (4 * KS - 4) // 16, 4 * KS - 4
+    rng = np.random.default_rng(KS)
+    F1 = rng.standard_normal((32, DP))                 # 32 owner rows of the wave
+    T1, T2 = rng.standard_normal((n, DP)), rng.standard_normal((n, DP))
+    j, kq = S.X, S.KQ
+    f1 = [[F1[16 * nt + j, 4 * s + kq] for s in range(KS)] for nt in range(2)]
+    acc1 = [[np.zeros((64, 4)) for _ in range(2)] for _ in range(NF)]
+    ax = np.zeros((2, 64, 4))
+    for s0 in range(0, n, 64):
+        t1 = np.zeros((64, DP)); t2 = np.zeros((64, DP))
+        rows = min(64, n - s0)
+        t1[:rows], t2[:rows] = T1[s0:s0 + rows], T2[s0:s0 + rows]
+        sa = [[np.zeros((64, 4)) for _ in range(2)] for _ in range(4)]
+        for s in range(KS):
+            for mt in range(4):
+                a1 = t1[16 * mt + j, 4 * s + kq]
+                for nt in range(2):
+                    sa[mt][nt] = S.mfma(a1, f1[nt][s], sa[mt][nt])
+        for mt in range(4):
+            for s in range(4):
+                row = 16 * mt + 4 * kq + s
+                for dt in range(NF):
+                    a = t2[row, 16 * dt + j]
+                    for nt in range(2):
+                        acc1[dt][nt] = S.mfma(a, sa[mt][nt][:, s], acc1[dt][nt])
+                x1 = t2[row, XC:XC + 4]
+                for nt in range(2):
+                    ax[nt] += sa[mt][nt][:, s][:, None] * x1
+    O = np.full((32, DP), np.nan)
+    for l in range(64):
+        for nt in range(2):
+            ow = 16 * nt + j[l]
+            for dt in range(NF):
+                O[ow, 16 * dt + 4 * kq[l]:16 * dt + 4 * kq[l] + 4] = acc1[dt][nt][l]
+            if kq[l] == 0:
+                O[ow, XC:XC + 4] = sum(ax[nt][j[l] + 16 * q] for q in range(4))
+    assert np.allclose(O, (F1 @ T1.T) @ T2, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,P", [(141, 24), (30, 8)])
+def test_dft_analysis_lane_map(n, P):
+    """dft_analysis_kernel (gt_dft.hip): the line slab lands in LDS with granule q of row r holding logical granule
+    q ^ (((r >> 1) & 1) << 2); wave (mt, nt) computes one 16 x 16 tile of Y = F^T X with two accumulators."""
+    C = 32
+    KMAX = 16 if n <= 64 else (36 if n <= 144 else 56)
+    rng = np.random.default_rng(n)
+    F, X = rng.standard_normal((n, P)), rng.standard_normal((n, C))
+    nrow = 4 * KMAX + 16
+    lds = np.zeros((nrow, C))
+    for r in range(n):                                   # direct-load image: linear granule e = 8r + q
+        for q in range(8):
+            g = q ^ (((r >> 1) & 1) << 2)
+            lds[r, 4 * q:4 * q + 4] = X[r, 4 * g:4 * g + 4]
+    flat = lds.reshape(-1)
+    j, kq = S.X, S.KQ
+    Y = np.full((P, C), np.nan)
+    for wave in range(4):
+        mt, nt = wave >> 1, wave & 1
+        pr = np.minimum(16 * mt + j, P - 1)
+        fa = [np.where(4 * s + kq < n, F[np.minimum(4 * s + kq, n - 1), pr], 0.0) for s in range(KMAX)]
+        slot = (4 * nt + (j >> 2)) ^ (((kq >> 1) & 1) << 2)
+        boff = kq * C + slot * 4 + (j & 3)
+        acc = [np.zeros((64, 4)), np.zeros((64, 4))]
+        for s in range(KMAX):
+            acc[s & 1] = S.mfma(fa[s], flat[boff + 4 * s * C], acc[s & 1])
+        for l in range(64):
+            for r in range(4):
+                prr = min(16 * mt + 4 * kq[l] + r, P - 1)
+                Y[prr, 16 * nt + j[l]] = acc[0][l, r] + acc[1][l, r]
+    assert np.allclose(Y, F.T @ X, atol=1e-9)
