@@ -823,6 +823,89 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit
     }
 }
 
+// =================================================================================================
+// Weight-stationary kernel for the K = 128 token GEMMs (QKV, FFN1 and the FFN2 input gradient) -- STAGED behind
+// GT_STAGED=wsgemm, not yet run on hardware.  The v1 kernel spends a K = 128 tile as load -> 8 short stages ->
+// store with every co-resident block in the same phase (49-55 % of the fp32 MFMA peak).  Here a persistent
+// block keeps its 64-column slice of B (64 x 128 floats, 32 KB) in LDS for its whole life and only streams
+// 32-row A tiles (16 KB, double-buffered, direct global->LDS): one barrier and no B traffic per tile, the
+// epilogue's stores drain under the next tile's MFMAs (counted vmcnt), the next A tile is already in flight.
+//
+// Both LDS images are [row][128] in 16-byte granules with granule g of row r stored at slot g ^ (r & 7); a lane
+// (x = row or column, kq) reads the granules 4*g8 + kq, g8 = 0..7, as one ds_read_b128 each and uses component c
+// as the operand of k-step (g8, c), i.e. k = 16 g8 + 4 kq + c on both operands: 8 MFMAs per 3 LDS reads.
+// Row / column assignment follows gemm_epilogue's convention (MT = 1, NT = 2), so every fused epilogue works.
+// XCD-aware persistent grid: the N/64 slice blocks that share an A row panel get the same block id mod 8.
+constexpr int WS_BM = 32, WS_BN = 64, WS_K = 128;
+template <int LB>
+__global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) float sB[WS_BN * WS_K];
+    __shared__ __attribute__((aligned(16))) float sA[2][WS_BM * WS_K];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    // block -> (slice, y group): blocks L, L+8, L+16, ... of one XCD walk the slices of one y group first
+    const int slices = p.N / WS_BN, per_xcd = (int)gridDim.x / (8 * slices);
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int slice = q % slices, ygrp = (q / slices) * 8 + xcd, ygroups = per_xcd * 8;
+    const int n0 = slice * WS_BN;
+    const int mtiles = (p.M + WS_BM - 1) / WS_BM;
+
+    auto issue = [&](int tile, int buf) {                 // A tile: 16 chunks of 1 KiB, 4 per wave
+        const int m0 = tile * WS_BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = wave * 4 + i, e = ch * 64 + lane;
+            const int r = e >> 5, g = (e & 31) ^ (r & 7);
+            const float* src = (m0 + r < p.M) ? p.A + (int64_t)(m0 + r) * p.lda + 4 * g : gt_zero16;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(&sA[buf][ch * 256]), 16, 0, 0);
+        }
+    };
+    int tile = ygrp;
+    if (tile < mtiles) issue(tile, 0);
+    // B slice, once: image [n][128], granule g of column n at slot g ^ (n & 7)
+    if (LB == 0) {
+        for (int e = tid; e < WS_BN * 32; e += 256) {
+            const int n = e >> 5, g = (e & 31) ^ (n & 7);
+            *reinterpret_cast<f32x4*>(&sB[e * 4]) = *reinterpret_cast<const f32x4*>(p.B + (int64_t)(n0 + n) * p.ldb + 4 * g);
+        }
+    } else {
+        for (int e = tid; e < WS_BN * WS_K; e += 256) {
+            const int k = e / WS_BN, n = e - k * WS_BN;    // coalesced along n
+            sB[(n * 32 + ((k >> 2) ^ (n & 7))) * 4 + (k & 3)] = p.B[(int64_t)k * p.ldb + n0 + n];
+        }
+    }
+    const int arow = wm * 16 + li;                         // A operand row of this lane (MT = 1)
+    const int bcol = wn * 32 + 2 * li;                     // B operand columns bcol, bcol + 1 (NT = 2)
+    int buf = 0, stores_prev = -1;
+    for (; tile < mtiles; tile += ygroups, buf ^= 1) {
+        // tile's A has landed for this wave (older than the previous tile's stores, which may still drain)
+        if (stores_prev == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (tile + ygroups < mtiles) issue(tile + ygroups, buf ^ 1);
+        const float* a_img = sA[buf];
+        f32x4 acc[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) {
+            const int G = 4 * g8 + kq;
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&a_img[(arow * 32 + (G ^ (arow & 7))) * 4]);
+            const f32x4 b40 = *reinterpret_cast<const f32x4*>(&sB[(bcol * 32 + (G ^ (bcol & 7))) * 4]);
+            const f32x4 b41 = *reinterpret_cast<const f32x4*>(&sB[((bcol + 1) * 32 + (G ^ ((bcol + 1) & 7))) * 4]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[0][0] = mfma16(a4[c], b40[c], acc[0][0]);
+                acc[0][1] = mfma16(a4[c], b41[c], acc[0][1]);
+            }
+        }
+        const int m0 = tile * WS_BM;
+        gemm_epilogue<1, 2>(p, acc, m0 + wm * 16, n0 + wn * 32 + 2 * li, 0, 0, 0, 0, kq);
+        // a full, aligned tile whose epilogue reads nothing but the bias issues exactly 4 float2 stores after the
+        // prefetch (the bias loads have been consumed by then): allowing 4 outstanding operations is safe
+        stores_prev = (m0 + WS_BM <= p.M && p.c_vec && !p.pre && !p.res && !p.add && !p.aux_op && !p.rp) ? 4 : 0;
+    }
+}
+
 struct Cfg { int mt, nt, wm, wn; };
 static const Cfg kCfgs[] = {{4, 4, 2, 2}, {2, 4, 2, 2}, {2, 2, 2, 2}, {2, 2, 4, 1}, {2, 1, 4, 1}};
 constexpr int kNumCfg = 5;
@@ -894,7 +977,7 @@ static void launch_stream(hipStream_t st, const GemmP& p) {
     hipLaunchKernelGGL((gemm_stream_kernel<LA, LB, MT>), dim3(nblk), dim3(256), 0, st, q);
 }
 
-struct Plan { int cfg, bm, bn, bk, tiles_m, tiles_n, split, k_chunk, stream; };
+struct Plan { int cfg, bm, bn, bk, tiles_m, tiles_n, split, k_chunk, stream, ws; };
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool m4(int64_t v) { return (v & 3) == 0; }
@@ -902,6 +985,26 @@ static inline bool m4(int64_t v) { return (v & 3) == 0; }
 static bool has_epilogue(const gt_gemm_desc* d) {
     return d->bias || d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res ||
            d->out_scale != 1.f || d->ep_mode != GT_EP_NORMAL || d->K2 > 0;
+}
+
+static bool staged(const char* what) {
+    const char* e = getenv("GT_STAGED");
+    return e && strstr(e, what) != nullptr;
+}
+static int ws_blocks(const gt_gemm_desc* d) {
+    const int slices = d->N / WS_BN;
+    return 8 * std::max(1, 64 / slices) * slices;
+}
+// weight-stationary K = 128 kernel (staged): token GEMMs with a k-contiguous A, whole 64-column slices
+static bool ws_eligible(const gt_gemm_desc* d) {
+    static const bool on = staged("wsgemm");
+    if (!on || d->K != WS_K || d->layout_a != 0 || d->batch0 * d->batch1 != 1 || d->split_k > 1) return false;
+    if (d->N % WS_BN || d->N / WS_BN > 64 || d->ep_mode != GT_EP_NORMAL || d->K2 > 0) return false;
+    if (d->a_drop.p > 0.f || d->a_colsum) return false;
+    if (!al16(d->A) || !m4(d->lda)) return false;
+    if (d->layout_b == 0 && (!al16(d->B) || !m4(d->ldb))) return false;
+    const int slices = d->N / WS_BN, ygroups = 8 * std::max(1, 64 / slices);
+    return ceil_div(d->M, WS_BM) >= ygroups;
 }
 
 static int make_plan(const gt_gemm_desc* d, Plan* pl) {
@@ -971,6 +1074,8 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     split = std::max(1, ceil_div(std::max(d->K, 1), chunk));
     pl->split = split;
     pl->k_chunk = chunk;
+    pl->ws = ws_eligible(d) ? 1 : 0;
+    if (pl->ws) { pl->split = 1; pl->stream = 0; pl->k_chunk = WS_K; }
     return 0;
 }
 
@@ -1019,7 +1124,9 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
     int rc = make_plan(d, &pl);
     if (rc) return rc;
     const Cfg& c = kCfgs[pl.cfg];
-    if (pl.stream)
+    if (pl.ws)
+        snprintf(buf, n, "void gt::gemm_ws_kernel<%d>(gt::GemmP)", d->layout_b);
+    else if (pl.stream)
         snprintf(buf, n, "void gt::gemm_stream_kernel<%d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b, c.mt);
     else
         snprintf(buf, n, "void gt::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b,
@@ -1160,7 +1267,10 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
 
     dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split, (unsigned)batch);
     const int lay = d->layout_a * 2 + d->layout_b;
-    if (d->ep_mode == GT_EP_HEADNORM) {
+    if (pl.ws) {
+        if (d->layout_b == 0) hipLaunchKernelGGL((gemm_ws_kernel<0>), dim3(ws_blocks(d)), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_ws_kernel<1>), dim3(ws_blocks(d)), dim3(256), 0, st, p);
+    } else if (d->ep_mode == GT_EP_HEADNORM) {
         launch_hn(pl.cfg, grid, st, p);
     } else if (d->ep_mode != GT_EP_NORMAL) {
         if (lay != 0) return GT_ENOTSUP;

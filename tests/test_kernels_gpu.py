@@ -771,3 +771,37 @@ def test_qkv_headnorm_epilogue_staged(H, gpu_device, T, h, dk, p, mask):
     nn = bin(mask).count("1")
     if nn:
         assert rel_l2(stats[:nn], st_ref[:nn]) < 1e-6
+
+
+@pytest.mark.skipif("wsgemm" not in os.environ.get("GT_TEST_STAGED", "") or "wsgemm" not in os.environ.get("GT_STAGED", ""),
+                    reason="staged kernel: run with GT_STAGED=wsgemm GT_TEST_STAGED=wsgemm")
+@pytest.mark.parametrize("lb,M,N,ep", [(0, 8192 + 40, 384, "bias"), (0, 4096, 256, "relu_drop"), (1, 5000, 256, "plain"),
+                                       (0, 3000, 128, "res")])
+def test_gemm_ws_staged(H, gpu_device, lb, M, N, ep):
+    """gemm_ws_kernel (weight-stationary K = 128) against fp64, with the epilogues the token GEMMs use."""
+    dev = gpu_device
+    K = 128
+    A = rnd(M, K, dev=dev, seed=120)
+    Bm = rnd(N, K, dev=dev, seed=121, scale=0.2) if lb == 0 else rnd(K, N, dev=dev, seed=121, scale=0.2)
+    assert "gemm_ws_kernel" in H.gemm_kernel_name(A, Bm, M, N, K, layout_b=lb, lda=K, ldb=(K if lb == 0 else N), ldc=N)
+    Cc = torch.full((M, N), float("nan"), device=dev)
+    ref = A.double() @ (Bm.double().t() if lb == 0 else Bm.double())
+    kw = {}
+    if ep == "bias":
+        b = rnd(N, dev=dev, seed=122)
+        kw["bias"] = b
+        ref = ref + b.double()
+    elif ep == "relu_drop":
+        H.set_seed(5, dev)
+        d = H.dropout_desc(0.1, 3, dev)
+        b = rnd(N, dev=dev, seed=122)
+        kw.update(bias=b, act=H.ACT_RELU, drop=d)
+        mask = H.dropout_apply(torch.ones(M * N, device=dev), d).reshape(M, N).double()
+        ref = torch.relu(ref + b.double()) * mask
+    elif ep == "res":
+        r = rnd(M, N, dev=dev, seed=123)
+        kw.update(res=r, ldr=N)
+        ref = ref + r.double()
+    H.gemm(A, Bm, Cc, M, N, K, layout_b=lb, lda=K, ldb=(K if lb == 0 else N), ldc=N, **kw)
+    torch.cuda.synchronize()
+    assert rel_l2(Cc, ref) < KTOL

@@ -317,3 +317,73 @@ def test_dft_analysis_lane_map(n, P):
                 prr = min(16 * mt + 4 * kq[l] + r, P - 1)
                 Y[prr, 16 * nt + j[l]] = acc[0][l, r] + acc[1][l, r]
     assert np.allclose(Y, F.T @ X, atol=1e-9)
+
+
+@pytest.mark.parametrize("LB,M,N", [(0, 96, 128), (1, 70, 64)])
+def test_gemm_ws_lane_map(LB, M, N):
+    """gemm_ws_kernel (gt_gemm.hip, staged): swizzled [row][128] LDS images, k = 16 g8 + 4 kq + c on both operands,
+    row/column assignment of gemm_epilogue<1, 2> (rows mw0 + 4kq + r, columns nb + t with nb = n0 + 32 wn + 2 li)."""
+    K = 128
+    rng = np.random.default_rng(LB + M)
+    A = rng.standard_normal((M, K))
+    Bm = rng.standard_normal((N, K)) if LB == 0 else rng.standard_normal((K, N))    # B(k, n)
+    Bkn = Bm.T if LB == 0 else Bm
+    li, kq = S.X, S.KQ
+    C = np.full((M, N), np.nan)
+    for slice_ in range(N // 64):
+        n0 = slice_ * 64
+        sB = np.zeros(64 * 128)
+        if LB == 0:
+            for e in range(64 * 32):
+                n, g = e >> 5, (e & 31) ^ ((e >> 5) & 7)
+                sB[4 * e:4 * e + 4] = Bm[n0 + n, 4 * g:4 * g + 4]
+        else:
+            for e in range(64 * 128):
+                k, n = e // 64, e % 64
+                sB[(n * 32 + ((k >> 2) ^ (n & 7))) * 4 + (k & 3)] = Bm[k, n0 + n]
+        for tile in range((M + 31) // 32):
+            m0 = tile * 32
+            sA = np.zeros(32 * 128)
+            for e in range(1024):                         # direct-load image, zero16 beyond M
+                r, g = e >> 5, (e & 31) ^ ((e >> 5) & 7)
+                if m0 + r < M:
+                    sA[4 * e:4 * e + 4] = A[m0 + r, 4 * g:4 * g + 4]
+            for wave in range(4):
+                wm, wn = wave >> 1, wave & 1
+                arow = wm * 16 + li
+                bcol = wn * 32 + 2 * li
+                acc = [np.zeros((64, 4)), np.zeros((64, 4))]
+                for g8 in range(8):
+                    G = 4 * g8 + kq
+                    ia = (arow * 32 + (G ^ (arow & 7))) * 4
+                    ib0 = (bcol * 32 + (G ^ (bcol & 7))) * 4
+                    ib1 = ((bcol + 1) * 32 + (G ^ ((bcol + 1) & 7))) * 4
+                    for c in range(4):
+                        acc[0] = S.mfma(sA[ia + c], sB[ib0 + c], acc[0])
+                        acc[1] = S.mfma(sA[ia + c], sB[ib1 + c], acc[1])
+                mw0, nb = m0 + wm * 16, n0 + wn * 32 + 2 * li
+                for l in range(64):
+                    for r in range(4):
+                        m = mw0 + 1 * (4 * kq[l] + r) + 0
+                        if m < M:
+                            for t in range(2):
+                                C[m, nb[l] + t] = acc[t][l, r]
+    assert np.allclose(C, A @ Bkn, atol=1e-9)
+
+
+def test_gemm_ws_grid_decomposition():
+    """Every (slice, 32-row tile) is visited exactly once, and the slice blocks that share a y group sit on one XCD."""
+    for N, M in ((384, 236672), (256, 4096), (64, 2048 + 5)):
+        slices = N // 64
+        per_xcd = max(1, 64 // slices)
+        blocks, ygroups = 8 * per_xcd * slices, 8 * per_xcd
+        mtiles = (M + 31) // 32
+        seen = {}
+        for L in range(blocks):
+            xcd, q = L & 7, L >> 3
+            slice_, ygrp = q % slices, (q // slices) * 8 + xcd
+            assert ygrp < ygroups and ygrp % 8 == xcd
+            for tile in range(ygrp, mtiles, ygroups):
+                assert (slice_, tile) not in seen
+                seen[(slice_, tile)] = L
+        assert len(seen) == slices * mtiles
