@@ -875,6 +875,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmP p) {
             sB[(n * 32 + ((k >> 2) ^ (n & 7))) * 4 + (k & 3)] = p.B[(int64_t)k * p.ldb + n0 + n];
         }
     }
+    __syncthreads();                                       // the ds_writes of the B image are visible to every wave
     const int arow = wm * 16 + li;                         // A operand row of this lane (MT = 1)
     const int bcol = wn * 32 + 2 * li;                     // B operand columns bcol, bcol + 1 (NT = 2)
     int buf = 0, stores_prev = -1;
