@@ -11,415 +11,15 @@
 // of a lane then holds NT consecutive output columns -> 16-byte global stores.
 // An XOR swizzle on the column index (bits 3-4, keyed by k>>2) makes both the transposing
 // ds_write_b32 of k-contiguous operands and the ds_read_b128 of the MFMA loop conflict-free.
-#include "gt_common.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
+#include "gt_gemm_core.h"
+
 namespace gt {
-
-struct GemmP {
-    int M, N, K;
-    int tiles_m, tiles_n, batch1, k_chunk, n_split, n_batch, n_work;
-    const float* A; int64_t lda, a_bs0, a_bs1;
-    const float* B; int64_t ldb, b_bs0, b_bs1;
-    float* C; int64_t ldc, c_bs0, c_bs1, c_split;
-    int a_vec, b_vec, c_vec, raw;
-    DropDev a_drop; int64_t a_drop_ld, a_drop_bstride;
-    float* acs;                 // per-(K-slice, batch) partial row sums of the (masked) A operand, or null
-    float alpha; const float* bias;
-    int rp; const float* rp_a; int64_t rp_lda, rp_a_bs0; const float* rp_b; int64_t rp_ldb;
-    const float* add; int64_t ldadd, add_bs0, add_bs1;
-    float* pre; int64_t ldpre;
-    int act, aux_op; const float* aux; int64_t ldaux, aux_bs0, aux_bs1; float aux_scale;
-    DropDev drop; int drop_ld, n_off;      // mask index = (z*M + m)*drop_ld + n_off + n
-    const float* res; int64_t ldr, r_bs0, r_bs1;
-    float out_scale;
-    int ep_mode, n_out; const float* w2; int64_t ldw2; const float* b2; float* out2; const float* g2;
-    float* dw2_partial;      // MLP_BWD: [tiles_m * WM][n_out][N]
-    int K2; const float* A2; int64_t lda2, a2_bs0, a2_bs1; const float* B2; int64_t ldb2, b2_bs0, b2_bs1;
-    int a2_vec, b2_vec;
-    int light_wait;          // streamed kernel: counted vmcnt after full-tile epilogues (see kernel)
-    // GT_EP_HEADNORM: head-norm forward fused behind the QKV projection
-    const float* hn_gamma; const float* hn_beta; const float* hn_pos; float* hn_out; float* hn_stats;
-    int hn_h, hn_dk, hn_p, hn_DP, hn_mask; float hn_eps;
-};
-
-// ---- global -> registers: 4 consecutive elements of the operand tile -----------------------
-// L == 0: operand(x,k) = base[x*ld + k]  (k contiguous)  idx -> x = idx/(BK/4), k = 4*(idx%(BK/4))
-// L == 1: operand(x,k) = base[k*ld + x]  (x contiguous)  idx -> k = idx/(BX/4), x = 4*(idx%(BX/4))
-template <int L, int BX, int BK>
-__device__ __forceinline__ f32x4 gload(const float* __restrict__ base, int64_t ld, int x0, int X,
-                                       int k0, int kend, int idx, int vec, const DropDev& dd,
-                                       uint32_t dkey, int64_t dld, int64_t dboff) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (L == 0) {
-        constexpr int KQ = BK / 4;
-        const int x = x0 + idx / KQ, k = k0 + ((idx % KQ) << 2);
-        if (x < X && k < kend) {
-            const float* ptr = base + (int64_t)x * ld + k;
-            if (vec && k + 3 < kend) {
-                v = *reinterpret_cast<const f32x4*>(ptr);
-            } else {
-                v[0] = ptr[0];
-                if (k + 1 < kend) v[1] = ptr[1];
-                if (k + 2 < kend) v[2] = ptr[2];
-                if (k + 3 < kend) v[3] = ptr[3];
-            }
-            if (dd.thresh) {
-                const uint32_t di = (uint32_t)(dboff + (int64_t)x * dld + k);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= drop_mul(dd, dkey, di + j);
-            }
-        }
-    } else {
-        constexpr int Q = BX / 4;
-        const int k = k0 + idx / Q, x = x0 + ((idx % Q) << 2);
-        if (k < kend && x < X) {
-            const float* ptr = base + (int64_t)k * ld + x;
-            if (vec && x + 3 < X) {
-                v = *reinterpret_cast<const f32x4*>(ptr);
-            } else {
-                v[0] = ptr[0];
-                if (x + 1 < X) v[1] = ptr[1];
-                if (x + 2 < X) v[2] = ptr[2];
-                if (x + 3 < X) v[3] = ptr[3];
-            }
-            if (dd.thresh) {
-                const uint32_t di = (uint32_t)(dboff + (int64_t)k * dld + x);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= drop_mul(dd, dkey, di + j);
-            }
-        }
-    }
-    return v;
-}
-
-// ---- registers -> LDS image s[BK][BX], column swizzled by ((k>>2)&3)<<3 ---------------------
-template <int L, int BX, int BK>
-__device__ __forceinline__ void sstore(float* __restrict__ s, int idx, f32x4 v) {
-    if (L == 0) {
-        constexpr int KQ = BK / 4;
-        const int x = idx / KQ, c = idx % KQ;
-        const int col = x ^ (((c & 3) << 3) & (BX - 1));
-        s[(4 * c + 0) * BX + col] = v[0];
-        s[(4 * c + 1) * BX + col] = v[1];
-        s[(4 * c + 2) * BX + col] = v[2];
-        s[(4 * c + 3) * BX + col] = v[3];
-    } else {
-        constexpr int Q = BX / 4;
-        const int k = idx / Q, x = (idx % Q) << 2;
-        const int col = x ^ ((((k >> 2) & 3) << 3) & (BX - 1));
-        *reinterpret_cast<f32x4*>(&s[k * BX + col]) = v;
-    }
-}
-
-template <int NV>
-__device__ __forceinline__ void lds_frag(const float* __restrict__ s, float (&f)[NV]) {
-    if (NV == 4) {
-        f32x4 t = *reinterpret_cast<const f32x4*>(s);
-        f[0] = t[0]; f[1] = t[1]; f[2] = t[2]; f[3] = t[3];
-    } else if (NV == 2) {
-        f32x2 t = *reinterpret_cast<const f32x2*>(s);
-        f[0] = t[0]; f[1] = t[1];
-    } else {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) f[j] = s[j];
-    }
-}
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-#ifdef GT_ABL_NOMFMA      // ablation build (tools/ablate_gemm.sh): keep the operands live, skip the matrix pipe
-    asm volatile("" ::"v"(a), "v"(b));
-    return c;
-#endif
-#ifdef GT_EMULATE_MFMA
-    // Debug build: the same distributed-operand semantics with shuffles (documents the layout the
-    // kernel assumes: A[row=lane&15][k=lane>>4], B[k=lane>>4][col=lane&15], D[row=4*(lane>>4)+r][col=lane&15]).
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float av = __shfl(a, ((lane >> 4) * 4 + r) + 16 * k, 64);
-            float bv = __shfl(b, (lane & 15) + 16 * k, 64);
-            c[r] = fmaf(av, bv, c[r]);
-        }
-    }
-    return c;
-#else
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#endif
-}
-
-// Fused epilogue shared by both kernels.  The calling lane holds, for each of the MT x NT 16x16
-// accumulator tiles, rows  mw0 + MT*(4*kq + r) + s  (r = 0..3) and columns  nb + t.
-// HN: additionally run the per-head LayerNorm of gt_headnorm_fwd on the (biased) row segments this lane group
-// holds and scatter them into the head-tile layout (GT_EP_HEADNORM; NT == 4, dk/4 lanes per head segment).
-template <int NT>
-__device__ __forceinline__ void headnorm_scatter(const GemmP& p, const float (&v)[NT], int m, int nb) {
-    const int dk = p.hn_dk, G = dk >> 2;
-    const int stream = nb / (p.hn_h * dk), head = (nb / dk) % p.hn_h, dim = nb % dk;
-    const bool normed = (p.hn_mask >> stream) & 1;
-    float y[4] = {v[0], v[1 % NT], v[2 % NT], v[3 % NT]};
-    if (normed) {
-        const int ni = __popc(p.hn_mask & ((1 << stream) - 1));
-        const float inv = 1.f / (float)dk;
-        float sum = (y[0] + y[1]) + (y[2] + y[3]);
-        for (int o = G >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        const float mu = sum * inv;
-        float c[4] = {y[0] - mu, y[1] - mu, y[2] - mu, y[3] - mu};
-        float ss = (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
-        for (int o = G >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float rstd = 1.f / sqrtf(ss * inv + p.hn_eps);
-        const float* gm = p.hn_gamma + (ni * p.hn_h + head) * dk + dim;
-        const float* bt = p.hn_beta + (ni * p.hn_h + head) * dk + dim;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) y[t] = c[t] * rstd * gm[t] + bt[t];
-        if (dim == 0)
-            *reinterpret_cast<f32x2*>(p.hn_stats + (((int64_t)ni * p.M + m) * p.hn_h + head) * 2) = f32x2{mu, rstd};
-    }
-    float* row = p.hn_out + (((int64_t)stream * p.M + m) * p.hn_h + head) * p.hn_DP;
-    float* dst = row + p.hn_p + dim;
-    if ((p.hn_p & 3) == 0) *reinterpret_cast<f32x4*>(dst) = f32x4{y[0], y[1], y[2], y[3]};
-    else if ((p.hn_p & 1) == 0) {
-        *reinterpret_cast<f32x2*>(dst) = f32x2{y[0], y[1]};
-        *reinterpret_cast<f32x2*>(dst + 2) = f32x2{y[2], y[3]};
-    } else { dst[0] = y[0]; dst[1] = y[1]; dst[2] = y[2]; dst[3] = y[3]; }
-    if (dim == 0)
-        for (int jj = 0; jj < p.hn_p; ++jj) row[jj] = p.hn_pos[(int64_t)m * p.hn_p + jj];
-    if (dim == dk - 4)
-        for (int jj = p.hn_p + dk; jj < p.hn_DP; ++jj) row[jj] = 0.f;
-}
-
-template <int MT, int NT, bool HN = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, const f32x4 (&acc)[MT][NT], int mw0, int nb,
-                                              int z, int b0, int b1, int sidx, int kq) {
-        if (nb >= p.N) return;
-#ifdef GT_ABL_NOSTORE
-    if (acc[0][0][0] != 12345.678f) return;
-#endif
-    const bool full = (nb + NT <= p.N);
-    const int64_t coff = b0 * p.c_bs0 + b1 * p.c_bs1 + (int64_t)sidx * p.c_split;
-    float* __restrict__ C = p.C + coff;
-
-    float biasv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
-    const uint32_t dkey = drop_key_dev(p.drop);
-
-#pragma unroll
-    for (int s = 0; s < MT; ++s) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mw0 + MT * (4 * kq + r) + s;
-            if (m >= p.M) continue;
-            float v[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = acc[s][t][r];
-            float* cp = C + (int64_t)m * p.ldc + nb;
-            if (p.raw) {
-                if (full && p.c_vec && NT == 4) {
-                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (nb + t < p.N) cp[t] = v[t];
-                }
-                continue;
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = p.alpha * v[t] + biasv[t];
-            if (p.rp) {
-                const float* ra_ = p.rp_a + b0 * p.rp_a_bs0 + (int64_t)m * p.rp_lda;
-                for (int j = 0; j < p.rp; ++j) {
-                    const float aj = ra_[j];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (nb + t < p.N) v[t] += aj * p.rp_b[(int64_t)(nb + t) * p.rp_ldb + j];
-                }
-            }
-            const bool vec4 = full && p.c_vec && NT == 4;
-            // tile-row accessors: one 16-byte access when the row segment is aligned, scalars otherwise
-            auto ldrow = [&](const float* src, float (&o)[NT]) {
-                if (vec4) {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(src);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) o[t] = t4[t & 3];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) o[t] = (nb + t < p.N) ? src[t] : 0.f;
-                }
-            };
-            if (p.add) {
-                float ad[NT];
-                ldrow(p.add + b0 * p.add_bs0 + b1 * p.add_bs1 + (int64_t)m * p.ldadd + nb, ad);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] += ad[t];
-            }
-            if (p.pre) {
-                float* pp = p.pre + ((int64_t)z * p.M + m) * p.ldpre + nb;
-                if (vec4) {
-                    *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1 % NT], v[2 % NT], v[3 % NT]};
-                } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (nb + t < p.N) pp[t] = v[t];
-                }
-            }
-            if (p.act == GT_ACT_RELU) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] = fmaxf(v[t], 0.f);
-            } else if (p.act == GT_ACT_SILU) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] = silu_f(v[t]);
-            }
-            if (p.aux_op) {
-                float ax[NT];
-                ldrow(p.aux + b0 * p.aux_bs0 + b1 * p.aux_bs1 + (int64_t)m * p.ldaux + nb, ax);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float a = ax[t];
-                    v[t] *= (p.aux_op == GT_AUX_GT0)   ? (a > 0.f ? p.aux_scale : 0.f)
-                            : (p.aux_op == GT_AUX_DSILU) ? dsilu_f(a)
-                                                         : a * p.aux_scale;
-                }
-            }
-            if (p.drop.thresh) {
-                const uint32_t di = (uint32_t)(((int64_t)z * p.M + m) * p.drop_ld + p.n_off + nb);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] *= drop_mul(p.drop, dkey, di + t);
-            }
-            if (p.res) {
-                float rv[NT];
-                ldrow(p.res + b0 * p.r_bs0 + b1 * p.r_bs1 + (int64_t)m * p.ldr + nb, rv);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] = rv[t] + p.out_scale * v[t];
-            } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] *= p.out_scale;
-            }
-            if (full && p.c_vec && NT == 4) {
-                *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-            } else if (full && p.c_vec && NT == 2) {
-                *reinterpret_cast<f32x2*>(cp) = f32x2{v[0], v[1]};
-            } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (nb + t < p.N) cp[t] = v[t];
-            }
-            if (HN) headnorm_scatter<NT>(p, v, m, nb);     // v = alpha*acc + bias (no other epilogue field is set)
-        }
-    }
-}
-
-// Epilogues of the fused two-layer pointwise head (see gt_gemm_desc.ep_mode).  Called by every thread of
-// the block after the K loop (smem is free then); N <= BN, so the block owns complete rows.
-template <int MT, int NT, int WM, int WN, int NO>
-__device__ __forceinline__ void head_epilogue(const GemmP& p, const f32x4 (&acc)[MT][NT], float* smem, int m0,
-                                              int wm, int wn, int li, int kq, int tile_m) {
-    constexpr int BM = WM * 16 * MT;
-    const int nb = wn * 16 * NT + NT * li;
-    const int tid = threadIdx.x;
-    float biasv[NT], w2v[NO][NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
-#pragma unroll
-        for (int o = 0; o < NO; ++o) w2v[o][t] = (o < p.n_out && nb + t < p.N) ? p.w2[(int64_t)o * p.ldw2 + nb + t] : 0.f;
-    }
-    if (p.ep_mode == GT_EP_ROWDOT) {
-        float* part = smem;                                    // [WN][BM][4]
-#pragma unroll
-        for (int s = 0; s < MT; ++s)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ml = wm * 16 * MT + MT * (4 * kq + r) + s;
-                float d[NO];
-#pragma unroll
-                for (int o = 0; o < NO; ++o) d[o] = 0.f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    float v = p.alpha * acc[s][t][r] + biasv[t];
-                    v = (p.act == GT_ACT_RELU) ? fmaxf(v, 0.f) : (p.act == GT_ACT_SILU ? silu_f(v) : v);
-#pragma unroll
-                    for (int o = 0; o < NO; ++o) d[o] = fmaf(v, w2v[o][t], d[o]);
-                }
-#pragma unroll
-                for (int o = 0; o < NO; ++o) {                 // sum over the 16 column lanes of this row
-                    float x = d[o];
-                    x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64);
-                    x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
-                    d[o] = x;
-                }
-                if (li == 0) {
-#pragma unroll
-                    for (int o = 0; o < NO; ++o) part[(wn * BM + ml) * 4 + o] = d[o];
-                }
-            }
-        __syncthreads();
-        for (int e = tid; e < BM * p.n_out; e += blockDim.x) {
-            const int ml = e / p.n_out, o = e % p.n_out, m = m0 + ml;
-            if (m < p.M) {
-                float x = p.b2 ? p.b2[o] : 0.f;
-#pragma unroll
-                for (int w = 0; w < WN; ++w) x += part[(w * BM + ml) * 4 + o];
-                p.out2[(int64_t)m * p.n_out + o] = x;
-            }
-        }
-    } else {                                                   // GT_EP_MLP_BWD
-        float cs[NO][NT];
-#pragma unroll
-        for (int o = 0; o < NO; ++o)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) cs[o][t] = 0.f;
-#pragma unroll
-        for (int s = 0; s < MT; ++s)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 16 * MT + MT * (4 * kq + r) + s;
-                const bool ok = m < p.M;
-                float g[NO];
-#pragma unroll
-                for (int o = 0; o < NO; ++o) g[o] = (ok && o < p.n_out) ? p.g2[(int64_t)m * p.n_out + o] : 0.f;
-                float outv[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float h = p.alpha * acc[s][t][r] + biasv[t];
-                    float gw = 0.f;
-#pragma unroll
-                    for (int o = 0; o < NO; ++o) gw = fmaf(g[o], w2v[o][t], gw);
-                    float a, da;
-                    if (p.act == GT_ACT_SILU) silu_both(h, a, da);
-                    else if (p.act == GT_ACT_RELU) { a = fmaxf(h, 0.f); da = h > 0.f ? 1.f : 0.f; }
-                    else { a = h; da = 1.f; }
-                    outv[t] = gw * da;
-#pragma unroll
-                    for (int o = 0; o < NO; ++o) cs[o][t] = fmaf(g[o], a, cs[o][t]);
-                }
-                if (ok && nb < p.N) {
-                    float* cp = p.C + (int64_t)m * p.ldc + nb;
-                    if (NT == 4 && p.c_vec && nb + 4 <= p.N) *reinterpret_cast<f32x4*>(cp) = f32x4{outv[0], outv[1 % NT], outv[2 % NT], outv[3 % NT]};
-                    else {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) if (nb + t < p.N) cp[t] = outv[t];
-                    }
-                }
-            }
-        // dw2 partial of this wave's 16*MT rows: combine the 4 row lanes (kq), lanes kq == 0 store
-#pragma unroll
-        for (int o = 0; o < NO; ++o)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float x = cs[o][t];
-                x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
-                if (kq == 0 && o < p.n_out && nb + t < p.N)
-                    p.dw2_partial[(((int64_t)tile_m * WM + wm) * p.n_out + o) * p.N + nb + t] = x;
-            }
-    }
-}
 
 // HEAD: instance with the fused two-layer-head epilogues instead of the general one (kept out of the
 // general instances: its register footprint would cost them occupancy)
@@ -558,7 +158,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((HEAD == 0 && BK == 16) ? 4 : 1)) voi
         return;
     }
     // ------------------------------- epilogue -------------------------------------------------
-    gemm_epilogue<MT, NT, (HEAD < 0)>(p, acc, m0 + wm * 16 * MT, n0 + wn * 16 * NT + NT * li, z, b0, b1,
+    gemm_epilogue<MT, NT>(p, acc, m0 + wm * 16 * MT, n0 + wn * 16 * NT + NT * li, z, b0, b1,
                                       (int)blockIdx.y, kq);
 }
 
@@ -823,90 +423,6 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit
     }
 }
 
-// =================================================================================================
-// Weight-stationary kernel for the K = 128 token GEMMs (QKV, FFN1 and the FFN2 input gradient) -- STAGED behind
-// GT_STAGED=wsgemm, not yet run on hardware.  The v1 kernel spends a K = 128 tile as load -> 8 short stages ->
-// store with every co-resident block in the same phase (49-55 % of the fp32 MFMA peak).  Here a persistent
-// block keeps its 64-column slice of B (64 x 128 floats, 32 KB) in LDS for its whole life and only streams
-// 32-row A tiles (16 KB, double-buffered, direct global->LDS): one barrier and no B traffic per tile, the
-// epilogue's stores drain under the next tile's MFMAs (counted vmcnt), the next A tile is already in flight.
-//
-// Both LDS images are [row][128] in 16-byte granules with granule g of row r stored at slot g ^ (r & 7); a lane
-// (x = row or column, kq) reads the granules 4*g8 + kq, g8 = 0..7, as one ds_read_b128 each and uses component c
-// as the operand of k-step (g8, c), i.e. k = 16 g8 + 4 kq + c on both operands: 8 MFMAs per 3 LDS reads.
-// Row / column assignment follows gemm_epilogue's convention (MT = 1, NT = 2), so every fused epilogue works.
-// XCD-aware persistent grid: the N/64 slice blocks that share an A row panel get the same block id mod 8.
-constexpr int WS_BM = 32, WS_BN = 64, WS_K = 128;
-template <int LB>
-__global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmP p) {
-    __shared__ __attribute__((aligned(16))) float sB[WS_BN * WS_K];
-    __shared__ __attribute__((aligned(16))) float sA[2][WS_BM * WS_K];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    // block -> (slice, y group): blocks L, L+8, L+16, ... of one XCD walk the slices of one y group first
-    const int slices = p.N / WS_BN, per_xcd = (int)gridDim.x / (8 * slices);
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int slice = q % slices, ygrp = (q / slices) * 8 + xcd, ygroups = per_xcd * 8;
-    const int n0 = slice * WS_BN;
-    const int mtiles = (p.M + WS_BM - 1) / WS_BM;
-
-    auto issue = [&](int tile, int buf) {                 // A tile: 16 chunks of 1 KiB, 4 per wave
-        const int m0 = tile * WS_BM;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = wave * 4 + i, e = ch * 64 + lane;
-            const int r = e >> 5, g = (e & 31) ^ (r & 7);
-            const float* src = (m0 + r < p.M) ? p.A + (int64_t)(m0 + r) * p.lda + 4 * g : gt_zero16;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(&sA[buf][ch * 256]), 16, 0, 0);
-        }
-    };
-    int tile = ygrp;
-    if (tile < mtiles) issue(tile, 0);
-    // B slice, once: image [n][128], granule g of column n at slot g ^ (n & 7)
-    if (LB == 0) {
-        for (int e = tid; e < WS_BN * 32; e += 256) {
-            const int n = e >> 5, g = (e & 31) ^ (n & 7);
-            *reinterpret_cast<f32x4*>(&sB[e * 4]) = *reinterpret_cast<const f32x4*>(p.B + (int64_t)(n0 + n) * p.ldb + 4 * g);
-        }
-    } else {
-        for (int e = tid; e < WS_BN * WS_K; e += 256) {
-            const int k = e / WS_BN, n = e - k * WS_BN;    // coalesced along n
-            sB[(n * 32 + ((k >> 2) ^ (n & 7))) * 4 + (k & 3)] = p.B[(int64_t)k * p.ldb + n0 + n];
-        }
-    }
-    __syncthreads();                                       // the ds_writes of the B image are visible to every wave
-    const int arow = wm * 16 + li;                         // A operand row of this lane (MT = 1)
-    const int bcol = wn * 32 + 2 * li;                     // B operand columns bcol, bcol + 1 (NT = 2)
-    int buf = 0, stores_prev = -1;
-    for (; tile < mtiles; tile += ygroups, buf ^= 1) {
-        // tile's A has landed for this wave (older than the previous tile's stores, which may still drain)
-        if (stores_prev == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        if (tile + ygroups < mtiles) issue(tile + ygroups, buf ^ 1);
-        const float* a_img = sA[buf];
-        f32x4 acc[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-#pragma unroll
-        for (int g8 = 0; g8 < 8; ++g8) {
-            const int G = 4 * g8 + kq;
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&a_img[(arow * 32 + (G ^ (arow & 7))) * 4]);
-            const f32x4 b40 = *reinterpret_cast<const f32x4*>(&sB[(bcol * 32 + (G ^ (bcol & 7))) * 4]);
-            const f32x4 b41 = *reinterpret_cast<const f32x4*>(&sB[((bcol + 1) * 32 + (G ^ ((bcol + 1) & 7))) * 4]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc[0][0] = mfma16(a4[c], b40[c], acc[0][0]);
-                acc[0][1] = mfma16(a4[c], b41[c], acc[0][1]);
-            }
-        }
-        const int m0 = tile * WS_BM;
-        gemm_epilogue<1, 2>(p, acc, m0 + wm * 16, n0 + wn * 32 + 2 * li, 0, 0, 0, 0, kq);
-        // a full, aligned tile whose epilogue reads nothing but the bias issues exactly 4 float2 stores after the
-        // prefetch (the bias loads have been consumed by then): allowing 4 outstanding operations is safe
-        stores_prev = (m0 + WS_BM <= p.M && p.c_vec && !p.pre && !p.res && !p.add && !p.aux_op && !p.rp) ? 4 : 0;
-    }
-}
-
 struct Cfg { int mt, nt, wm, wn; };
 static const Cfg kCfgs[] = {{4, 4, 2, 2}, {2, 4, 2, 2}, {2, 2, 2, 2}, {2, 2, 4, 1}, {2, 1, 4, 1}};
 constexpr int kNumCfg = 5;
@@ -932,11 +448,6 @@ static void launch_head_no(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
         case 3: hipLaunchKernelGGL((gemm_kernel<0, 0, 2, 2, 4, 1, 16, NO>), grid, dim3(256), 0, st, p); break;
         default: hipLaunchKernelGGL((gemm_kernel<0, 0, 2, 1, 4, 1, 16, NO>), grid, dim3(256), 0, st, p); break;
     }
-}
-// QKV projection + head norm (GT_EP_HEADNORM): 128-wide tile columns only (a head segment stays inside a wave)
-static void launch_hn(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
-    if (cfg == 0) hipLaunchKernelGGL((gemm_kernel<0, 0, 4, 4, 2, 2, 16, -1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<0, 0, 2, 4, 2, 2, 16, -1>), grid, dim3(256), 0, st, p);
 }
 static void launch_head(int cfg, dim3 grid, hipStream_t st, const GemmP& p) {
     if (p.n_out == 1) launch_head_no<1>(cfg, grid, st, p);
@@ -978,7 +489,7 @@ static void launch_stream(hipStream_t st, const GemmP& p) {
     hipLaunchKernelGGL((gemm_stream_kernel<LA, LB, MT>), dim3(nblk), dim3(256), 0, st, q);
 }
 
-struct Plan { int cfg, bm, bn, bk, tiles_m, tiles_n, split, k_chunk, stream, ws; };
+struct Plan { int cfg, bm, bn, bk, tiles_m, tiles_n, split, k_chunk, stream, x3; };
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool m4(int64_t v) { return (v & 3) == 0; }
@@ -988,30 +499,20 @@ static bool has_epilogue(const gt_gemm_desc* d) {
            d->out_scale != 1.f || d->ep_mode != GT_EP_NORMAL || d->K2 > 0;
 }
 
-static bool staged(const char* what) {
-    const char* e = getenv("GT_STAGED");
-    return e && strstr(e, what) != nullptr;
-}
-static int ws_blocks(const gt_gemm_desc* d) {
-    const int slices = d->N / WS_BN;
-    return 8 * std::max(1, 64 / slices) * slices;
-}
-// weight-stationary K = 128 kernel (staged): token GEMMs with a k-contiguous A, whole 64-column slices
-static bool ws_eligible(const gt_gemm_desc* d) {
-    static const bool on = staged("wsgemm");
-    if (!on || d->K != WS_K || d->layout_a != 0 || d->batch0 * d->batch1 != 1 || d->split_k > 1) return false;
-    if (d->N % WS_BN || d->N / WS_BN > 64 || d->ep_mode != GT_EP_NORMAL || d->K2 > 0) return false;
-    if (d->a_drop.p > 0.f || d->a_colsum) return false;
-    if (!al16(d->A) || !m4(d->lda)) return false;
-    if (d->layout_b == 0 && (!al16(d->B) || !m4(d->ldb))) return false;
-    const int slices = d->N / WS_BN, ygroups = 8 * std::max(1, 64 / slices);
-    return ceil_div(d->M, WS_BM) >= ygroups;
+// number of bf16 planes the split-operand kernel (gt_gemm_x3.hip) would use for d, 0 = fp32 MFMA kernels
+static int x3_planes(const gt_gemm_desc* d) {
+    const int planes = d->precision == GT_PREC_BF16X3 ? 3 : d->precision == GT_PREC_BF16X2 ? 2
+                       : d->precision == GT_PREC_BF16 ? 1 : 0;
+    if (!planes || !x3_shape_ok(d) || (d->a_colsum && d->layout_a != 1)) return 0;
+    return planes;
 }
 
 static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     if (d->M <= 0 || d->N <= 0 || d->K < 0 || d->batch0 <= 0 || d->batch1 <= 0) return GT_EINVAL;
+    if (d->precision < GT_PREC_F32 || d->precision > GT_PREC_BF16) return GT_EINVAL;
     const int64_t batch = (int64_t)d->batch0 * d->batch1;
     if (batch > 65535) return GT_EINVAL;
+    pl->x3 = x3_planes(d);
     // Tile choice by a small cost model (calibrated on MI355X with tools/gemm_probe.py): the blocks that
     // share a CU share its matrix pipes, so time ~ ceil(tiles / CUs) * tile area / efficiency of the
     // configuration (MFMAs per LDS read / per barrier).  Padding waste shows up through the tile count.
@@ -1024,7 +525,6 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
         if (head_ep && bn < d->N) continue;                         // the fused head needs whole rows per block
         // the 128x128 head instance needs > 256 registers (one block per CU): the 64x128 one runs two
         if (head_ep && i == 0 && d->N <= 128) continue;
-        if (d->ep_mode == GT_EP_HEADNORM && i > 1) continue;         // head segments must stay inside a wave tile
         const double tiles = (double)ceil_div(d->M, bm) * ceil_div(d->N, bn) * (double)batch;
         // under-filled grids: with split-K available the K-slices fill the chip (time ~ total padded work),
         // otherwise every block has a CU to itself (time ~ one tile)
@@ -1037,6 +537,7 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
         const int f = atoi(e);
         if (f >= 0 && f < kNumCfg) c = f;
     }
+    if (pl->x3) c = 0;                                // the split-operand kernel has one geometry: 128 x 128 tiles
     pl->cfg = c;
     // BK=32 pays for the long-K reductions with row-contiguous operands (weight gradients); the
     // short-K token GEMMs are prologue/epilogue-bound and run better with the smaller stage
@@ -1052,6 +553,7 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     if (d->ep_mode != GT_EP_NORMAL) { pl->stream = 0; pl->bk = 16; }
     if (d->K2 > 0) pl->stream = 0;
     if (pl->stream) pl->bk = 32;
+    if (pl->x3) { pl->stream = 0; pl->bk = 16; }
     pl->bm = kCfgs[c].wm * 16 * kCfgs[c].mt;
     pl->bn = kCfgs[c].wn * 16 * kCfgs[c].nt;
     pl->tiles_m = ceil_div(d->M, pl->bm);
@@ -1075,8 +577,6 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     split = std::max(1, ceil_div(std::max(d->K, 1), chunk));
     pl->split = split;
     pl->k_chunk = chunk;
-    pl->ws = ws_eligible(d) ? 1 : 0;
-    if (pl->ws) { pl->split = 1; pl->stream = 0; pl->k_chunk = WS_K; }
     return 0;
 }
 
@@ -1125,14 +625,14 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
     int rc = make_plan(d, &pl);
     if (rc) return rc;
     const Cfg& c = kCfgs[pl.cfg];
-    if (pl.ws)
-        snprintf(buf, n, "void gt::gemm_ws_kernel<%d>(gt::GemmP)", d->layout_b);
+    if (pl.x3)
+        snprintf(buf, n, "%s", x3_kernel_name(d->layout_a, d->layout_b, pl.x3));
     else if (pl.stream)
         snprintf(buf, n, "void gt::gemm_stream_kernel<%d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b, c.mt);
     else
         snprintf(buf, n, "void gt::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b,
                  c.mt, c.nt, c.wm, c.wn, pl.bk,
-                 d->ep_mode == GT_EP_NORMAL ? 0 : (d->ep_mode == GT_EP_HEADNORM ? -1 : (d->n_out == 1 ? 1 : 4)));
+                 d->ep_mode == GT_EP_NORMAL ? 0 : (d->n_out == 1 ? 1 : 4));
     return 0;
 }
 
@@ -1151,17 +651,7 @@ extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
 static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int64_t ws_bytes, void* stream) {
     if (!d || !d->A || !d->B) return GT_EINVAL;
     if (!d->C && d->ep_mode != GT_EP_ROWDOT) return GT_EINVAL;
-    if (d->ep_mode == GT_EP_HEADNORM) {
-        if (d->layout_a || d->layout_b || d->batch0 * d->batch1 != 1 || d->K2 > 0) return GT_ENOTSUP;
-        if (d->hn_dk != 16 && d->hn_dk != 32 && d->hn_dk != 64) return GT_ENOTSUP;
-        if (d->hn_h <= 0 || d->hn_p < 0 || d->N != 3 * d->hn_h * d->hn_dk || (d->hn_norm_mask & ~7)) return GT_EINVAL;
-        if (!d->hn_out || (d->hn_p > 0 && !d->hn_pos)) return GT_EINVAL;
-        if (d->hn_norm_mask && (!d->hn_gamma || !d->hn_beta || !d->hn_stats)) return GT_EINVAL;
-        if (d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res || d->out_scale != 1.f ||
-            d->a_drop.p > 0.f || d->a_colsum)
-            return GT_ENOTSUP;
-        if ((reinterpret_cast<uintptr_t>(d->hn_out) | reinterpret_cast<uintptr_t>(d->hn_stats)) & 15) return GT_EALIGN;
-    } else if (d->ep_mode != GT_EP_NORMAL) {
+    if (d->ep_mode != GT_EP_NORMAL) {
         if (d->ep_mode != GT_EP_ROWDOT && d->ep_mode != GT_EP_MLP_BWD) return GT_EINVAL;
         if (d->N > 128 || d->batch0 * d->batch1 != 1 || d->n_out < 1 || d->n_out > 4 || !d->w2) return GT_ENOTSUP;
         if (d->ep_mode == GT_EP_ROWDOT && !d->out2) return GT_EINVAL;
@@ -1204,13 +694,7 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     const int64_t mn = (int64_t)d->M * d->N;
     float* dw2_partial = nullptr;
     const int dw2_slabs = pl.tiles_m * kCfgs[pl.cfg].wm;
-    if (d->ep_mode == GT_EP_HEADNORM) {
-        if (pl.split != 1 || pl.cfg > 1) return GT_ENOTSUP;
-        p.ep_mode = d->ep_mode;
-        p.hn_gamma = d->hn_gamma; p.hn_beta = d->hn_beta; p.hn_pos = d->hn_pos; p.hn_out = d->hn_out;
-        p.hn_stats = d->hn_stats; p.hn_h = d->hn_h; p.hn_dk = d->hn_dk; p.hn_p = d->hn_p;
-        p.hn_DP = (d->hn_dk + d->hn_p + 3) & ~3; p.hn_mask = d->hn_norm_mask; p.hn_eps = d->hn_eps;
-    } else if (d->ep_mode != GT_EP_NORMAL) {
+    if (d->ep_mode != GT_EP_NORMAL) {
         if (pl.tiles_n != 1 || pl.split != 1) return GT_ENOTSUP;
         p.ep_mode = d->ep_mode; p.n_out = d->n_out; p.w2 = d->w2; p.ldw2 = d->ldw2; p.b2 = d->b2;
         p.out2 = d->out2; p.g2 = d->g2;
@@ -1268,11 +752,10 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
 
     dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split, (unsigned)batch);
     const int lay = d->layout_a * 2 + d->layout_b;
-    if (pl.ws) {
-        if (d->layout_b == 0) hipLaunchKernelGGL((gemm_ws_kernel<0>), dim3(ws_blocks(d)), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_ws_kernel<1>), dim3(ws_blocks(d)), dim3(256), 0, st, p);
-    } else if (d->ep_mode == GT_EP_HEADNORM) {
-        launch_hn(pl.cfg, grid, st, p);
+    if (pl.x3) {
+        int rcx = x3_launch(p, d->layout_a, d->layout_b, pl.x3, (unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split,
+                            (unsigned)batch, st);
+        if (rcx) return rcx;
     } else if (d->ep_mode != GT_EP_NORMAL) {
         if (lay != 0) return GT_ENOTSUP;
         launch_head(pl.cfg, grid, st, p);
@@ -1340,7 +823,8 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
     const int rem = d->N % 128;
     Plan pl;
     // only when the aligned part alone fills the chip: two half-empty launches would serialise instead
-    if (d->N > 128 && rem != 0 && rem <= 64 && make_plan(d, &pl) == 0 && pl.split == 1 && pl.bn == 128 &&
+    if (d->N > 128 && rem != 0 && rem <= 64 && d->ep_mode == GT_EP_NORMAL && make_plan(d, &pl) == 0 && pl.split == 1 &&
+        pl.bn == 128 &&
         (int64_t)pl.tiles_m * (d->N / 128) * d->batch0 * d->batch1 >= 512) {
         const int n_main = d->N - rem;
         gt_gemm_desc a = *d, b = *d;
@@ -1348,6 +832,7 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
         b.N = rem;
         b.B = d->B + (d->layout_b == 0 ? (int64_t)n_main * d->ldb : (int64_t)n_main);
         b.C = d->C + n_main;
+        if (d->K2 > 0) b.B2 = d->B2 + (d->layout_b == 0 ? (int64_t)n_main * d->ldb2 : (int64_t)n_main);
         if (d->bias) b.bias = d->bias + n_main;
         if (d->rp) b.rp_b = d->rp_b + (int64_t)n_main * d->rp_ldb;
         if (d->add) b.add = d->add + n_main;

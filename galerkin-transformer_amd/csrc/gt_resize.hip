@@ -687,78 +687,12 @@ __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
     *reinterpret_cast<f32x4*>(p.y + addr<true>(b, c, iy, ix, p.C, p.Hi, p.Wi)) = acc;
 }
 
-// ---- mixed layouts (planar gradient -> channels-last dx and the reverse), STAGED behind GT_STAGED=resizebwd:
-// the bilinear weights are separable, so a block first folds the <= RS_MAXT contributing gradient ROWS of its
-// input row into one LDS row per channel (coalesced in the gradient's own layout), then gathers along x from
-// LDS in the layout of dx.  32 channels x Wo floats of LDS (odd pitch), one barrier, no scalar planar gathers.
-template <bool G_NHWC>
-__global__ __launch_bounds__(256) void resize_bwd_rowfold_kernel(const ResizeP p) {
-    extern __shared__ float rows[];                      // [32][P]
-    const int P = p.Wo | 1;
-    const int t = threadIdx.x;
-    const int c0 = blockIdx.x * 32, iy = blockIdx.y, b = blockIdx.z;
-    const Taps ty = taps_of(iy, p.sy, p.Hi, p.Ho);
-    auto fold = [&](int c, int ox) {
-        float acc = 0.f;
-        if (c < p.C) {
-#pragma unroll
-            for (int jy = 0; jy < RS_MAXT; ++jy) {
-                if (jy < ty.n) {
-                    const int64_t o = addr<G_NHWC>(b, c, ty.lo + jy, ox, p.C, p.Ho, p.Wo);
-                    float g = p.x[o];
-                    if (p.gate && !(p.gate[o] > 0.f)) g = 0.f;
-                    acc = fmaf(ty.w[jy], g, acc);
-                }
-            }
-        }
-        return acc;
-    };
-    if (!G_NHWC) {                                       // planar gradient: lanes run along x
-        for (int e = t; e < 32 * p.Wo; e += 256) {
-            const int cc = e / p.Wo, ox = e - cc * p.Wo;
-            rows[cc * P + ox] = fold(c0 + cc, ox);
-        }
-    } else {                                             // channels-last gradient: lanes run along channels
-        const int cc = t & 31;
-        for (int ox = t >> 5; ox < p.Wo; ox += 8) rows[cc * P + ox] = fold(c0 + cc, ox);
-    }
-    __syncthreads();
-    auto gather = [&](int cc, int ix) {
-        const Taps tx = taps_of(ix, p.sx, p.Wi, p.Wo);
-        float acc = 0.f;
-#pragma unroll
-        for (int jx = 0; jx < RS_MAXT; ++jx)
-            if (jx < tx.n) acc = fmaf(tx.w[jx], rows[cc * P + tx.lo + jx], acc);
-        return acc;
-    };
-    if (!G_NHWC) {                                       // dx channels-last: 32 lanes = 32 channels of one pixel
-        const int cc = t & 31, c = c0 + cc;
-        for (int ix = t >> 5; ix < p.Wi; ix += 8) {
-            const float v = gather(cc, ix);
-            if (c < p.C) p.y[addr<true>(b, c, iy, ix, p.C, p.Hi, p.Wi)] = v;
-        }
-    } else {                                             // dx planar: lanes run along x
-        for (int e = t; e < 32 * p.Wi; e += 256) {
-            const int cc = e / p.Wi, ix = e - cc * p.Wi, c = c0 + cc;
-            const float v = gather(cc, ix);
-            if (c < p.C) p.y[addr<false>(b, c, iy, ix, p.C, p.Hi, p.Wi)] = v;
-        }
-    }
-}
-
 // true when no input index of the axis has more than RS_MAXT contributing outputs (host-side bound:
 // an input cell's support spans at most 2 * (no-1)/(ni-1) outputs)
 static inline bool taps_fit(int ni, int no) {
     return ni <= 1 ? no <= RS_MAXT : 2.0 * (double)(no - 1) / (double)(ni - 1) + 2.0 <= (double)RS_MAXT;
 }
 
-static bool staged_rowfold() {
-    static const bool on = [] {
-        const char* e = getenv("GT_STAGED");
-        return e && strstr(e, "resizebwd") != nullptr;
-    }();
-    return on;
-}
 static inline float scale_of(int ni, int no) { return (no > 1) ? (float)(ni - 1) / (float)(no - 1) : 0.f; }
 
 }  // namespace gt
@@ -814,14 +748,6 @@ extern "C" int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx
         if (ceil_div(C, 8) > 65535) return GT_EINVAL;
         dim3 pg((unsigned)ceil_div((int64_t)Hi * Wi, 256), (unsigned)ceil_div(C, 8), (unsigned)B);
         hipLaunchKernelGGL(resize_bwd_planar_kernel, pg, dim3(256), 0, st, p);
-    }
-    else if (in_nhwc != out_nhwc && staged_rowfold() && taps_fit(Hi, Ho) && taps_fit(Wi, Wo) && Wo <= 480 &&
-             ceil_div(C, 32) <= 65535) {
-        // G (forward-output layout) planar <=> out_nhwc == 0
-        dim3 rg((unsigned)ceil_div(C, 32), (unsigned)Hi, (unsigned)B);
-        const size_t lds = (size_t)32 * (Wo | 1) * sizeof(float);
-        if (!out_nhwc) hipLaunchKernelGGL((resize_bwd_rowfold_kernel<false>), rg, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((resize_bwd_rowfold_kernel<true>), rg, dim3(256), lds, st, p);
     }
     else if (!out_nhwc && in_nhwc) hipLaunchKernelGGL((resize_bwd_kernel<false, true>), grid, dim3(256), 0, st, p);
     else if (out_nhwc && !in_nhwc) hipLaunchKernelGGL((resize_bwd_kernel<true, false>), grid, dim3(256), 0, st, p);

@@ -15,9 +15,12 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
+ABI_VERSION = 7          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
-EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
+EP_NORMAL, EP_ROWDOT, EP_MLP_BWD = 0, 1, 2
+PREC_F32, PREC_BF16X3, PREC_BF16X2, PREC_BF16 = 0, 1, 2, 3
+PREC_CODE = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x2": PREC_BF16X2, "bf16": PREC_BF16}
 ACT_CODE = {None: ACT_NONE, "none": ACT_NONE, "identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
 
 
@@ -54,9 +57,7 @@ class GtGemmDesc(C.Structure):
         ("b2", C.c_void_p), ("out2", C.c_void_p), ("g2", C.c_void_p), ("dw2", C.c_void_p),
         ("K2", C.c_int32), ("A2", C.c_void_p), ("lda2", C.c_int64), ("a2_bs0", C.c_int64), ("a2_bs1", C.c_int64),
         ("B2", C.c_void_p), ("ldb2", C.c_int64), ("b2_bs0", C.c_int64), ("b2_bs1", C.c_int64),
-        ("hn_gamma", C.c_void_p), ("hn_beta", C.c_void_p), ("hn_pos", C.c_void_p), ("hn_out", C.c_void_p),
-        ("hn_stats", C.c_void_p), ("hn_h", C.c_int32), ("hn_dk", C.c_int32), ("hn_p", C.c_int32),
-        ("hn_norm_mask", C.c_int32), ("hn_eps", C.c_float),
+        ("precision", C.c_int32),
     ]
 
 
@@ -152,7 +153,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.gt_abi_version() != 6:
+        if handle.gt_abi_version() != ABI_VERSION:
             raise RuntimeError("libgt_hip ABI version mismatch")
         _lib = handle
     return _lib
@@ -250,17 +251,46 @@ def need_f32_cuda(*ts: torch.Tensor):
             raise TypeError(f"galerkin_transformer HIP operators are fp32 (got {t.dtype})")
 
 
+# ----------------------------------------------------------------------------------- GEMM arithmetic mode
+# "bf16x3" (default): fp32 operands split exactly into three bf16 terms, six plane products on the bf16 MFMA pipe,
+#           fp32 accumulation -- fp32-class results (the 1e-5 parity gate holds) at 16/6 of the fp32 matrix rate;
+# "f32":    v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 FMA chain;
+# "bf16x2" / "bf16": two terms / plain bf16 operands -- throughput modes with their own looser gates.
+# See gt_gemm_desc.precision in include/gt_hip.h.  GT_PRECISION in the environment sets the initial mode.
+_precision = [PREC_CODE[os.environ.get("GT_PRECISION", "bf16x3")]]
+
+
+def set_precision(mode: str) -> str:
+    """Select the arithmetic of every gt_gemm contraction issued from now on; returns the previous mode."""
+    if mode not in PREC_CODE:
+        raise ValueError(f"precision must be one of {sorted(PREC_CODE)}, got {mode!r}")
+    old = get_precision()
+    _precision[0] = PREC_CODE[mode]
+    return old
+
+
+def get_precision() -> str:
+    return {v: k for k, v in PREC_CODE.items()}[_precision[0]]
+
+
 # ----------------------------------------------------------------------------------- scratch / rng state
 _ws_cache = {}
+_ws_retired = []          # outgrown buffers stay alive: a captured HIP graph may have their pointer baked in
 _WS_MIN = 64 << 20
 
 
 def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Per-device scratch buffer (stream-ordered reuse: every consumer runs on the current stream)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Scratch buffer per (device, stream): consumers of one stream are stream-ordered, so reuse is safe; two
+    streams never share a buffer (a graph capture runs on its own stream, so captured work gets its own buffer
+    from the capture's memory pool).  A buffer that has to grow is retired, not freed -- graphs captured earlier
+    keep replaying into memory nobody else owns."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, dev, torch.cuda.current_stream(dev).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         size = max(_WS_MIN, int(nbytes * 1.25))
+        if buf is not None:
+            _ws_retired.append(buf)
         buf = torch.empty(size, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
@@ -279,9 +309,22 @@ def seed_state(device: torch.device) -> torch.Tensor:
     return s
 
 
+# call-site salts: every operator call that draws masks takes the next value(s), so two sites never share a mask.
+# set_seed() rewinds the counter: a seeded run reproduces whatever ran earlier in the process.  A captured HIP
+# graph keeps the salts it was captured with and varies its masks through the device-resident seed instead.
+_salt = [1]
+
+
+def next_salt(k: int = 4) -> int:
+    s = _salt[0]
+    _salt[0] = (s + k) & 0x7FFFFFFF
+    return s
+
+
 def set_seed(seed: int, device: Optional[torch.device] = None):
     device = device or torch.device("cuda", torch.cuda.current_device())
     seed_state(device).fill_(seed & 0x7FFFFFFFFFFFFFFF)
+    _salt[0] = 1
 
 
 def advance_seed(device: Optional[torch.device] = None, inc: int = 1):
@@ -317,8 +360,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          out2: Optional[torch.Tensor] = None, g2: Optional[torch.Tensor] = None,
          dw2: Optional[torch.Tensor] = None,
          K2: int = 0, A2: Optional[torch.Tensor] = None, lda2: int = 0, a2_bs=(0, 0),
-         B2: Optional[torch.Tensor] = None, ldb2: int = 0, b2_bs=(0, 0), hn: Optional[dict] = None):
-    """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics)."""
+         B2: Optional[torch.Tensor] = None, ldb2: int = 0, b2_bs=(0, 0),
+         precision: Optional[str] = None):
+    """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics).  precision=None uses the module mode
+    (set_precision)."""
     need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, a_colsum)
     L = lib()
     d = GtGemmDesc()
@@ -327,6 +372,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     d.layout_a, d.layout_b = layout_a, layout_b
     d.batch0, d.batch1 = batch
     d.split_k = split_k
+    d.precision = _precision[0] if precision is None else PREC_CODE[precision]
     d.A, d.lda, d.a_bs0, d.a_bs1 = A.data_ptr(), lda, a_bs[0], a_bs[1]
     d.B, d.ldb, d.b_bs0, d.b_bs1 = B.data_ptr(), ldb, b_bs[0], b_bs[1]
     d.C, d.ldc, d.c_bs0, d.c_bs1 = ptr(Cout), ldc, c_bs[0], c_bs[1]
@@ -361,12 +407,6 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         need_f32_cuda(A2, B2)
         d.K2, d.A2, d.lda2, d.a2_bs0, d.a2_bs1 = K2, A2.data_ptr(), lda2, a2_bs[0], a2_bs[1]
         d.B2, d.ldb2, d.b2_bs0, d.b2_bs1 = B2.data_ptr(), ldb2, b2_bs[0], b2_bs[1]
-    if hn is not None:          # GT_EP_HEADNORM: gamma, beta, pos, out, stats, h, dk, p, norm_mask, eps
-        need_f32_cuda(hn.get("gamma"), hn.get("beta"), hn.get("pos"), hn["out"], hn.get("stats"))
-        d.ep_mode = EP_HEADNORM
-        d.hn_gamma, d.hn_beta, d.hn_pos = ptr(hn.get("gamma")), ptr(hn.get("beta")), ptr(hn.get("pos"))
-        d.hn_out, d.hn_stats = hn["out"].data_ptr(), ptr(hn.get("stats"))
-        d.hn_h, d.hn_dk, d.hn_p, d.hn_norm_mask, d.hn_eps = hn["h"], hn["dk"], hn["p"], hn["norm_mask"], hn["eps"]
     need = L.gt_gemm_ws_bytes(C.byref(d))
     wsp, wsn = None, 0
     if need > 0:
@@ -392,11 +432,12 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     return Cout
 
 
-def gemm_kernel_name(A, B, M, N, K, *, layout_a=0, layout_b=0, lda, ldb, ldc, split_k=1) -> str:
+def gemm_kernel_name(A, B, M, N, K, *, layout_a=0, layout_b=0, lda, ldb, ldc, split_k=1, precision=None) -> str:
     """Symbol of the kernel gt_gemm launches for a plain (epilogue-free, unbatched) product."""
     d = GtGemmDesc()
     lib().gt_gemm_desc_init(C.byref(d))
     d.M, d.N, d.K, d.layout_a, d.layout_b, d.split_k = M, N, K, layout_a, layout_b, split_k
+    d.precision = _precision[0] if precision is None else PREC_CODE[precision]
     d.A, d.lda, d.B, d.ldb, d.ldc = A.data_ptr(), lda, B.data_ptr(), ldb, ldc
     nm = C.create_string_buffer(160)
     check(lib().gt_gemm_kernel_name(C.byref(d), nm, 160), "gt_gemm_kernel_name")
@@ -665,8 +706,6 @@ def galerkin_ktv(Kp: torch.Tensor, Vp: torch.Tensor, B: int, n: int, h: int, dk:
 
 
 # kernels that exist and pass their CPU lane-model checks but have not been measured on hardware yet are opt-in:
-# GT_STAGED=dkv,...  (see include/gt_hip.h for each)
-STAGED = frozenset(x for x in os.environ.get("GT_STAGED", "").split(",") if x)
 
 
 def galerkin_dkv(Kp, Vp, dM, dKp, dVp, B: int, n: int, h: int, DP: int):

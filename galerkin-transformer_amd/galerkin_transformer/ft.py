@@ -302,56 +302,75 @@ class BurgersDataset(Dataset):
 
 # --------------------------------------------------------------------------------------- losses
 class WeightedL2Loss(_WeightedLoss):
-    """1-D relative L2 loss with optional H1-seminorm regulariser on a periodic grid (ft.py:848-980).
+    """1-D relative L2 loss with optional H1-seminorm regulariser and latent orthogonaliser
+    (ft.py:848-980).  As in the reference the weights gamma, alpha and delta are stored pre-multiplied by the
+    mesh size h (ft.py:872-874), ``periodic`` is accepted but the difference stencil is always the interior
+    one (ft.py:894-899), and ``orthogonal_reg`` gates the term on the latent features.
     Returns (loss, regularizer, orthogonalizer, metric)."""
 
-    def __init__(self, dilation=2, regularizer=False, h=1 / 512, beta=1.0, gamma=1e-1, alpha=0.0, delta=0.0,
+    def __init__(self, dilation=2, regularizer=False, h=1 / 512, beta=1.0, gamma=1e-1, alpha=0.0,
                  metric_reduction='L1', periodic=False, return_norm=True, orthogonal_reg=False,
-                 orthogonal_mode='global', noise=0.0, debug=False):
+                 orthogonal_mode='global', delta=1e-4, noise=0.0, debug=False):
         super().__init__()
         assert dilation % 2 == 0
         self.dilation, self.regularizer, self.h = dilation, regularizer, h
-        self.beta, self.gamma, self.alpha, self.delta = beta, gamma, alpha, delta
+        self.beta = beta
+        self.gamma, self.alpha, self.delta = gamma * h, alpha * h, delta * h
         self.metric_reduction, self.periodic, self.return_norm = metric_reduction, periodic, return_norm
-        self.noise, self.eps = noise, 1e-8
+        self.orthogonal_reg, self.orthogonal_mode = orthogonal_reg, orthogonal_mode
+        self.noise, self.eps, self.debug = noise, 1e-8, debug
 
     def central_diff(self, x, h=None):
         h = self.h if h is None else h
         d = self.dilation
-        if self.periodic:
-            x = torch.cat([x[:, -d // 2:], x, x[:, :d // 2]], dim=1)
-            return (x[:, d:] - x[:, :-d]) / (d * h)
-        return (x[:, d:] - x[:, :-d]) / (d * h)
+        return (x[:, d:] - x[:, :-d]) / d / h
+
+    def _reduce(self, v):
+        return v.sqrt().mean() if self.return_norm else v.mean()
+
+    def _orthogonalizer(self, preds_latent):
+        # per latent tensor (N, L, E): mean squared off-diagonal of the Gram matrix (E x E for the global /
+        # galerkin modes, L x L for local / fourier), scaled by delta*h
+        terms = []
+        for y in preds_latent:
+            local = self.orthogonal_mode in ('local', 'fourier')
+            if not local and self.orthogonal_mode not in ('global', 'galerkin', 'linear'):
+                raise ValueError(self.orthogonal_mode)
+            gram = y @ y.transpose(-2, -1) if local else y.transpose(-2, -1) @ y
+            with torch.no_grad():
+                diag = torch.diag_embed(y.pow(2).sum(dim=-1 if local else -2))
+            terms.append(self.delta * (gram - diag).pow(2).mean(dim=(-1, -2)))
+        return self._reduce(torch.stack(terms, dim=-1))
 
     def forward(self, preds, targets, preds_prime=None, targets_prime=None, preds_latent: list = [],
                 K=None):
         h = self.h
         if self.noise > 0:
+            assert 0 <= self.noise <= 0.2
             with torch.no_grad():
                 targets = targets * (1.0 + self.noise * torch.rand_like(targets))
         target_norm = h * targets.pow(2).sum(dim=1)
         targets_prime_norm = h * targets_prime.pow(2).sum(dim=1) if targets_prime is not None else 1
         loss = self.beta * (h * (preds - targets).pow(2)).sum(dim=1) / target_norm
         if preds_prime is not None and self.alpha > 0:
-            kk = 1.0 if K is None else K
-            loss = loss + self.alpha * h * (preds_prime - kk * targets_prime).pow(2).sum(dim=1) \
+            loss = loss + self.alpha * (h * (preds_prime - K * targets_prime).pow(2)).sum(dim=1) \
                 / targets_prime_norm
         if self.metric_reduction == 'L2':
             metric = loss.mean().sqrt().item()
         elif self.metric_reduction == 'L1':
             metric = loss.sqrt().mean().item()
-        else:
+        elif self.metric_reduction == 'Linf':
             metric = loss.sqrt().max().item()
-        loss = loss.sqrt().mean() if self.return_norm else loss.mean()
+        loss = self._reduce(loss)
+        zero = lambda: torch.tensor([0.0], requires_grad=True, device=preds.device)
         if self.regularizer and self.gamma > 0 and targets_prime is not None:
             s = self.dilation // 2
-            diff = self.central_diff(preds)
-            tp = targets_prime if self.periodic else targets_prime[:, s:-s]
-            reg = self.gamma * h * (tp - diff).pow(2).sum(dim=1) / targets_prime_norm
-            reg = reg.sqrt().mean() if self.return_norm else reg.mean()
+            reg = self.gamma * h * (targets_prime[:, s:-s] - self.central_diff(preds)).pow(2).sum(dim=1) \
+                / targets_prime_norm
+            reg = self._reduce(reg)
         else:
-            reg = torch.tensor([0.0], requires_grad=True, device=preds.device)
-        ortho = torch.tensor([0.0], requires_grad=True, device=preds.device)
+            reg = zero()
+        ortho = self._orthogonalizer(preds_latent) if (self.orthogonal_reg > 0 and preds_latent) else zero()
         return loss, reg, ortho, metric
 
 

@@ -21,7 +21,6 @@ from . import _hip as H
 #   "replay"   : multiply by explicit masks queued with push_attention_masks() (mask-replay parity)
 _attn_mode = "reference"
 _attn_masks = []
-_salt = [1]
 
 
 def set_attention_dropout(mode: str):
@@ -41,10 +40,7 @@ def push_attention_masks(masks):
     _attn_masks.extend(masks)
 
 
-def _next_salt(k: int = 4) -> int:
-    s = _salt[0]
-    _salt[0] = (s + k) & 0x7FFFFFFF
-    return s
+_next_salt = H.next_salt        # call-site salt counter (rewound by _hip.set_seed / utils.get_seed)
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -226,6 +222,8 @@ class UpsampleFcFn(Function):
 
 
 def upsample_fc(x_cf, size, weight, bias, grid):
+    if grid.requires_grad:
+        raise NotImplementedError("ops.upsample_fc: `grid` gets no gradient")
     return UpsampleFcFn.apply(x_cf, (int(size[0]), int(size[1])), weight, bias, grid)
 
 
@@ -304,6 +302,8 @@ class LinearFn(Function):
 
 
 def linear(x, weight, bias=None, extra=None, act: str = None, p_drop: float = 0.0):
+    if extra is not None and extra.requires_grad:
+        raise NotImplementedError("ops.linear: `extra` (the concatenated coordinates) gets no gradient")
     return LinearFn.apply(x, weight, bias, extra, H.ACT_CODE[act], float(p_drop))
 
 
@@ -388,6 +388,13 @@ def layer_norm(x, weight, bias, eps):
     return LayerNormFn.apply(x, weight, bias, float(eps))
 
 
+def _check_res_is_x(res, x, what: str):
+    """The fused backward passes return d(res) folded into d(x): only valid when the residual input IS x."""
+    if res is not None and res is not x and not (res.data_ptr() == x.data_ptr() and res.shape == x.shape
+                                                 and res.stride() == x.stride()):
+        raise ValueError(f"ops.{what}: `res` must be the input tensor itself (or None)")
+
+
 # ----------------------------------------------------------------------------------- FFN
 class FeedForwardFn(Function):
     """out = res + dropout2(lr2(dropout_h(act(lr1(x)))))   (layers.py:979-987 + model.py:131-132).
@@ -457,6 +464,7 @@ class FeedForwardFn(Function):
 
 def feed_forward(x, w1, b1, w2, b2, res=None, act="relu", p_h=0.0, p_out=0.0):
     """res must be x itself (or None): the fused backward folds d(res) into d(x)."""
+    _check_res_is_x(res, x, "feed_forward")
     return FeedForwardFn.apply(x, w1, b1, w2, b2, res, H.ACT_CODE[act], float(p_h), float(p_out))
 
 
@@ -484,16 +492,8 @@ class SimpleAttentionFn(Function):
         wq, wf = _c(wqkv), _c(wfc)
         salt = _next_salt(4)
         qkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
-        if "qkvnorm" in H.STAGED and dk in (16, 32, 64):
-            # staged: the head norm rides on the projection's epilogue (GT_EP_HEADNORM), one pass less over [T, 3d]
-            out3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
-            stats = torch.empty(2, T, h, 2, dtype=torch.float32, device=dev)
-            H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv,
-                   hn=dict(gamma=gamma, beta=beta, pos=posc, out=out3, stats=stats, h=h, dk=dk, p=p,
-                           norm_mask=norm_mask, eps=eps))
-        else:
-            H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
-            out3, stats = H.headnorm_fwd(qkv, posc, gamma, beta, T, h, dk, p, norm_mask, eps)
+        H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
+        out3, stats = H.headnorm_fwd(qkv, posc, gamma, beta, T, h, dk, p, norm_mask, eps)
         Qp, Kp, Vp = out3[0], out3[1], out3[2]
         hD = h * DP
         out = torch.empty(T, d, dtype=torch.float32, device=dev)
@@ -575,7 +575,7 @@ class SimpleAttentionFn(Function):
             dwfc = torch.empty(d, h * Dr, dtype=torch.float32, device=dev)
             H.slab_reduce(dWs, B, d * h * Dr, d * h * Dr, dwfc)
             # dK' = V' dM^T ; dV' = K' dM          per (b, head)
-            if "dkv" in H.STAGED and DP in H.FOURIER_DP:
+            if DP in H.FOURIER_DP:                             # one streaming pass (gt_galerkin_dkv)
                 H.galerkin_dkv(Kp, Vp, dM, dO3[1], dO3[2], B, n, h, DP)
             else:
                 H.gemm(Vp, dM, dO3[1], n, DP, DP, lda=hD, ldb=DP, ldc=hD, batch=(B, h), a_bs=(n * hD, DP),
@@ -633,6 +633,7 @@ def simple_attention(x, pos, wqkv, bqkv, gamma, beta, wfc, bfc, *, kind: str, n_
     """Self-attention block; ``res`` must be ``x`` (or None).  Returns (out, attn_weight).  For the Fourier
     type ``need_weights=False`` selects the fused kernel that never materialises the n x n matrix
     (attn_weight is then None); the Galerkin matrix is small and always returned."""
+    _check_res_is_x(res, x, "simple_attention")
     mode = _attn_mode
     mask, p_attn = None, 0.0
     if mode == "reference":

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 6
+#define GT_ABI_VERSION 7
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -151,22 +151,29 @@ typedef struct gt_gemm_desc {
     const float* A2; int64_t lda2, a2_bs0, a2_bs1;
     const float* B2; int64_t ldb2, b2_bs0, b2_bs1;
 
-    /* GT_EP_HEADNORM (STAGED, opt-in via GT_STAGED=qkvnorm in the Python mirror): the packed QKV projection
-     * (layers.py:838-840) with the per-head LayerNorm + position columns of gt_headnorm_fwd fused behind it
-     * (layers.py:841-874).  C [M, N = 3*h*dk] is written as usual (the backward reads the raw projection) and
-     * in the same pass every row's head segments go to hn_out [3][M][h][DP] (normalised where hn_norm_mask
-     * says so, coordinates in columns [0, hn_p), zero pad) and hn_stats [#normed][M][h][2] = (mean, rstd).
-     * dk in {16, 32, 64}, layout_a = layout_b = 0, no batching, no split-K, no other epilogue field but bias. */
-    const float* hn_gamma; const float* hn_beta; const float* hn_pos;
-    float* hn_out; float* hn_stats;
-    int32_t hn_h, hn_dk, hn_p, hn_norm_mask;
-    float hn_eps;
+    /* Arithmetic of the contraction (GT_PREC_*).  Operands, accumulator and result are fp32 in every mode; what
+     * changes is the MFMA instruction the products run on:
+     *   GT_PREC_F32    v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 FMA chain (157 TFLOP/s peak);
+     *   GT_PREC_BF16X3 every operand value is split exactly into three bf16 terms while it is staged
+     *                  (a = h0 + h1 + h2 to 2^-24) and the six plane products down to 2^-16 are accumulated on
+     *                  v_mfma_f32_32x32x16_bf16 in fp32: same rounding class as GT_PREC_F32 (the 1e-5 parity gate
+     *                  holds), 16/6 of its matrix rate;
+     *   GT_PREC_BF16X2 two terms / three products (~2^-16 relative);
+     *   GT_PREC_BF16   operands rounded to bf16, one product: throughput mode with its own (3e-3) gate.
+     * The split kernel serves the plain-epilogue products with M, N >= 96 (whole 128 x 128 tiles); everything else
+     * (fused heads, head-norm epilogue, narrow or tiny problems, the tall-skinny path) stays on the fp32 pipe in
+     * every mode. */
+    int32_t precision;
 } gt_gemm_desc;
+
+#define GT_PREC_F32    0
+#define GT_PREC_BF16X3 1
+#define GT_PREC_BF16X2 2
+#define GT_PREC_BF16   3
 
 #define GT_EP_NORMAL  0
 #define GT_EP_ROWDOT  1
 #define GT_EP_MLP_BWD 2
-#define GT_EP_HEADNORM 3
 
 void    gt_gemm_desc_init(gt_gemm_desc* d);            /* zero + alpha=1, out_scale=1, batch=1 */
 int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d);
@@ -236,9 +243,7 @@ int gt_galerkin_finalize_bwd(const float* dPt, const float* Mt, const float* mas
 
 /* dK'[t] = V'[t] dM^T,  dV'[t] = K'[t] dM  for every token of every (batch, head): the backward of
  * M = K'^T V' (layers.py:723) as one streaming pass over the head tiles [B*n][h][DP] (dM [B,h,DP,DP]).
- * DP in {20, 36, 52}, else GT_ENOTSUP (two batched gt_gemm launches do the same).  STAGED: validated against a
- * lane-accurate CPU model (tests/test_lane_models_cpu.py) but not yet measured on hardware; the Python mirror
- * uses it only when GT_STAGED contains "dkv". */
+ * DP in {20, 36, 52}, else GT_ENOTSUP (two batched gt_gemm launches do the same). */
 int gt_galerkin_dkv(const float* Kp, const float* Vp, const float* dM, float* dKp, float* dVp, int32_t B,
                     int32_t n, int32_t h, int32_t DP, void* stream);
 

@@ -726,9 +726,8 @@ def test_drop_act_fused_equals_chain(H, gpu_device, n, p1, a1, p2, a2):
         assert abs(kept - (1 - p1)) < 0.02
 
 
-@pytest.mark.skipif("dkv" not in os.environ.get("GT_TEST_STAGED", ""), reason="staged kernel: set GT_TEST_STAGED=dkv")
 @pytest.mark.parametrize("B,n,h,DP", [(2, 100, 4, 36), (1, 37, 2, 20), (3, 1849, 4, 36), (1, 64, 1, 52)])
-def test_galerkin_dkv_staged(H, gpu_device, B, n, h, DP):
+def test_galerkin_dkv(H, gpu_device, B, n, h, DP):
     """gt_galerkin_dkv against fp64 (and thereby against the two batched GEMMs it would replace)."""
     dev = gpu_device
     Kp = rnd(B * n, h, DP, dev=dev, seed=100)
@@ -742,66 +741,128 @@ def test_galerkin_dkv_staged(H, gpu_device, B, n, h, DP):
     assert rel_l2(dV.reshape(B, n, h, DP), torch.einsum("bnhk,bhkc->bnhc", K4, dM.double())) < KTOL
 
 
-@pytest.mark.skipif("qkvnorm" not in os.environ.get("GT_TEST_STAGED", ""), reason="staged kernel: set GT_TEST_STAGED=qkvnorm")
-@pytest.mark.parametrize("T,h,dk,p,mask", [(1000, 4, 32, 2, 0b110), (333, 2, 64, 1, 0b011), (4099, 8, 16, 2, 0b110),
-                                           (257, 4, 32, 0, 0b000)])
-def test_qkv_headnorm_epilogue_staged(H, gpu_device, T, h, dk, p, mask):
-    """GT_EP_HEADNORM: projection + per-head LayerNorm in one launch == gt_gemm followed by gt_headnorm_fwd."""
-    dev = gpu_device
-    d = h * dk
-    x = rnd(T, d, dev=dev, seed=110)
-    w = rnd(3 * d, d, dev=dev, seed=111, scale=0.2)
-    b = rnd(3 * d, dev=dev, seed=112)
-    gamma = 1 + 0.1 * rnd(2, h, dk, dev=dev, seed=113)
-    beta = 0.1 * rnd(2, h, dk, dev=dev, seed=114)
-    pos = rnd(T, p, dev=dev, seed=115) if p else None
-    eps = 1e-7
-    qkv = torch.empty(T, 3 * d, device=dev)
-    H.gemm(x, w, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b)
-    out_ref, st_ref = H.headnorm_fwd(qkv, pos, gamma, beta, T, h, dk, p, mask, eps)
-    DP = H.round4(dk + p)
-    qkv2 = torch.full_like(qkv, float("nan"))
-    out3 = torch.full((3, T, h, DP), float("nan"), device=dev)
-    stats = torch.zeros(2, T, h, 2, device=dev)
-    H.gemm(x, w, qkv2, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b,
-           hn=dict(gamma=gamma, beta=beta, pos=pos, out=out3, stats=stats, h=h, dk=dk, p=p, norm_mask=mask, eps=eps))
-    torch.cuda.synchronize()
-    assert torch.equal(qkv2, qkv)
-    assert rel_l2(out3, out_ref) < 1e-6
-    nn = bin(mask).count("1")
-    if nn:
-        assert rel_l2(stats[:nn], st_ref[:nn]) < 1e-6
+# ----------------------------------------------------------------------------- split-operand bf16 kernel
+X3_TOL = {"f32": 2e-6, "bf16x3": 2e-6, "bf16x2": 2e-4, "bf16": 2e-2}
 
 
-@pytest.mark.skipif("wsgemm" not in os.environ.get("GT_TEST_STAGED", "") or "wsgemm" not in os.environ.get("GT_STAGED", ""),
-                    reason="staged kernel: run with GT_STAGED=wsgemm GT_TEST_STAGED=wsgemm")
-@pytest.mark.parametrize("lb,M,N,ep", [(0, 8192 + 40, 384, "bias"), (0, 4096, 256, "relu_drop"), (1, 5000, 256, "plain"),
-                                       (0, 3000, 128, "res")])
-def test_gemm_ws_staged(H, gpu_device, lb, M, N, ep):
-    """gemm_ws_kernel (weight-stationary K = 128) against fp64, with the epilogues the token GEMMs use."""
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x2", "bf16"])
+@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (128, 128, 16), (1000, 256, 130), (257, 131, 77), (96, 200, 1849)])
+def test_gemm_x3_layouts(H, gpu_device, prec, la, lb, M, N, K):
+    """gemm_x3_kernel (fp32 operands split into bf16 planes, fp32 accumulate) against fp64: every layout, ragged
+    edges in M, N and K, unaligned leading dimensions (scalar loader path)."""
     dev = gpu_device
-    K = 128
-    A = rnd(M, K, dev=dev, seed=120)
-    Bm = rnd(N, K, dev=dev, seed=121, scale=0.2) if lb == 0 else rnd(K, N, dev=dev, seed=121, scale=0.2)
-    assert "gemm_ws_kernel" in H.gemm_kernel_name(A, Bm, M, N, K, layout_b=lb, lda=K, ldb=(K if lb == 0 else N), ldc=N)
+    A = rnd(M, K, dev=dev, seed=201) if la == 0 else rnd(K, M, dev=dev, seed=201)
+    B = rnd(N, K, dev=dev, seed=202) if lb == 0 else rnd(K, N, dev=dev, seed=202)
+    assert "gemm_x3_kernel" in H.gemm_kernel_name(A, B, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1],
+                                                  ldb=B.shape[1], ldc=N, precision=prec)
     Cc = torch.full((M, N), float("nan"), device=dev)
-    ref = A.double() @ (Bm.double().t() if lb == 0 else Bm.double())
-    kw = {}
-    if ep == "bias":
-        b = rnd(N, dev=dev, seed=122)
-        kw["bias"] = b
-        ref = ref + b.double()
-    elif ep == "relu_drop":
-        H.set_seed(5, dev)
-        d = H.dropout_desc(0.1, 3, dev)
-        b = rnd(N, dev=dev, seed=122)
-        kw.update(bias=b, act=H.ACT_RELU, drop=d)
-        mask = H.dropout_apply(torch.ones(M * N, device=dev), d).reshape(M, N).double()
-        ref = torch.relu(ref + b.double()) * mask
-    elif ep == "res":
-        r = rnd(M, N, dev=dev, seed=123)
-        kw.update(res=r, ldr=N)
-        ref = ref + r.double()
-    H.gemm(A, Bm, Cc, M, N, K, layout_b=lb, lda=K, ldb=(K if lb == 0 else N), ldc=N, **kw)
+    H.gemm(A, B, Cc, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1], ldb=B.shape[1], ldc=N, precision=prec)
     torch.cuda.synchronize()
-    assert rel_l2(Cc, ref) < KTOL
+    assert rel_l2(Cc, ref_mm(A, B, la, lb)) < X3_TOL[prec]
+
+
+def test_gemm_x3_identity_exact(H, gpu_device):
+    """The three-plane split is exact (a = h0 + h1 + h2 bit for bit), so I * B must come back unchanged, and an
+    asymmetric B catches a transposed accumulator map of the 32x32 MFMA."""
+    dev = gpu_device
+    n = 256
+    A = torch.eye(n, device=dev)
+    B = (torch.arange(n * n, device=dev, dtype=torch.float32).reshape(n, n) % 97) / 7.0 + 1e-3 * rnd(n, n, dev=dev, seed=203)
+    Cc = torch.empty(n, n, device=dev)
+    H.gemm(A, B, Cc, n, n, n, lda=n, ldb=n, ldc=n, precision="bf16x3")
+    torch.cuda.synchronize()
+    assert torch.equal(Cc, B.t().contiguous())
+
+
+def test_gemm_x3_precision_ladder(H, gpu_device):
+    """Error against fp64 must fall by ~2^-8 per extra plane: bf16 ~ 3e-3, bf16x2 ~ 1e-5, bf16x3 ~ fp32 MFMA."""
+    dev = gpu_device
+    M, N, K = 512, 256, 512
+    A, B = rnd(M, K, dev=dev, seed=204), rnd(N, K, dev=dev, seed=205)
+    ref = ref_mm(A, B, 0, 0)
+    err = {}
+    for prec in ("f32", "bf16x3", "bf16x2", "bf16"):
+        Cc = torch.empty(M, N, device=dev)
+        H.gemm(A, B, Cc, M, N, K, lda=K, ldb=K, ldc=N, precision=prec)
+        torch.cuda.synchronize()
+        err[prec] = rel_l2(Cc, ref)
+    print("x3 precision ladder:", err)
+    assert err["bf16"] < 1e-2 and err["bf16x2"] < 1e-4 and err["bf16x3"] < 1e-6
+    assert err["bf16x3"] < 4 * err["f32"] + 1e-7
+    assert err["bf16x2"] < err["bf16"] / 50
+
+
+@pytest.mark.parametrize("split", [0, 3, 16])
+def test_gemm_x3_split_k_colsum(H, gpu_device, split):
+    """Weight-gradient use: A^T B with K = tokens, split-K slabs, bias gradient (row sums of A) as a by-product."""
+    dev = gpu_device
+    M, N, K = 384, 128, 5000
+    A, B = rnd(K, M, dev=dev, seed=206), rnd(K, N, dev=dev, seed=207)
+    Cc, cs = torch.empty(M, N, device=dev), torch.empty(M, device=dev)
+    H.gemm(A, B, Cc, M, N, K, layout_a=1, layout_b=1, lda=M, ldb=N, ldc=N, split_k=split, alpha=0.5, a_colsum=cs,
+           precision="bf16x3")
+    torch.cuda.synchronize()
+    assert rel_l2(Cc, 0.5 * (A.double().t() @ B.double())) < KTOL
+    assert rel_l2(cs, A.double().sum(0)) < KTOL
+
+
+def test_gemm_x3_epilogues_batched(H, gpu_device):
+    """Per-sample batched product with bias + dropout + residual + out_scale (the Galerkin Q'P launch), and the
+    FFN input-gradient epilogue (aux > 0 mask), on the split kernel; same seed => the mask of the fp32 kernel."""
+    dev = gpu_device
+    Bn, n, hD, d = 3, 700, 144, 128
+    Q, P, b = rnd(Bn, n, hD, dev=dev, seed=208), rnd(Bn, hD, d, dev=dev, seed=209, scale=0.2), rnd(d, dev=dev, seed=210)
+    R = rnd(Bn, n, d, dev=dev, seed=211)
+    outs = {}
+    for prec in ("f32", "bf16x3"):
+        out = torch.empty(Bn, n, d, device=dev)
+        H.gemm(Q, P, out, n, d, hD, layout_b=1, lda=hD, ldb=d, ldc=d, batch=(Bn, 1), a_bs=(n * hD, 0), b_bs=(hD * d, 0),
+               c_bs=(n * d, 0), bias=b, drop=H.dropout_desc(0.3, 77, dev), res=R, ldr=d, r_bs=(n * d, 0), out_scale=-1.0,
+               precision=prec)
+        outs[prec] = out
+    torch.cuda.synchronize()
+    assert rel_l2(outs["bf16x3"], outs["f32"]) < KTOL
+    plain = torch.empty(Bn, n, d, device=dev)
+    H.gemm(Q, P, plain, n, d, hD, layout_b=1, lda=hD, ldb=d, ldc=d, batch=(Bn, 1), a_bs=(n * hD, 0), b_bs=(hD * d, 0),
+           c_bs=(n * d, 0), bias=b, precision="bf16x3")
+    torch.cuda.synchronize()
+    assert rel_l2(plain, torch.einsum("bnk,bkd->bnd", Q.double(), P.double()) + b.double()) < KTOL
+    T, f = 1000, 256
+    g, W2, hid = rnd(T, d, dev=dev, seed=212), rnd(d, f, dev=dev, seed=213, scale=0.2), rnd(T, f, dev=dev, seed=214)
+    gh = torch.empty(T, f, device=dev)
+    H.gemm(g, W2, gh, T, f, d, layout_b=1, lda=d, ldb=f, ldc=f, aux_op=H.AUX_GT0, aux=hid, ldaux=f, aux_scale=1.25,
+           precision="bf16x3")
+    torch.cuda.synchronize()
+    assert rel_l2(gh, (g.double() @ W2.double()) * (hid.double() > 0) * 1.25) < KTOL
+
+
+def test_gemm_x3_second_product_width_split(H, gpu_device):
+    """Second accumulated product (K2) on a width that gt_gemm splits into 128-aligned part + remainder: the
+    remainder launch must read B2's own columns (B2 was not offset)."""
+    dev = gpu_device
+    M, N, K, K2 = 70000, 160, 48, 32
+    A, B = rnd(M, K, dev=dev, seed=215), rnd(K, N, dev=dev, seed=216)
+    A2, B2 = rnd(M, K2, dev=dev, seed=217), rnd(K2, N, dev=dev, seed=218)
+    ref = A.double() @ B.double() + A2.double() @ B2.double()
+    for prec in ("f32", "bf16x3"):
+        Cc = torch.full((M, N), float("nan"), device=dev)
+        H.gemm(A, B, Cc, M, N, K, layout_b=1, lda=K, ldb=N, ldc=N, K2=K2, A2=A2, lda2=K2, B2=B2, ldb2=N, precision=prec)
+        torch.cuda.synchronize()
+        assert rel_l2(Cc, ref) < KTOL, prec
+
+
+def test_gemm_x3_a_dropout_matches_f32_kernel(H, gpu_device):
+    dev = gpu_device
+    M, N, K = 400, 256, 300
+    outs = {}
+    for la in (0, 1):
+        A = rnd(M, K, dev=dev, seed=219) if la == 0 else rnd(K, M, dev=dev, seed=219)
+        B = rnd(N, K, dev=dev, seed=220)
+        for prec in ("f32", "bf16x3"):
+            Cc = torch.empty(M, N, device=dev)
+            H.gemm(A, B, Cc, M, N, K, layout_a=la, lda=A.shape[1], ldb=K, ldc=N, a_drop=H.dropout_desc(0.25, 5, dev),
+                   a_drop_sign=-1.0, a_drop_ld=A.shape[1], precision=prec)
+            outs[prec] = Cc
+        torch.cuda.synchronize()
+        assert rel_l2(outs["bf16x3"], outs["f32"]) < KTOL

@@ -64,75 +64,6 @@ def test_galerkin_dkv_lane_map(G, n):
     assert np.allclose(dV, K @ dM, atol=1e-10)
 
 
-@pytest.mark.parametrize("h,dk,pp,mask", [(4, 32, 2, 0b110), (2, 64, 1, 0b011), (8, 16, 2, 0b110), (4, 32, 0, 0b000)])
-def test_headnorm_epilogue_lane_map(h, dk, pp, mask):
-    """headnorm_scatter (gt_gemm.hip, GT_EP_HEADNORM): the epilogue lane (li, kq) of a 64x64 wave tile holds rows
-    mw0 + MT*(4kq + r) + s and the 4 columns nb .. nb+3; head statistics are xor-shuffles inside dk/4-lane groups."""
-    MT, NT, eps = 4, 4, 1e-7
-    N, DP = 3 * h * dk, (dk + pp + 3) & ~3
-    M = 64 * 2
-    rng = np.random.default_rng(h * dk)
-    V = rng.standard_normal((M, N))
-    gamma, beta = rng.standard_normal((3, h, dk)), rng.standard_normal((3, h, dk))
-    pos = rng.standard_normal((M, max(pp, 1)))
-    out = np.full((3, M, h, DP), np.nan)
-    stats = np.full((3, M, h, 2), np.nan)
-    li, kq = S.X, S.KQ
-    G = dk // 4
-    for mw0 in range(0, M, 16 * MT):                  # wave tiles: 64 rows x 64 columns
-        for n0 in range(0, N, 16 * NT):
-            nb = n0 + NT * li                          # per lane
-            for s in range(MT):
-                for r in range(4):
-                    m = mw0 + MT * (4 * kq + r) + s    # per lane
-                    v = V[m[:, None], nb[:, None] + np.arange(4)]            # [64, 4]
-                    stream, head, dim = nb // (h * dk), (nb // dk) % h, nb % dk
-                    normed = (mask >> stream) & 1
-                    ni = np.array([bin(mask & ((1 << st) - 1)).count("1") for st in stream])
-                    y = v.copy()
-                    tot = v.sum(1)
-                    o = G >> 1
-                    while o > 0:
-                        tot = tot + tot[S.LANES ^ o]
-                        o >>= 1
-                    mu = tot / dk
-                    c = v - mu[:, None]
-                    ss = (c * c).sum(1)
-                    o = G >> 1
-                    while o > 0:
-                        ss = ss + ss[S.LANES ^ o]
-                        o >>= 1
-                    rstd = 1.0 / np.sqrt(ss / dk + eps)
-                    for l in range(64):
-                        if normed[l]:
-                            gm = gamma[ni[l], head[l], dim[l]:dim[l] + 4]
-                            bt = beta[ni[l], head[l], dim[l]:dim[l] + 4]
-                            y[l] = c[l] * rstd[l] * gm + bt
-                            if dim[l] == 0:
-                                stats[ni[l], m[l], head[l]] = (mu[l], rstd[l])
-                        out[stream[l], m[l], head[l], pp + dim[l]:pp + dim[l] + 4] = y[l]
-                        if dim[l] == 0:
-                            out[stream[l], m[l], head[l], :pp] = pos[m[l], :pp]
-                        if dim[l] == dk - 4:
-                            out[stream[l], m[l], head[l], pp + dk:] = 0.0
-    # reference: per-head LayerNorm of the packed projection, coordinates in front, zero pad
-    X = V.reshape(M, 3, h, dk)
-    ref = np.zeros((3, M, h, DP))
-    nidx = 0
-    for st in range(3):
-        x = X[:, st]
-        if (mask >> st) & 1:
-            mu = x.mean(-1, keepdims=True)
-            var = ((x - mu) ** 2).mean(-1, keepdims=True)
-            x = (x - mu) / np.sqrt(var + eps) * gamma[nidx] + beta[nidx]
-            assert np.allclose(stats[nidx, :, :, 0], mu[..., 0]) and np.allclose(stats[nidx, :, :, 1], 1 / np.sqrt(var[..., 0] + eps))
-            nidx += 1
-        ref[st, :, :, pp:pp + dk] = x
-        ref[st, :, :, :pp] = pos[:, None, :pp]
-    assert not np.isnan(out).any()
-    assert np.allclose(out, ref, atol=1e-10)
-
-
 @pytest.mark.parametrize("MP,N,K", [(1, 2, 37), (1, 32, 64), (4, 32, 23)])
 def test_tsmm_lane_map(MP, N, K):
     """tsmm_kernel (gt_tsmm.hip): one float2 per lane feeds an even-column and an odd-column tile."""
@@ -317,73 +248,3 @@ def test_dft_analysis_lane_map(n, P):
                 prr = min(16 * mt + 4 * kq[l] + r, P - 1)
                 Y[prr, 16 * nt + j[l]] = acc[0][l, r] + acc[1][l, r]
     assert np.allclose(Y, F.T @ X, atol=1e-9)
-
-
-@pytest.mark.parametrize("LB,M,N", [(0, 96, 128), (1, 70, 64)])
-def test_gemm_ws_lane_map(LB, M, N):
-    """gemm_ws_kernel (gt_gemm.hip, staged): swizzled [row][128] LDS images, k = 16 g8 + 4 kq + c on both operands,
-    row/column assignment of gemm_epilogue<1, 2> (rows mw0 + 4kq + r, columns nb + t with nb = n0 + 32 wn + 2 li)."""
-    K = 128
-    rng = np.random.default_rng(LB + M)
-    A = rng.standard_normal((M, K))
-    Bm = rng.standard_normal((N, K)) if LB == 0 else rng.standard_normal((K, N))    # B(k, n)
-    Bkn = Bm.T if LB == 0 else Bm
-    li, kq = S.X, S.KQ
-    C = np.full((M, N), np.nan)
-    for slice_ in range(N // 64):
-        n0 = slice_ * 64
-        sB = np.zeros(64 * 128)
-        if LB == 0:
-            for e in range(64 * 32):
-                n, g = e >> 5, (e & 31) ^ ((e >> 5) & 7)
-                sB[4 * e:4 * e + 4] = Bm[n0 + n, 4 * g:4 * g + 4]
-        else:
-            for e in range(64 * 128):
-                k, n = e // 64, e % 64
-                sB[(n * 32 + ((k >> 2) ^ (n & 7))) * 4 + (k & 3)] = Bm[k, n0 + n]
-        for tile in range((M + 31) // 32):
-            m0 = tile * 32
-            sA = np.zeros(32 * 128)
-            for e in range(1024):                         # direct-load image, zero16 beyond M
-                r, g = e >> 5, (e & 31) ^ ((e >> 5) & 7)
-                if m0 + r < M:
-                    sA[4 * e:4 * e + 4] = A[m0 + r, 4 * g:4 * g + 4]
-            for wave in range(4):
-                wm, wn = wave >> 1, wave & 1
-                arow = wm * 16 + li
-                bcol = wn * 32 + 2 * li
-                acc = [np.zeros((64, 4)), np.zeros((64, 4))]
-                for g8 in range(8):
-                    G = 4 * g8 + kq
-                    ia = (arow * 32 + (G ^ (arow & 7))) * 4
-                    ib0 = (bcol * 32 + (G ^ (bcol & 7))) * 4
-                    ib1 = ((bcol + 1) * 32 + (G ^ ((bcol + 1) & 7))) * 4
-                    for c in range(4):
-                        acc[0] = S.mfma(sA[ia + c], sB[ib0 + c], acc[0])
-                        acc[1] = S.mfma(sA[ia + c], sB[ib1 + c], acc[1])
-                mw0, nb = m0 + wm * 16, n0 + wn * 32 + 2 * li
-                for l in range(64):
-                    for r in range(4):
-                        m = mw0 + 1 * (4 * kq[l] + r) + 0
-                        if m < M:
-                            for t in range(2):
-                                C[m, nb[l] + t] = acc[t][l, r]
-    assert np.allclose(C, A @ Bkn, atol=1e-9)
-
-
-def test_gemm_ws_grid_decomposition():
-    """Every (slice, 32-row tile) is visited exactly once, and the slice blocks that share a y group sit on one XCD."""
-    for N, M in ((384, 236672), (256, 4096), (64, 2048 + 5)):
-        slices = N // 64
-        per_xcd = max(1, 64 // slices)
-        blocks, ygroups = 8 * per_xcd * slices, 8 * per_xcd
-        mtiles = (M + 31) // 32
-        seen = {}
-        for L in range(blocks):
-            xcd, q = L & 7, L >> 3
-            slice_, ygrp = q % slices, (q // slices) * 8 + xcd
-            assert ygrp < ygroups and ygrp % 8 == xcd
-            for tile in range(ygrp, mtiles, ygroups):
-                assert (slice_, tile) not in seen
-                seen[(slice_, tile)] = L
-        assert len(seen) == slices * mtiles
