@@ -3,17 +3,20 @@
 (BASELINE.json configs[1]: ex2_darcy.py FourierTransformer2D, 6 x (d=128, 4 heads, d_k'=34) encoder
 layers on the 43x43 coarse grid, two SpectralConv2d decoder layers at 141x141).
 
-    python bench.py --gpus N --steps K --warmup W [--batch B_per_gpu]
+    python bench.py --gpus N --steps K --warmup W [--batch B_per_gpu] [--scaling weak|strong --global-batch G]
+                    [--workload ...] [--loss mse|weighted_l2] [--precision bf16x3|f32|bf16x2|bf16]
 
-A step = forward + MSE loss + backward + (gradient all-reduce) + clip_grad_norm_(0.99) + Adam on one
-batch of synthetic tensors already resident in HBM (the recipe of the reference's
-examples/ex2_memory_profile.py:58-71 plus the optimizer of examples/ex2_darcy.py).  Every dropout of
-config.yml:ex2_darcy is active (train mode), including the reference's always-on p=0.5 attention
-dropout.  fp32 throughout (the reference's arithmetic; the 1e-5 parity gate holds in this mode).
+A step = forward + loss + backward + (gradient all-reduce) + clip_grad_norm_(0.99) + Adam on one batch of
+synthetic tensors already resident in HBM (the recipe of the reference's examples/ex2_memory_profile.py:58-71
+plus the optimizer of examples/ex2_darcy.py).  Every dropout of config.yml is active (train mode), including
+the reference's always-on p=0.5 attention dropout.  Operands, accumulators and results are fp32; the contractions
+run in the library's default arithmetic (``bf16x3``: fp32 operands split exactly into three bf16 terms, six plane
+products on the bf16 MFMA pipe, fp32 accumulation -- the mode the 1e-5 parity tests run in); ``--precision f32``
+selects the bit-exact fp32 MFMA kernels, and the default run reports both.
 
-One process per GPU (launched by torch.distributed.run for N>1), batch-sharded data parallel:
-per-GPU batch fixed (weak scaling), one flat gradient all-reduce over RCCL per step.
-Rank 0 prints ONE JSON line (see the bench contract in the task statement).
+One process per GPU (launched by torch.distributed.run for N>1), batch-sharded data parallel: the per-GPU batch is
+fixed (``--scaling weak``, the default) or the global batch is (``--scaling strong --global-batch G``); one flat
+gradient all-reduce over RCCL per step.  Rank 0 prints ONE JSON line (see the bench contract in the task statement).
 """
 import argparse
 import json
@@ -30,18 +33,22 @@ import torch.distributed as dist
 
 N_FINE, N_COARSE = 141, 43          # 421 grid subsampled by 3 / by 10 (ex2_darcy.py defaults)
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBS = 8000.0
+PLANE_PRODUCTS = {"bf16x3": 6, "bf16x2": 3, "bf16": 1}
 
 
 # name -> (config.yml section, fine subsample, coarse subsample, config overrides, where the target lives)
 # The headline (BASELINE.json configs[1]) is ex2_darcy141; the others are informational end-to-end runs of
-# the remaining 2-D configurations through the same training step.
+# the remaining BASELINE configurations through the same training step.
 WORKLOADS = {
     "ex2_darcy141": ("ex2_darcy", 3, 10, dict(), "fine"),
     "ex2_darcy211_fourier": ("ex2_darcy", 2, 7, dict(attention_type="fourier", xavier_init=0.001), "fine"),
     "ex3_darcy_inv": ("ex3_darcy_inv", 3, 12, dict(), "coarse"),
+    "ex4_ns": None,                  # FourierTransformer2DLite, 64x64, 10-step rollout (ns_lite.py:205-238)
+    "ex1_burgers": None,             # SimpleTransformer, n = 8192, d_model 64, 4 heads (BASELINE configs[0])
 }
-
+DEFAULT_BATCH = {"ex2_darcy141": 128, "ex2_darcy211_fourier": 8, "ex3_darcy_inv": 128, "ex4_ns": 16, "ex1_burgers": 32}
 
 WORKLOAD_TEXT = {
     "ex2_darcy141": "ex2_darcy FourierTransformer2D 141x141 fine / 43x43 coarse, galerkin, "
@@ -49,7 +56,11 @@ WORKLOAD_TEXT = {
     "ex2_darcy211_fourier": "ex2_darcy FourierTransformer2D 211x211 fine / 61x61 coarse, fourier (QK^T)V, "
                             "6 layers d=128 h=4 ffn=256, 2x SpectralConv2d(32, modes 12) [informational]",
     "ex3_darcy_inv": "ex3_darcy_inv FourierTransformer2D 141x141 -> 36x36, galerkin, 6 layers d=192 h=4 ffn=384, "
-                     "pointwise decoder [informational]",
+                     "pointwise decoder, input noise 0.1 [informational]",
+    "ex4_ns": "ex4 FourierTransformer2DLite 64x64, galerkin 1 head d=48 (LayerNorm, no per-head norm), 4 layers, "
+              "2x SpectralConv2d(20, modes 12); one step = 10-step autoregressive rollout + one backward [informational]",
+    "ex1_burgers": "ex1_burgers SimpleTransformer n=8192, galerkin, 4 layers d=64 h=4 ffn=128, 2x SpectralConv1d "
+                   "[informational]",
 }
 
 
@@ -72,56 +83,165 @@ def darcy_config(workload="ex2_darcy141"):
     return cfg
 
 
+def ns_config():
+    """examples/ex4_navier_stokes_2+1d.py:29-58."""
+    return dict(node_feats=10 + 2, pos_dim=2, n_targets=1, n_hidden=48, num_feat_layers=0, num_encoder_layers=4,
+                n_head=1, dim_feedforward=96, attention_type="galerkin", feat_extract_type=None, xavier_init=0.01,
+                diagonal_weight=0.01, layer_norm=True, attn_norm=False, return_attn_weight=False,
+                return_latent=False, decoder_type="ifft", freq_dim=20, num_regressor_layers=2, fourier_modes=12,
+                spacial_dim=2, spacial_fc=False, dropout=0.0, encoder_dropout=0.0, decoder_dropout=0.0,
+                ffn_dropout=0.05, debug=False)
+
+
+def burgers_config():
+    """config.yml:ex1_burgers with the BASELINE.json configs[0] override (galerkin, d_model 64, 4 heads)."""
+    import yaml
+    with open(os.path.join(ROOT, "galerkin-transformer_amd", "config.yml")) as f:
+        cfg = yaml.full_load(f)["ex1_burgers"]
+    cfg.update(attention_type="galerkin", n_hidden=64, n_head=4, dim_feedforward=128)
+    return cfg
+
+
+def build_model(workload):
+    import galerkin_transformer as gt
+    if workload == "ex4_ns":
+        cfg = ns_config()
+        return gt.FourierTransformer2DLite(**cfg), cfg
+    if workload == "ex1_burgers":
+        cfg = burgers_config()
+        return gt.SimpleTransformer(**cfg), cfg
+    cfg = darcy_config(workload)
+    return gt.FourierTransformer2D(**cfg), cfg
+
+
+def _central_diff2d(u, h):
+    """(B, n, n, 1) -> (B, n, n, 2): dilation-2 central differences on the zero-padded field (what the datasets
+    store as target_grad)."""
+    import torch.nn.functional as F
+    p = F.pad(u[..., 0], (1, 1, 1, 1))
+    gx = (p[:, 2:, 1:-1] - p[:, :-2, 1:-1]) / 2
+    gy = (p[:, 1:-1, 2:] - p[:, 1:-1, :-2]) / 2
+    return torch.stack([gx, gy], dim=-1) / h
+
+
 def synthetic_batch(B, device, seed, workload="ex2_darcy141"):
+    """Dict of HBM-resident tensors of the workload's shapes (randn fields on the true grids)."""
     from galerkin_transformer.ft import DarcyDataset
-    _, sf, sc, _, where = WORKLOADS[workload]
-    n_f, n_t = _n(sf), (_n(sf) if where == "fine" else _n(sc))
     g = torch.Generator().manual_seed(seed)
-    node = torch.randn(B, n_f, n_f, 1, generator=g)
-    target = torch.randn(B, n_t, n_t, 1, generator=g)
-    pos = torch.from_numpy(DarcyDataset.get_grid(421, subsample=sc, return_elem=False)).float()
-    grid = torch.from_numpy(DarcyDataset.get_grid(421, subsample=(sf if where == "fine" else sc),
-                                                  return_elem=False)).float()
-    pos = pos.reshape(1, -1, 2).repeat(B, 1, 1)
-    grid = grid.unsqueeze(0).repeat(B, 1, 1, 1)
-    return [t.to(device).contiguous() for t in (node, pos, grid, target)]
+    if workload == "ex4_ns":
+        n = 64
+        ax = torch.linspace(0, 1, n)
+        gx, gy = torch.meshgrid(ax, ax, indexing="xy")
+        grid = torch.stack([gx, gy], -1)
+        x, u = torch.randn(B, n, n, 10, generator=g), torch.randn(B, n, n, 10, generator=g)
+        gradu = torch.stack([_central_diff2d(u[..., t:t + 1], 1 / n) for t in range(10)], dim=-1)
+        out = dict(node=x, pos=grid.reshape(1, -1, 2).repeat(B, 1, 1), grid=grid.unsqueeze(0).repeat(B, 1, 1, 1),
+                   target=u, target_grad=gradu)
+    elif workload == "ex1_burgers":
+        n = 8192
+        pos = torch.linspace(0, 1, n)[None, :, None].repeat(B, 1, 1)
+        out = dict(node=torch.randn(B, n, 1, generator=g), pos=pos, grid=pos.clone(),
+                   target=torch.randn(B, n, 1, generator=g))
+    else:
+        _, sf, sc, _, where = WORKLOADS[workload]
+        n_f, n_t = _n(sf), (_n(sf) if where == "fine" else _n(sc))
+        node = torch.randn(B, n_f, n_f, 1, generator=g)
+        target = torch.randn(B, n_t, n_t, 1, generator=g)
+        if workload == "ex3_darcy_inv":                  # ex3_darcy_inv.py --noise 0.1: noisy measurements in
+            node = node + 0.1 * torch.randn(B, n_f, n_f, 1, generator=g)
+        pos = torch.from_numpy(DarcyDataset.get_grid(421, subsample=sc, return_elem=False)).float()
+        grid = torch.from_numpy(DarcyDataset.get_grid(421, subsample=(sf if where == "fine" else sc),
+                                                      return_elem=False)).float()
+        out = dict(node=node, pos=pos.reshape(1, -1, 2).repeat(B, 1, 1), grid=grid.unsqueeze(0).repeat(B, 1, 1, 1),
+                   target=target, target_grad=_central_diff2d(target, 1.0 / n_t),
+                   coeff=torch.rand(B, n_t, n_t, 1, generator=g) + 0.5)
+    return {k: v.to(device).contiguous() for k, v in out.items()}
+
+
+def make_loss(workload, kind):
+    """batch, model -> scalar loss tensor, with no host read-back (the step is captured into a HIP graph).
+    mse: the reference profilers' objective (ex2_memory_profile.py:58-71).  weighted_l2: the training objective of
+    the example scripts, WeightedL2Loss2d(regularizer=True, h, gamma) loss + regulariser (ex2_darcy.py:118,
+    utils_ft.py:656-681; ns_lite.py:205-238 for the rollout)."""
+    from galerkin_transformer.ft import WeightedL2Loss2d
+    if workload == "ex4_ns":
+        lf = WeightedL2Loss2d(regularizer=True, h=1 / 64, gamma=0.1)
+
+        def rollout(model, b):
+            x, total = b["node"], 0
+            for t in range(x.size(-1)):
+                up = model(x, None, pos=b["pos"], grid=b["grid"])["preds"]
+                if kind == "mse":
+                    total = total + ((up[..., 0] - b["target"][..., t]) ** 2).mean()
+                else:
+                    l, r, _ = lf.terms(up[..., 0], b["target"][..., t], targets_prime=b["target_grad"][..., t])
+                    total = total + lf.reduce(l) + lf.reduce(r)
+                x = torch.cat((x[..., 1:], up), dim=-1)
+            return total
+        return rollout
+    if workload == "ex1_burgers":
+        if kind != "mse":
+            raise SystemExit("--loss weighted_l2 is implemented for the 2-D workloads")
+        return lambda model, b: ((model(b["node"], None, b["pos"], b["grid"])["preds"][..., :1] - b["target"]) ** 2).mean()
+    if kind == "mse":
+        return lambda model, b: ((model(b["node"], None, b["pos"], b["grid"])["preds"] - b["target"]) ** 2).mean()
+    gamma = 0.5                                           # examples/ex2_darcy.py default --gamma
+
+    def wl2(model, b):
+        out = model(b["node"], None, b["pos"], b["grid"])["preds"]
+        lf = WeightedL2Loss2d(regularizer=True, h=1.0 / b["target"].shape[1], gamma=gamma)
+        l, r, _ = lf.terms(out[..., 0], b["target"][..., 0], targets_prime=b["target_grad"], K=b["coeff"])
+        return lf.reduce(l) + lf.reduce(r)
+    return wl2
 
 
 class Trainer:
-    """fwd+loss+bwd | all-reduce | clip+Adam, each compute leg captured in a HIP graph."""
+    """fwd+loss+bwd(+grad gather) | all-reduce | clip+Adam, each compute leg captured in a HIP graph."""
 
-    def __init__(self, model, batch, world, lr=1e-3, clip=0.99, use_graph=True):
+    def __init__(self, model, batch, world, lr=1e-3, clip=0.99, use_graph=True, workload="ex2_darcy141", loss="mse",
+                 optimizer="flat"):
+        import galerkin_transformer as gt
         from galerkin_transformer import _hip
         self._hip = _hip
         self.model, self.world, self.clip = model, world, clip
-        self.node, self.pos, self.grid, self.target = batch
+        self.batch = batch if isinstance(batch, dict) else dict(zip(("node", "pos", "grid", "target"), batch))
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.dev = self.node.device
-        try:
+        self.dev = self.batch["node"].device
+        self.loss_fn = make_loss(workload, loss)
+        self.flat = optimizer == "flat"
+        if self.flat:
+            self.opt = gt.FlatClipAdam(self.params, lr=lr, max_norm=clip)
+            self.opt_kind = "FlatClipAdam (gt_grad_sqnorm + gt_adam_clip_step on one flat bucket)"
+            self.reducer = None
+        else:
             self.opt = torch.optim.Adam(self.params, lr=lr, capturable=True, fused=True)
-            self.opt_kind = "adam(fused,capturable)"
-        except Exception:
-            self.opt = torch.optim.Adam(self.params, lr=lr, capturable=True, foreach=True)
-            self.opt_kind = "adam(foreach,capturable)"
+            self.opt_kind = "torch clip_grad_norm_(foreach) + adam(fused,capturable)"
+            from galerkin_transformer.distributed import FlatGradAllReducer
+            self.reducer = FlatGradAllReducer(self.params)
         self.loss = torch.zeros((), device=self.dev)
         self.g_fb = self.g_opt = None
         self.use_graph = use_graph
-        from galerkin_transformer.distributed import FlatGradAllReducer
-        self.reducer = FlatGradAllReducer(self.params)
 
     def fwd_bwd(self):
         self._hip.advance_seed(self.dev)
-        out = self.model(self.node, None, self.pos, self.grid)["preds"]
-        loss = ((out - self.target) ** 2).mean()
+        loss = self.loss_fn(self.model, self.batch)
         loss.backward()
         self.loss.copy_(loss.detach())
+        if self.flat:
+            self.opt.gather_grads()          # grads -> the flat bucket the collective and the optimizer work on
 
     def comm(self):
-        self.reducer.reduce()            # one flat 8.9 MB RCCL all-reduce per step (no-op for N=1)
+        if self.flat:
+            self.opt.all_reduce()            # ONE flat RCCL sum-all-reduce per step, in place, no copy back
+        else:
+            self.reducer.reduce()
 
     def opt_step(self):
-        torch.nn.utils.clip_grad_norm_(self.params, self.clip, foreach=True)
-        self.opt.step()
+        if self.flat:
+            self.opt.apply()
+        else:
+            torch.nn.utils.clip_grad_norm_(self.params, self.clip, foreach=True)
+            self.opt.step()
 
     def eager_step(self):
         for p in self.params:
@@ -170,9 +290,30 @@ class Trainer:
             self.g_opt.replay()
 
 
-def roofline_leg(trainer):
-    """Per-launch HIP-event timing of one eager step, then the dominant hot-path kernel re-timed
-    back-to-back on the launch stream."""
+def timed_run(tr, steps, warmup, world):
+    for _ in range(warmup):
+        tr.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=tr.dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def roofline_leg(trainer, precision):
+    """Per-launch HIP-event timing of one eager step, then the dominant hot-path kernel re-timed back-to-back on the
+    launch stream; plus the per-leg table (head norm, K^T V, FFN, Q.P) the north star asks for."""
     from galerkin_transformer import _hip
     with _hip.Profile() as prof:
         trainer.eager_step()
@@ -202,7 +343,14 @@ def roofline_leg(trainer):
     e1.record()
     torch.cuda.synchronize()
     dur_s = e0.elapsed_time(e1) / reps * 1e-3
-    achieved = best[1] / dur_s / 1e12
+    x3 = "x3" in dom
+    products = PLANE_PRODUCTS.get(precision, 1) if x3 else 1
+    peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+    useful = best[1] / dur_s / 1e12                      # 2 M N K per launch: what the caller asked for
+    executed = useful * products                         # flops the matrix pipe actually retires
+    hbm = best[2] / dur_s / 1e9
+    # which roofline bounds this launch: the larger of (executed flops / MFMA peak, bytes / HBM peak)
+    bound = "mfma" if executed / peak >= hbm / PEAK_HBM_GBS else "hbm"
     # HBM traffic of this kernel + launch shape from the rocprofv3 --pmc passes (tools/gpu_pmc.sh), when a
     # measurement for exactly this launch is on file under profiles/
     traffic, tsrc = None, None
@@ -213,38 +361,91 @@ def roofline_leg(trainer):
             traffic, tsrc = int(rec["read_bytes"] + rec["write_bytes"]), rec["source"]
     except (OSError, ValueError):
         pass
-    roof = dict(bound="mfma", kernel="gt::" + dom.replace("+splitk", ""), launch_shape_MNKb=list(best[6]),
+    roof = dict(bound=bound, kernel="gt::" + dom.replace("+splitk", ""), launch_shape_MNKb=list(best[6]),
                 includes_splitk_reduce=dom.endswith("+splitk"), launches_per_step=len(recs),
                 share_of_hip_path=round(table[dom]["ms"] / sum(v["ms"] for v in table.values()), 3),
                 avg_launch_us=round(dur_s * 1e6, 2),
                 # all launch shapes of this kernel symbol in one step (what a profiler's per-kernel average mixes)
                 symbol_avg_launch_us_all_shapes=round(table[dom]["ms"] / table[dom]["calls"] * 1e3, 2),
-                achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=tsrc,
+                achieved=round(executed if bound == "mfma" else hbm, 2),
+                peak=peak if bound == "mfma" else PEAK_HBM_GBS, unit="TFLOP/s" if bound == "mfma" else "GB/s",
+                frac=round(executed / peak if bound == "mfma" else hbm / PEAK_HBM_GBS, 4),
+                mfma={"useful_tflops": round(useful, 2), "plane_products": products,
+                      "executed_tflops": round(executed, 2), "peak_tflops": peak, "frac": round(executed / peak, 4),
+                      "useful_vs_f32_mfma_peak": round(useful / PEAK_F32_MFMA_TFLOPS, 4)},
+                hbm={"algorithmic_gbs": round(hbm, 1), "peak_gbs": PEAK_HBM_GBS, "frac": round(hbm / PEAK_HBM_GBS, 4)},
+                traffic=traffic, traffic_source=tsrc,
                 algorithmic_flops_per_launch=best[1], algorithmic_bytes_per_launch=best[2])
+    # legs the north star names (per launch averages of this step, algorithmic bytes / flops over HIP-event time)
+    legs = {}
+    for key, label in (("gt_headnorm_fwd", "headnorm_fwd"), ("gt_headnorm_bwd", "headnorm_bwd"),
+                       ("gt_galerkin_ktv", "galerkin_ktv"), ("gt_galerkin_dkv", "galerkin_dkv")):
+        if key in table and table[key]["ms"] > 0:
+            t = table[key]
+            legs[label] = dict(us=round(t["ms"] / t["calls"] * 1e3, 1),
+                               algorithmic_gbs=round(t["bytes"] / (t["ms"] * 1e-3) / 1e9, 1),
+                               hbm_frac=round(t["bytes"] / (t["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                               tflops=round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2))
+    roof["legs"] = legs
     return roof, table
 
 
 def cpu_baseline_leg(model_cpu_sd, cfg, budget_s=20.0):
-    """The oracle's plain-torch CPU restatement of the same training step (B=4, the reference default
-    batch) timed on this host's cores: 1 warm-up + as many steps as fit the budget (>= 3)."""
-    from oracle import galerkin_oracle as O
+    """CPU training step on this host's cores, B=4 (the reference default batch): 1 warm-up + as many steps as fit
+    the budget (>= 3).  kind "reference" = the reference's own modules (only where /root/reference exists, i.e. the
+    build container); kind "port" = oracle/galerkin_oracle.py, the pinned CPU restatement -- its step is slightly
+    LIGHTER than the reference's (it treats every nn.Dropout as identity; the always-on attention dropout is kept)."""
     B = 4
     # torch's CPU kernels stop scaling (and then regress) well below the core count of a GPU host:
     # cap the thread pool; "cores" in the output is the number of threads actually used
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    node, pos, grid, target = synthetic_batch(B, torch.device("cpu"), seed=7)
-    sd = {k: v.detach().clone().float().requires_grad_(v.is_floating_point()) for k, v in model_cpu_sd.items()}
-    state = {}
-    O.model_train_step_cpu(sd, cfg, node, pos, grid, target, state)
+    b = synthetic_batch(B, torch.device("cpu"), seed=7)
+    node, pos, grid, target = b["node"], b["pos"], b["grid"], b["target"]
+    kind = "port"
+    if os.path.isdir("/root/reference/libs"):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+            from make_golden import import_reference
+            _, M, _ = import_reference()
+            mc = dict(cfg)
+            model = M.FourierTransformer2D(**mc).train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+            def step():
+                opt.zero_grad()
+                out = model(node, None, pos, grid)["preds"]
+                ((out - target) ** 2).mean().backward()
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 0.99)
+                opt.step()
+            kind = "reference"
+        except Exception as e:                                        # fall back to the port
+            print(f"[bench] reference import failed ({type(e).__name__}: {e}); timing the oracle", file=sys.stderr)
+            kind = "port"
+    if kind == "port":
+        from oracle import galerkin_oracle as O
+        sd = {k: v.detach().clone().float().requires_grad_(v.is_floating_point()) for k, v in model_cpu_sd.items()}
+        state = {}
+        step = lambda: O.model_train_step_cpu(sd, cfg, node, pos, grid, target, state)
+    step()
     t0, n = time.perf_counter(), 0
     while n < 3 or (time.perf_counter() - t0 < budget_s and n < 40):
-        O.model_train_step_cpu(sd, cfg, node, pos, grid, target, state)
+        step()
         n += 1
     dt = time.perf_counter() - t0
-    return dict(value=round(B * n / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} steps of batch {B} (fwd+MSE+bwd+clip+Adam, oracle/galerkin_oracle.py), "
-                       f"{dt:.1f} s of CPU time")
+    src = ("the reference's FourierTransformer2D imported from /root/reference" if kind == "reference" else
+           "oracle/galerkin_oracle.py (every nn.Dropout = identity, attention dropout kept: a slightly lighter step "
+           "than the reference's)")
+    return dict(value=round(B * n / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind=kind,
+                sample=f"{n} steps of batch {B} (fwd+MSE+bwd+clip+Adam, {src}), {dt:.1f} s of CPU time")
+
+
+DTYPE_TEXT = {
+    "f32": "f32",
+    "bf16x3": "f32 (operands split exactly into 3 bf16 terms, 6 plane products on the bf16 MFMA pipe, f32 accumulate; "
+              "fp32-class results: the 1e-5 parity gate is tested in this mode)",
+    "bf16x2": "f32 storage / bf16x2 split MFMA (~2^-16 relative; throughput mode, own gate)",
+    "bf16": "f32 storage / bf16-rounded MFMA operands, f32 accumulate (throughput mode, own 3e-3 gate)",
+}
 
 
 def main():
@@ -252,14 +453,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default per workload")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--global-batch", type=int, default=None, help="--scaling strong: fixed total batch, split evenly")
     ap.add_argument("--workload", default="ex2_darcy141", choices=sorted(WORKLOADS),
                     help="ex2_darcy141 is the headline metric; the others are informational")
+    ap.add_argument("--loss", default="mse", choices=["mse", "weighted_l2"])
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16x2", "bf16"],
+                    help="arithmetic of the contractions (default: the library default, bf16x3)")
+    ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets the "
                     "multi-rank path be exercised with several ranks on one GPU in tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra timed run in the exact fp32 MFMA mode")
     ap.add_argument("--table", default=None, help="write the per-kernel event table to this JSON file")
     a = ap.parse_args()
 
@@ -278,44 +486,50 @@ def main():
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
+    if a.scaling == "strong":
+        gb = a.global_batch or DEFAULT_BATCH[a.workload] * 8
+        if gb % world:
+            raise SystemExit(f"--global-batch {gb} is not divisible by {world} ranks")
+        per_gpu = gb // world
+    else:
+        per_gpu = a.batch or DEFAULT_BATCH[a.workload]
+        gb = per_gpu * world
+
     import galerkin_transformer as gt
     from galerkin_transformer import _hip
     _hip.lib()                                           # fail loudly if the HIP library is missing
-    cfg = darcy_config(a.workload)
+    if a.precision:
+        gt.set_precision(a.precision)
+    precision = gt.get_precision()
     torch.manual_seed(1127802)                           # identical init on every rank
-    model = gt.FourierTransformer2D(**cfg)
+    model, cfg = build_model(a.workload)
     cpu_sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev).train()
     gt.set_attention_dropout("reference")
     from galerkin_transformer.distributed import rank_seed
     _hip.set_seed(rank_seed(1127802, rank), dev)         # per-rank dropout streams
-    batch = synthetic_batch(a.batch, dev, seed=1000 + rank, workload=a.workload)
-    tr = Trainer(model, batch, world, use_graph=not a.no_graph)
+    batch = synthetic_batch(per_gpu, dev, seed=1000 + rank, workload=a.workload)
+    tr = Trainer(model, batch, world, use_graph=not a.no_graph, workload=a.workload, loss=a.loss,
+                 optimizer=a.optimizer)
     graphed = tr.capture()
-
-    for _ in range(a.warmup):
-        tr.step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        tr.step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_run(tr, a.steps, a.warmup, world)
     loss = float(tr.loss.item())
+
+    # the same timed region once more in the bit-exact fp32 MFMA arithmetic (new captures, same weights trajectory)
+    f32_leg = None
+    if precision != "f32" and not a.no_f32_leg:
+        gt.set_precision("f32")
+        tr.g_fb = tr.g_opt = None
+        g2 = tr.capture(warm=1)
+        e2 = timed_run(tr, a.steps, min(a.warmup, 2), world)
+        f32_leg = {"value": round(gb * a.steps / e2, 2), "ms_per_step": round(e2 / a.steps * 1e3, 3),
+                   "hip_graph": bool(g2), "arithmetic": "v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32 FMA chain)"}
+        gt.set_precision(precision)
 
     roof, table = (None, {})
     if rank == 0 and not a.no_roofline:
         try:
-            roof, table = roofline_leg(tr)
+            roof, table = roofline_leg(tr, precision)
         except Exception as e:
             print(f"[bench] roofline leg failed: {type(e).__name__}: {e}", file=sys.stderr)
     cpu = None
@@ -328,7 +542,6 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        gb = a.batch * world
         value = gb * a.steps / elapsed
         out = {
             "metric": ("training samples/s, Darcy 141x141 Galerkin encoder (fwd+loss+bwd+clip+Adam)"
@@ -336,14 +549,15 @@ def main():
                        f"training samples/s, {a.workload} (informational, not the headline metric)"),
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (randn node/target of the Darcy shapes, true 43^2/141^2 grids, random init)",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": DTYPE_TEXT[precision],
+            "data": "synthetic (randn fields of the workload's shapes on the true grids, random init)",
             "config": {"workload": WORKLOAD_TEXT[a.workload],
                        "params": sum(p.numel() for p in model.parameters()),
-                       "global_batch": gb, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
-                       "hip_graph": bool(graphed), "optimizer": tr.opt_kind,
-                       "dropout": "config.yml ex2_darcy (train mode) + reference attention dropout p=0.5",
+                       "global_batch": gb, "per_gpu_batch": per_gpu, "parallelism": f"dp{world}",
+                       "hip_graph": bool(graphed), "optimizer": tr.opt_kind, "loss": a.loss, "precision": precision,
+                       "dropout": "config.yml (train mode) + reference attention dropout p=0.5",
                        "final_loss": round(loss, 6)},
+            "f32_mfma_exact": f32_leg,
             "roofline": roof, "cpu_baseline": cpu,
         }
         if a.table and table:

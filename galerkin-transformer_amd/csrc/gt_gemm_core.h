@@ -377,6 +377,6 @@ __device__ __forceinline__ void head_epilogue(const GemmP& p, const f32x4 (&acc)
 bool x3_shape_ok(const gt_gemm_desc* d);
 int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned tiles, unsigned split, unsigned batch,
               hipStream_t st);
-const char* x3_kernel_name(int layout_a, int layout_b, int planes);
+const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes);
 
 }  // namespace gt

@@ -23,6 +23,8 @@
 // coalesced dword loads (64 consecutive rows per wave instruction); the dropout mask of the A prologue, the
 // row-sum by-product (bias gradients), split-K, batching and the second accumulated product are those of gt_gemm.
 #include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 
 #include "gt_gemm_core.h"
 
@@ -48,41 +50,43 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t (&out)[PLA
     }
 }
 
-// 8 consecutive k (k0 .. k0+7) of operand row x:  L == 0: base[x*ld + k],  L == 1: base[k*ld + x]
+// 8 consecutive k (k0 .. k0+7) of operand row x:  L == 0: base[x*ld + k],  L == 1: base[k*ld + x].
+// Branch-free: out-of-range elements are redirected to a device zero, so every lane issues the same loads and no
+// s_waitcnt lands between the loads and the MFMAs of the stage being computed (a divergent loader makes hipcc drain
+// vmcnt at the join, i.e. BEFORE the MFMAs it should overlap with).  `whole` (block-uniform): the stage lies inside
+// [.., kend) and the operand is 16-byte aligned, so a k-contiguous row is two dwordx4 loads.
+__device__ __attribute__((aligned(16))) float x3_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
 template <int L>
 __device__ __forceinline__ void x3_load8(const float* __restrict__ base, int64_t ld, int x, int X, int k0, int kend,
-                                         int vec, const DropDev& dd, uint32_t dkey, int64_t dld, int64_t dboff,
-                                         float (&v)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    if (x >= X || k0 >= kend) return;
+                                         bool whole, float (&v)[8]) {
+    const bool row_ok = x < X;
     if (L == 0) {
         const float* ptr = base + (int64_t)x * ld + k0;
-        if (vec && k0 + 7 < kend) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ptr);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(ptr + 4);
+        if (whole) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(row_ok ? ptr : x3_zero);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(row_ok ? ptr + 4 : x3_zero);
             v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
             v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (k0 + j < kend) v[j] = ptr[j];
-        }
-        if (dd.thresh) {
-            const uint32_t di = (uint32_t)(dboff + (int64_t)x * dld + k0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= drop_mul(dd, dkey, di + j);
+            for (int j = 0; j < 8; ++j) v[j] = *((row_ok && k0 + j < kend) ? ptr + j : x3_zero);
         }
     } else {
         const float* ptr = base + (int64_t)k0 * ld + x;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (k0 + j < kend) v[j] = ptr[(int64_t)j * ld];
-        if (dd.thresh) {
+        for (int j = 0; j < 8; ++j) v[j] = *((row_ok && (whole || k0 + j < kend)) ? ptr + (int64_t)j * ld : x3_zero);
+    }
+}
+
+// stateless dropout mask of the A prologue on the 8 staged values (same mask index as gload in gt_gemm_core.h)
+template <int L>
+__device__ __forceinline__ void x3_mask8(const DropDev& dd, uint32_t dkey, int64_t dld, int64_t dboff, int x, int k0,
+                                         float (&v)[8]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                v[j] *= drop_mul(dd, dkey, (uint32_t)(dboff + (int64_t)(k0 + j) * dld + x));
-        }
+    for (int j = 0; j < 8; ++j) {
+        const int64_t di = dboff + (L == 0 ? (int64_t)x * dld + k0 + j : (int64_t)(k0 + j) * dld + x);
+        v[j] *= drop_mul(dd, dkey, (uint32_t)di);
     }
 }
 
@@ -99,6 +103,35 @@ __device__ __forceinline__ void x3_store8(char* __restrict__ img, int row, int k
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Epilogue shared by both kernels.  Result registers of the 32x32 MFMA with the N-side tile as its A operand: lane
+// (lr = lane & 31, lh = lane >> 5) holds output row  mrow + 32 i  of accumulator (i, j) and the four 4-column groups
+// ncol + 32 j + 8 g .. + 3  (ncol already includes 4 * lh).
+__device__ __forceinline__ void x3_epilogue(const GemmP& p, const f32x16 (&acc)[2][2], int mrow, int ncol, int z,
+                                            int b0, int b1, int sidx) {
+    const int64_t coff = b0 * p.c_bs0 + b1 * p.c_bs1 + (int64_t)sidx * p.c_split;
+    float* __restrict__ C = p.C + coff;
+    const uint32_t dkey = drop_key_dev(p.drop);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nb = ncol + 32 * j + 8 * g;
+            if (nb >= p.N) continue;
+            const bool full = nb + 4 <= p.N;
+            float biasv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = mrow + 32 * i;
+                if (m >= p.M) continue;
+                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                ep_row<4>(p, v, biasv, C, m, nb, z, b0, b1, full, dkey);
+            }
+        }
+    }
 }
 
 template <int LA, int LB, int PLANES>
@@ -128,7 +161,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmP p) {
     int kend_c = kend, avec_c = p.a_vec, bvec_c = p.b_vec;
     const uint32_t akey = drop_key_dev(p.a_drop);
     const int64_t adoff = (int64_t)z * p.a_drop_bstride;
-    const DropDev nodrop{0u, 0u, 1.f, nullptr};
 
     // staging role of this thread: one row of each operand tile, one k-half (8 consecutive k) per stage
     const int arow = (LA == 0) ? (tid >> 1) : (tid & 127), akh = (LA == 0) ? (tid & 1) : (tid >> 7);
@@ -144,37 +176,25 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmP p) {
 
     float ra[8], rb[8];
     float asum = 0.f;
+    int ka = 0;                                   // first k of the values held in ra (for the mask index)
     const bool do_acs = (LA == 1) && p.acs != nullptr && tn == 0;
-    auto g2r = [&](int k0) {
-        x3_load8<LA>(A, lda_c, m0 + arow, p.M, k0 + 8 * akh, kend_c, avec_c, p.a_drop, akey, p.a_drop_ld, adoff, ra);
-        x3_load8<LB>(Bm, ldb_c, n0 + brow, p.N, k0 + 8 * bkh, kend_c, bvec_c, nodrop, 0u, 0, 0, rb);
-        if (LA == 1 && do_acs) asum += ((ra[0] + ra[1]) + (ra[2] + ra[3])) + ((ra[4] + ra[5]) + (ra[6] + ra[7]));
+    // FAST: every element of the stage is in range along k and k-contiguous rows are 16-byte aligned -- straight-line
+    // loads (row validity by pointer select), so the only vmcnt wait of an iteration sits in r2s, after the MFMAs.
+    auto g2r = [&](int k0, auto fast) {
+        constexpr bool FAST = decltype(fast)::value;
+        const bool inside = FAST || (k0 + X3_BK <= kend_c);       // block-uniform
+        ka = k0 + 8 * akh;
+        x3_load8<LA>(A, lda_c, m0 + arow, p.M, ka, kend_c, inside && (FAST || LA == 1 || avec_c), ra);
+        x3_load8<LB>(Bm, ldb_c, n0 + brow, p.N, k0 + 8 * bkh, kend_c, inside && (FAST || LB == 1 || bvec_c), rb);
     };
-    auto r2s = [&](int buf) {
+    auto r2s = [&](int buf) {                     // first use of the loaded registers: the vmcnt wait lands here
+        if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, adoff, m0 + arow, ka, ra);
+        if (LA == 1 && do_acs) asum += ((ra[0] + ra[1]) + (ra[2] + ra[3])) + ((ra[4] + ra[5]) + (ra[6] + ra[7]));
         char* st = smem + buf * STAGE;
         x3_store8<PLANES>(st, arow, akh, ra);
         x3_store8<PLANES>(st + PLANES * X3_PLANE, brow, bkh, rb);
     };
-
-    const int nk1 = (kend > kbeg) ? (kend - kbeg + X3_BK - 1) / X3_BK : 0;
-    const int nk = nk1 + (p.K2 > 0 ? (p.K2 + X3_BK - 1) / X3_BK : 0);
-    auto enter_seg2 = [&]() {
-        A = p.A2 + b0 * p.a2_bs0 + b1 * p.a2_bs1;
-        Bm = p.B2 + b0 * p.b2_bs0 + b1 * p.b2_bs1;
-        lda_c = p.lda2; ldb_c = p.ldb2; kend_c = p.K2; avec_c = p.a2_vec; bvec_c = p.b2_vec;
-    };
-    if (nk > 0) {
-        if (nk1 == 0) { enter_seg2(); g2r(0); }
-        else g2r(kbeg);
-        r2s(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            if (kt + 1 == nk1) enter_seg2();
-            g2r(kt + 1 < nk1 ? kbeg + (kt + 1) * X3_BK : (kt + 1 - nk1) * X3_BK);
-        }
+    auto compute = [&](int buf) {
         const char* sa = smem + buf * STAGE;
         const char* sb = sa + PLANES * X3_PLANE;
         bf16x8 am[2][PLANES], bn[2][PLANES];
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmP p) {
             }
         // plane pairs in increasing magnitude; the four accumulators interleave inside every pair
 #pragma unroll
-        for (int s = 2 * (PLANES - 1); s >= 0; --s) {
+        for (int s = PLANES - 1; s >= 0; --s) {          // plane pairs (pa, pb) with pa + pb = s <= PLANES - 1
 #pragma unroll
             for (int pa = 0; pa < PLANES; ++pa) {
                 const int pb = s - pa;
@@ -198,9 +218,40 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmP p) {
                     for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(bn[j][pb], am[i][pa], acc[i][j]);
             }
         }
-        if (kt + 1 < nk) r2s(buf ^ 1);
+    };
+
+    const int nk1 = (kend > kbeg) ? (kend - kbeg + X3_BK - 1) / X3_BK : 0;
+    const int nk = nk1 + (p.K2 > 0 ? (p.K2 + X3_BK - 1) / X3_BK : 0);
+    auto enter_seg2 = [&]() {
+        A = p.A2 + b0 * p.a2_bs0 + b1 * p.a2_bs1;
+        Bm = p.B2 + b0 * p.b2_bs0 + b1 * p.b2_bs1;
+        lda_c = p.lda2; ldb_c = p.ldb2; kend_c = p.K2; avec_c = p.a2_vec; bvec_c = p.b2_vec;
+    };
+    if (nk > 0) {
+        if (nk1 == 0) { enter_seg2(); g2r(0, std::false_type{}); }
+        else g2r(kbeg, std::false_type{});
+        r2s(0);
+    }
+    __syncthreads();
+    // iterations whose NEXT stage is a whole one of the first product take the branch-free loop
+    const bool fast_ok = (LA == 1 || p.a_vec) && (LB == 1 || p.b_vec);
+    const int nfast = fast_ok ? max(0, (kend - kbeg) / X3_BK - 1) : 0;
+    int kt = 0;
+    for (; kt < nfast; ++kt) {
+        g2r(kbeg + (kt + 1) * X3_BK, std::true_type{});
+        compute(kt & 1);
+        r2s((kt + 1) & 1);
         __syncthreads();
     }
+    for (; kt + 1 < nk; ++kt) {                   // K tail, unaligned operands, the second product
+        if (kt + 1 == nk1) enter_seg2();
+        g2r(kt + 1 < nk1 ? kbeg + (kt + 1) * X3_BK : (kt + 1 - nk1) * X3_BK, std::false_type{});
+        compute(kt & 1);
+        r2s((kt + 1) & 1);
+        __syncthreads();
+    }
+    if (nk > 0) compute((nk - 1) & 1);
+    __syncthreads();
 
     if (LA == 1 && do_acs) {              // uniform per block; the stages are free after the loop's last barrier
         float* part = reinterpret_cast<float*>(smem);
@@ -210,29 +261,181 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmP p) {
             p.acs[((int64_t)blockIdx.y * gridDim.z + z) * p.M + m0 + tid] = part[tid] + part[X3_BM + tid];
     }
 
-    // ------------------------------- epilogue: lane = one row m per accumulator row tile -------------------
-    const int64_t coff = b0 * p.c_bs0 + b1 * p.c_bs1 + (int64_t)blockIdx.y * p.c_split;
-    float* __restrict__ C = p.C + coff;
-    const uint32_t dkey = drop_key_dev(p.drop);
+    x3_epilogue(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, z, b0, b1, (int)blockIdx.y);
+}
+
+// =================================================================================================================
+// Ring variant for aligned operands: the fp32 tiles go global -> LDS by direct loads (no VGPR staging, no ds_write
+// pass) into a ring of R 16-deep stages, R - 1 stages in flight while one is consumed, so an HBM round trip is covered
+// by ~R - 1 stage times instead of one; the exact bf16 split happens in registers on the way from LDS into the MFMA
+// operands (each wave converts the two A and two B row tiles it multiplies).  One s_barrier per stage publishes the
+// landed stage and frees the slot the next request overwrites.
+//
+// LDS images of one stage (A then B, 8 KB each); a direct load writes wave-uniform base + lane * 16 B, so the images are
+// lane-linear and every swizzle is applied to the SOURCE address:
+//   k-contiguous operand (L == 0):  [128 rows][16 k]: the 16-byte granule g of row r sits at slot g ^ ((r >> 2) & 3);
+//                                   an MFMA lane (row, k-half h) reads granules 2h and 2h + 1 (two conflict-free
+//                                   ds_read_b128);
+//   x-contiguous operand (L == 1):  [16 k][128 x] as in memory; a lane reads its row's 8 k as 8 ds_read_b32 (lanes of a
+//                                   half-wave hit consecutive banks).
+// Needs: 16-byte aligned operands and leading dimensions, K % 4 == 0 for k-contiguous operands, X % 4 == 0 for
+// x-contiguous ones, no second product (the register-staged kernel above takes everything else).
+typedef __attribute__((address_space(3))) void* x3_lds_ptr;
+typedef const __attribute__((address_space(1))) void* x3_glb_ptr;
+constexpr int X3R_OP = X3_BM * X3_BK * 4;        // 8192 B: one operand tile of one stage
+constexpr int X3R_STAGE = 2 * X3R_OP;
+
+template <int L>
+__device__ __forceinline__ void x3r_issue(const float* __restrict__ base, int64_t ld, int x0, int X, int k0, int kend,
+                                          char* img, int wave, int lane) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave * 2 + i;                // 1-KiB piece of the 8-KiB image
+        const float* src;
+        if (L == 0) {
+            const int row = 16 * q + (lane >> 2), slot = lane & 3;
+            const int g = slot ^ ((row >> 2) & 3);
+            const int x = x0 + row, k = k0 + 4 * g;
+            src = (x < X && k < kend) ? base + (int64_t)x * ld + k : x3_zero;
+        } else {
+            const int kr = 2 * q + (lane >> 5), xx = x0 + 4 * (lane & 31), k = k0 + kr;
+            src = (k < kend && xx < X) ? base + (int64_t)k * ld + xx : x3_zero;
+        }
+        __builtin_amdgcn_global_load_lds((x3_glb_ptr)src, (x3_lds_ptr)(img + q * 1024), 16, 0, 0);
+    }
+}
+
+// this lane's 8 consecutive k (k-half lh) of tile row `row` (0..127) from a stage image
+template <int L>
+__device__ __forceinline__ void x3r_frag(const char* __restrict__ img, int row, int lh, float (&v)[8]) {
+    if (L == 0) {
+        const int s = (row >> 2) & 3;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(img + row * 64 + (((2 * lh) ^ s) << 4));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(img + row * 64 + (((2 * lh + 1) ^ s) << 4));
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+        const float* f = reinterpret_cast<const float*>(img) + (8 * lh) * X3_BM + row;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nb = n0 + wn * 64 + 32 * j + 8 * g + 4 * lh;
-            if (nb >= p.N) continue;
-            const bool full = nb + 4 <= p.N;
-            float biasv[4];
+        for (int j = 0; j < 8; ++j) v[j] = f[j * X3_BM];
+    }
+}
+
+template <int PLANES>
+__device__ __forceinline__ void x3r_split(const float (&v)[8], bf16x8 (&out)[PLANES]) {
+    uint32_t q[4][PLANES];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
+    for (int i = 0; i < 4; ++i) split_pair<PLANES>(v[2 * i], v[2 * i + 1], q[i]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = m0 + wm * 64 + 32 * i + lr;
-                if (m >= p.M) continue;
-                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                ep_row<4>(p, v, biasv, C, m, nb, z, b0, b1, full, dkey);
+    for (int pl = 0; pl < PLANES; ++pl)
+        out[pl] = __builtin_bit_cast(bf16x8, u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]});
+}
+
+template <int LA, int LB, int PLANES, int R>
+__global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[R * X3R_STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    int tile;
+    {
+        const int tiles = gridDim.x, q = tiles >> 3, r = tiles & 7;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * X3_BM, n0 = tn * X3_BN;
+    const int z = blockIdx.z, b0 = z / p.batch1, b1 = z % p.batch1;
+    const int kbeg = blockIdx.y * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
+    const float* A = p.A + b0 * p.a_bs0 + b1 * p.a_bs1;
+    const float* Bm = p.B + b0 * p.b_bs0 + b1 * p.b_bs1;
+    const uint32_t akey = drop_key_dev(p.a_drop);
+    const int64_t adoff = (int64_t)z * p.a_drop_bstride;
+    const bool do_acs = (LA == 1) && p.acs != nullptr && tn == 0 && wn == 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float asum[2] = {0.f, 0.f};
+
+    const int nk = (kend > kbeg) ? (kend - kbeg + X3_BK - 1) / X3_BK : 0;
+    auto issue = [&](int s) {                      // stage s -> slot s % R : 4 load instructions per wave
+        char* st = smem + (s % R) * X3R_STAGE;
+        const int k0 = kbeg + s * X3_BK;
+        x3r_issue<LA>(A, p.lda, m0, p.M, k0, kend, st, wave, lane);
+        x3r_issue<LB>(Bm, p.ldb, n0, p.N, k0, kend, st + X3R_OP, wave, lane);
+    };
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s)
+        if (s < nk) issue(s);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // stages kt+1 .. min(nk-1, kt+R-2) were requested after stage kt: VMEM retires in order, so "at most
+        // 4 * newer loads outstanding" means stage kt has landed for this wave; the barrier extends that to the block
+        // and also says everybody is done reading slot (kt-1) % R, which the next request overwrites
+        const int newer = min(nk - 1, kt + R - 2) - kt;
+        if (R > 3 && newer >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + R - 1 < nk) issue(kt + R - 1);
+
+        const char* sa = smem + (kt % R) * X3R_STAGE;
+        const char* sb = sa + X3R_OP;
+        const int kbase = kbeg + kt * X3_BK + 8 * lh;
+        bf16x8 am[2][PLANES], bn[2][PLANES];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v[8];
+            const int row = wm * 64 + 32 * i + lr;
+            x3r_frag<LA>(sa, row, lh, v);
+            if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, adoff, m0 + row, kbase, v);
+            if (LA == 1 && do_acs) asum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            x3r_split<PLANES>(v, am[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[8];
+            x3r_frag<LB>(sb, wn * 64 + 32 * j + lr, lh, v);
+            x3r_split<PLANES>(v, bn[j]);
+        }
+#pragma unroll
+        for (int s = PLANES - 1; s >= 0; --s) {          // plane pairs (pa, pb) with pa + pb = s <= PLANES - 1
+#pragma unroll
+            for (int pa = 0; pa < PLANES; ++pa) {
+                const int pb = s - pa;
+                if (pb < 0 || pb >= PLANES) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(bn[j][pb], am[i][pa], acc[i][j]);
             }
         }
     }
+
+    if (LA == 1 && do_acs) {        // row sums of the (masked) A operand: combine the two k-halves of a row
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float t = asum[i] + __shfl_xor(asum[i], 32, 64);
+            const int m = m0 + wm * 64 + 32 * i + lr;
+            if (lh == 0 && m < p.M) p.acs[((int64_t)blockIdx.y * gridDim.z + z) * p.M + m] = t;
+        }
+    }
+    x3_epilogue(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, z, b0, b1, (int)blockIdx.y);
+}
+
+// operands the ring kernel's direct loads can take (see its header comment)
+static bool x3r_ok(const GemmP& p, int layout_a, int layout_b) {
+    if (p.K2 > 0 || !p.a_vec || !p.b_vec) return false;
+    if ((layout_a == 0 || layout_b == 0) && (p.K & 3)) return false;
+    if (layout_a == 1 && (p.M & 3)) return false;
+    if (layout_b == 1 && (p.N & 3)) return false;
+    return true;
 }
 
 bool x3_shape_ok(const gt_gemm_desc* d) {
@@ -240,11 +443,34 @@ bool x3_shape_ok(const gt_gemm_desc* d) {
     return d->ep_mode == GT_EP_NORMAL && d->M >= 96 && d->N >= 96 && d->K >= 16;
 }
 
+// ring depth: 4 stages x 16 KB = 64 KB (two blocks per CU) or 3 x 16 KB = 48 KB (three blocks per CU)
+static int x3_ring_depth() {
+    static const int d = [] { const char* e = getenv("GT_X3_RING_DEPTH"); return (e && atoi(e) == 3) ? 3 : 4; }();
+    return d;
+}
+
+template <int LA, int LB, int R>
+static void x3_launch_ring(const GemmP& p, int planes, dim3 grid, hipStream_t st) {
+    if (planes == 1) hipLaunchKernelGGL((gemm_x3r_kernel<LA, LB, 1, R>), grid, dim3(256), 0, st, p);
+    else if (planes == 2) hipLaunchKernelGGL((gemm_x3r_kernel<LA, LB, 2, R>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_x3r_kernel<LA, LB, 3, R>), grid, dim3(256), 0, st, p);
+}
+
 template <int LA, int LB>
-static void x3_launch_planes(const GemmP& p, int planes, dim3 grid, hipStream_t st) {
+static void x3_launch_planes(const GemmP& p, int planes, bool ring, dim3 grid, hipStream_t st) {
+    if (ring) {
+        if (x3_ring_depth() == 3) x3_launch_ring<LA, LB, 3>(p, planes, grid, st);
+        else x3_launch_ring<LA, LB, 4>(p, planes, grid, st);
+        return;
+    }
     if (planes == 1) hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, 1>), grid, dim3(256), 0, st, p);
     else if (planes == 2) hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, 2>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, 3>), grid, dim3(256), 0, st, p);
+}
+
+static bool x3_use_ring(const GemmP& p, int layout_a, int layout_b) {
+    static const int force = [] { const char* e = getenv("GT_X3_RING"); return e ? atoi(e) : -1; }();   // tuning knob
+    return force == 0 ? false : x3r_ok(p, layout_a, layout_b);
 }
 
 int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned tiles, unsigned split, unsigned batch,
@@ -252,17 +478,22 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
     if (planes < 1 || planes > 3) return GT_EINVAL;
     const dim3 grid(tiles, split, batch);
     const int lay = layout_a * 2 + layout_b;
-    if (lay == 0) x3_launch_planes<0, 0>(p, planes, grid, st);
-    else if (lay == 1) x3_launch_planes<0, 1>(p, planes, grid, st);
-    else if (lay == 2) x3_launch_planes<1, 0>(p, planes, grid, st);
-    else x3_launch_planes<1, 1>(p, planes, grid, st);
+    const bool ring = x3_use_ring(p, layout_a, layout_b);
+    if (lay == 0) x3_launch_planes<0, 0>(p, planes, ring, grid, st);
+    else if (lay == 1) x3_launch_planes<0, 1>(p, planes, ring, grid, st);
+    else if (lay == 2) x3_launch_planes<1, 0>(p, planes, ring, grid, st);
+    else x3_launch_planes<1, 1>(p, planes, ring, grid, st);
     GT_LAUNCH_CHECK();
     return 0;
 }
 
-const char* x3_kernel_name(int layout_a, int layout_b, int planes) {
-    static thread_local char buf[96];
-    snprintf(buf, sizeof(buf), "void gt::gemm_x3_kernel<%d, %d, %d>(gt::GemmP)", layout_a, layout_b, planes);
+const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes) {
+    static thread_local char buf[112];
+    if (x3_use_ring(p, layout_a, layout_b))
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<%d, %d, %d, %d>(gt::GemmP)", layout_a, layout_b, planes,
+                 x3_ring_depth());
+    else
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3_kernel<%d, %d, %d>(gt::GemmP)", layout_a, layout_b, planes);
     return buf;
 }
 

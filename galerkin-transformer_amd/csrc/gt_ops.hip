@@ -837,6 +837,7 @@ __global__ __launch_bounds__(256) void modemix_fwd_kernel(const float* __restric
     }
 }
 
+template <int MAXP>      // (i, o) weight-gradient pairs per thread: Cin * Cout <= 256 * MAXP
 __global__ __launch_bounds__(256) void modemix_bwd_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ dY, int B, int Q,
     int Cin, int Cout, int64_t xbs, int64_t ybs, int Qx, int Qy, int qoff, float* __restrict__ dX,
@@ -852,8 +853,7 @@ __global__ __launch_bounds__(256) void modemix_bwd_kernel(
         sWr[e] = w.x;
         sWi[e] = w.y;
     }
-    // each thread owns up to 4 (i,o) pairs of dW, accumulated over the whole batch in registers
-    constexpr int MAXP = 8;
+    // each thread owns up to MAXP (i,o) pairs of dW, accumulated over the whole batch in registers
     float gr[MAXP], gi[MAXP];
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) gr[k] = gi[k] = 0.f;
@@ -1188,12 +1188,18 @@ extern "C" int gt_modemix_bwd(const float* X, const float* W, const float* dY, i
         q_off + Q > q_total_x || q_off + Q > q_total_y)
         return GT_EINVAL;
     if (((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(dW)) & 7) != 0) return GT_EALIGN;
-    if (Cin * Cout > 8 * 256) return GT_ENOTSUP;
+    if (Cin * Cout > 24 * 256) return GT_ENOTSUP;          // 96 x 48 (ex1 as shipped) = 18 pairs per thread
     const size_t lds =
         ((size_t)2 * Cin * Cout + (size_t)MM_BCH * 2 * Cin + (size_t)MM_BCH * 2 * Cout) * sizeof(float);
-    if (int rc = allow_big_lds(modemix_bwd_kernel, lds)) return rc;
-    hipLaunchKernelGGL(modemix_bwd_kernel, dim3(Q), dim3(256), lds, (hipStream_t)stream, X, W, dY, B, Q, Cin,
-                       Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, dX, dW);
+    if (Cin * Cout <= 8 * 256) {
+        if (int rc = allow_big_lds(modemix_bwd_kernel<8>, lds)) return rc;
+        hipLaunchKernelGGL(modemix_bwd_kernel<8>, dim3(Q), dim3(256), lds, (hipStream_t)stream, X, W, dY, B, Q, Cin,
+                           Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, dX, dW);
+    } else {
+        if (int rc = allow_big_lds(modemix_bwd_kernel<24>, lds)) return rc;
+        hipLaunchKernelGGL(modemix_bwd_kernel<24>, dim3(Q), dim3(256), lds, (hipStream_t)stream, X, W, dY, B, Q, Cin,
+                           Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, dX, dW);
+    }
     GT_LAUNCH_CHECK();
     return 0;
 }

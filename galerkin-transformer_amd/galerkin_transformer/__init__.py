@@ -14,6 +14,8 @@ from .model import (FourierTransformer, FourierTransformer2D, FourierTransformer
 
 from .ft import (BurgersDataset, DarcyDataset, UnitGaussianNormalizer, WeightedL2Loss,  # noqa: F401
                  WeightedL2Loss2d)
+from .optim import FlatClipAdam  # noqa: F401
+from ._hip import get_precision, set_precision  # noqa: F401
 from .utils import get_num_params, get_seed  # noqa: F401
 
 __version__ = "0.1.0"

@@ -126,6 +126,10 @@ _PROTOS = {
                                                                           C.c_void_p]),
     "gt_conv3x3_resize_bwd_ws_bytes": (C.c_int64, [C.c_int32] * 5),
     "gt_bilinear2d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
+    "gt_grad_sqnorm_ws_bytes": (C.c_int64, []),
+    "gt_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gt_adam_clip_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_void_p] +
+                          [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -321,10 +325,13 @@ def next_salt(k: int = 4) -> int:
     return s
 
 
-def set_seed(seed: int, device: Optional[torch.device] = None):
+def set_seed(seed: int, device: Optional[torch.device] = None, rewind_salts: bool = True):
+    """Set the device-resident dropout seed.  rewind_salts=False keeps the call-site counter running (use it to
+    reseed between steps of one traced / captured program whose salts must stay aligned)."""
     device = device or torch.device("cuda", torch.cuda.current_device())
     seed_state(device).fill_(seed & 0x7FFFFFFFFFFFFFFF)
-    _salt[0] = 1
+    if rewind_salts:
+        _salt[0] = 1
 
 
 def advance_seed(device: Optional[torch.device] = None, inc: int = 1):

@@ -395,11 +395,14 @@ class WeightedL2Loss2d(_WeightedLoss):
         gy = (u[:, s:-s, d:] - u[:, s:-s, :-d]) / d
         return torch.stack([gx, gy], dim=-1) / h
 
-    def forward(self, preds, targets, preds_prime=None, targets_prime=None, weights=None, K=None):
+    def terms(self, preds, targets, preds_prime=None, targets_prime=None, weights=None, K=None):
+        """Per-sample relative errors without any host read-back (what a captured training step uses):
+        (loss [N], regulariser [N] or None, norms).  forward() reduces them and adds the metric."""
         h = self.h if weights is None else weights
         d = self.dim
         K = torch.tensor(1) if K is None else K
         if self.noise > 0:
+            assert 0 <= self.noise <= 0.2
             with torch.no_grad():
                 targets = targets * (1.0 + self.noise * torch.rand_like(targets))
         target_norm = targets.pow(2).mean(dim=(1, 2)) + self.eps
@@ -411,13 +414,7 @@ class WeightedL2Loss2d(_WeightedLoss):
         if preds_prime is not None and self.alpha > 0:
             gd = (K * (preds_prime - targets_prime)).pow(2)
             loss = loss + self.alpha * gd.mean(dim=(1, 2, 3)) / targets_prime_norm
-        if self.metric_reduction == 'L2':
-            metric = loss.mean().sqrt().item()
-        elif self.metric_reduction == 'L1':
-            metric = loss.sqrt().mean().item()
-        else:
-            metric = loss.sqrt().max().item()
-        loss = loss.sqrt().mean() if self.return_norm else loss.mean()
+        reg = None
         if self.regularizer and targets_prime is not None:
             s = self.dilation // 2
             pd = self.central_diff(preds)
@@ -425,7 +422,22 @@ class WeightedL2Loss2d(_WeightedLoss):
             if K.ndim > 1:
                 K = K[:, s:-s, s:-s].contiguous()
             reg = self.gamma * h * (K * (tp - pd)).pow(2).mean(dim=(1, 2, 3)) / targets_prime_norm
-            reg = reg.sqrt().mean() if self.return_norm else reg.mean()
+        return loss, reg, dict(L2=target_norm, H1=targets_prime_norm)
+
+    def reduce(self, v):
+        return v.sqrt().mean() if self.return_norm else v.mean()
+
+    def forward(self, preds, targets, preds_prime=None, targets_prime=None, weights=None, K=None):
+        loss, reg, norms = self.terms(preds, targets, preds_prime, targets_prime, weights, K)
+        if self.metric_reduction == 'L2':
+            metric = loss.mean().sqrt().item()
+        elif self.metric_reduction == 'L1':
+            metric = loss.sqrt().mean().item()
+        elif self.metric_reduction == 'Linf':
+            metric = loss.sqrt().max().item()
+        loss = self.reduce(loss)
+        if reg is not None:
+            reg = self.reduce(reg)
         else:
             reg = torch.tensor([0.0], requires_grad=True, device=preds.device)
-        return loss, reg, metric, dict(L2=target_norm, H1=targets_prime_norm)
+        return loss, reg, metric, norms

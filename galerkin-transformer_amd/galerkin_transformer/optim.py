@@ -1,0 +1,122 @@
+"""``FlatClipAdam``: gradient clipping + Adam on one flat fp32 bucket, three HIP launches per step.
+
+Reference training step (libs/utils_ft.py:676-681)::
+
+    loss.backward(); nn.utils.clip_grad_norm_(model.parameters(), grad_clip); optimizer.step()
+
+with ``torch.optim.Adam``.  Here the parameters live in ONE contiguous fp32 buffer (every ``p.data`` is a view of
+it, so ``state_dict`` / ``load_state_dict`` / the modules are unaffected), the gradients are gathered into a second
+flat buffer -- which is also the bucket the data-parallel all-reduce works on, so there is no copy back -- and
+``gt_grad_sqnorm`` + ``gt_adam_clip_step`` (csrc/gt_optim.hip) do norm, clip coefficient, moments and update.  The step
+count and the learning rate are device scalars: a captured HIP graph of the step stays valid while a scheduler changes
+the rate.  It is a ``torch.optim.Optimizer``, so ``OneCycleLR`` and ``run_train`` take it unchanged.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _hip as H
+
+
+class FlatClipAdam(torch.optim.Optimizer):
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, max_norm: Optional[float] = None, group=None):
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("FlatClipAdam: no trainable parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.params = params
+        dev = params[0].device
+        H.need_f32_cuda(*params)
+        if any(p.device != dev for p in params):
+            raise ValueError("FlatClipAdam: all parameters must live on one device")
+        self.max_norm = float(max_norm) if max_norm else 0.0
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # every tensor starts on a 16-byte boundary of the bucket (the kernels use 16-byte accesses)
+        self.offsets, off = [], 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.numel = off
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.flat_param = torch.zeros(off, **f32)
+        self.flat_grad = torch.zeros(off, **f32)
+        self.exp_avg = torch.zeros(off, **f32)
+        self.exp_avg_sq = torch.zeros(off, **f32)
+        self.grad_views = []
+        with torch.no_grad():
+            for p, o in zip(params, self.offsets):
+                v = self.flat_param[o:o + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v                                    # the module now reads / the kernel updates the bucket
+                self.grad_views.append(self.flat_grad[o:o + p.numel()].view_as(p))
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)      # device-resident (uint64 in the ABI)
+        self.sched_dev = torch.tensor([float(lr), float(betas[0])], **f32)    # what schedulers move: lr, beta1
+        self.sqnorm = torch.zeros(1, **f32)
+        self._sched_host = (float(lr), float(betas[0]))
+
+    # ---- pieces (bench.py / a DDP loop call them separately to put the all-reduce in between) -----------------
+    def gather_grads(self):
+        """flat_grad <- the parameters' .grad (missing gradients count as zero): one multi-tensor copy."""
+        srcs, dsts = [], []
+        for p, v in zip(self.params, self.grad_views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                srcs.append(p.grad)
+                dsts.append(v)
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+
+    def all_reduce(self):
+        """Sum the flat gradient over the ranks (the 1/world average is folded into the update)."""
+        if self.world > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def sync_schedule(self):
+        """Copy the scheduler-controlled hyper-parameters (lr, and beta1, which OneCycleLR cycles as Adam's momentum)
+        from param_groups[0] to their device scalars.  Call it outside a captured graph; the graph reads the scalars."""
+        g = self.param_groups[0]
+        cur = (float(g["lr"]), float(g["betas"][0]))
+        if cur != self._sched_host:
+            self.sched_dev.copy_(torch.tensor(cur, dtype=torch.float32), non_blocking=True)
+            self._sched_host = cur
+
+    def apply(self):
+        """norm -> clip -> Adam on the flat buffers (capturable: no host read-back)."""
+        g = self.param_groups[0]
+        L = H.lib()
+        st = H.stream_ptr()
+        gscale = 1.0 / self.world
+        H.check(L.gt_seed_advance(self.step_count.data_ptr(), 1, st), "gt_seed_advance")
+        if self.max_norm > 0:
+            ws = H.workspace(self.flat_grad.device, L.gt_grad_sqnorm_ws_bytes())
+            H.check(L.gt_grad_sqnorm(self.flat_grad.data_ptr(), self.numel, gscale, self.sqnorm.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), st), "gt_grad_sqnorm")
+        H.check(L.gt_adam_clip_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                    self.exp_avg_sq.data_ptr(), self.numel,
+                                    self.sqnorm.data_ptr() if self.max_norm > 0 else None, gscale, self.max_norm,
+                                    self.sched_dev.data_ptr(), g["betas"][0], g["betas"][1], g["eps"],
+                                    g["weight_decay"], self.step_count.data_ptr(),
+                                    self.sched_dev.data_ptr() + 4, st), "gt_adam_clip_step")
+
+    # ---- torch.optim.Optimizer interface ----------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.sync_schedule()                                  # schedulers write param_groups[0]
+        self.gather_grads()
+        self.all_reduce()
+        self.apply()
+        return loss
+
+    def grad_norm(self) -> float:
+        """Global norm of the (averaged) gradient seen by the last step (host read-back; diagnostics only)."""
+        return float(self.sqnorm.sqrt().item())

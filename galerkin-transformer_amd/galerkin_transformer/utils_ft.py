@@ -112,7 +112,10 @@ def _forward(model, data, device):
 
 def _finish_step(model, loss, optimizer, lr_scheduler, grad_clip):
     loss.backward()
-    nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
+    if getattr(optimizer, "max_norm", 0):       # optim.FlatClipAdam: the clip is part of its fused step
+        optimizer.max_norm = float(grad_clip)
+    else:
+        nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
     optimizer.step()
     if lr_scheduler:
         lr_scheduler.step()

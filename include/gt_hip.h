@@ -372,6 +372,27 @@ int gt_conv3x3_resize_bwd(const float* g, const float* y, const float* x, const 
                           void* stream);
 int64_t gt_conv3x3_resize_bwd_ws_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W);
 
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer step on ONE flat fp32 bucket: what utils_ft.py:676-681 does per batch
+ * (nn.utils.clip_grad_norm_(model.parameters(), grad_clip); optimizer.step() with torch.optim.Adam), as three
+ * launches for the whole model.  Norm, step count and learning rate are read from DEVICE memory (no host sync; one
+ * captured launch serves every iteration).
+ *   gt_grad_sqnorm    out[0] = sum_i (scale * g[i])^2            (deterministic two-pass; ws >= gt_grad_sqnorm_ws_bytes())
+ *   gt_adam_clip_step g' = gscale * clip * g + weight_decay * p,  clip = min(1, max_norm / (sqrt(sqnorm[0]) + 1e-6))
+ *                     (max_norm <= 0: no clipping, sqnorm may be NULL);
+ *                     m = beta1 m + (1-beta1) g';  v = beta2 v + (1-beta2) g'^2;  t = step[0] (already incremented:
+ *                     bump it with gt_seed_advance before the call);
+ *                     p -= lr[0] / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)      -- torch.optim.Adam.
+ *   beta1_dev (optional device scalar) overrides beta1: OneCycleLR cycles Adam's beta1 together with the rate.
+ *   gscale folds the 1/world of the gradient average after a sum-all-reduce (pass the same factor as `scale` to
+ *   gt_grad_sqnorm so that the norm is the norm of the averaged gradient).  All pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int64_t gt_grad_sqnorm_ws_bytes(void);
+int gt_grad_sqnorm(const float* g, int64_t n, float scale, float* out, void* ws, int64_t ws_bytes, void* stream);
+int gt_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sqnorm, float gscale,
+                      float max_norm, const float* lr, float beta1, float beta2, float eps, float weight_decay,
+                      const uint64_t* step, const float* beta1_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

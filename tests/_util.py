@@ -30,7 +30,9 @@ class Golden:
 
 
 def all_golden(prefix=""):
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith(prefix))
+    """Module fixtures of make_golden.py (the host_* files of make_golden_host.py have their own tests)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN)
+                  if f.endswith(".npz") and f.startswith(prefix) and not f.startswith("host_"))
 
 
 def rel_l2(a, b):

@@ -1,0 +1,146 @@
+"""Host mirror against fixtures recorded from the reference itself (tests/golden/make_golden_host.py): the 1-D and 2-D
+weighted-L2 losses (values, metric, gradient w.r.t. the prediction), UnitGaussianNormalizer, same-seed parameter
+initialisation of the ex1..ex4 models (bit-equal), and the ex4 dataset/rollout plumbing.  CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import GOLDEN, rel_l2
+
+
+@pytest.fixture(scope="module")
+def host():
+    z = np.load(os.path.join(GOLDEN, "host_losses.npz"))
+    return z, json.loads(bytes(z["meta"]).decode())
+
+
+def _t(z, k):
+    return torch.from_numpy(np.array(z[k]))
+
+
+def test_weighted_l2_loss_1d_matches_reference(host):
+    """reference libs/ft.py:848-980, incl. gamma/alpha/delta pre-multiplied by h (ft.py:872-874)."""
+    from galerkin_transformer.ft import WeightedL2Loss
+    z, idx = host
+    preds, targets = _t(z, "l1/preds"), _t(z, "l1/targets")
+    for i, c in enumerate(idx["loss1d"]):
+        kw = {}
+        if "tprime" in c["use"]:
+            kw["targets_prime"] = _t(z, "l1/tprime")
+        if "pprime" in c["use"]:
+            kw["preds_prime"] = _t(z, "l1/pprime")
+        if "K" in c["use"]:
+            kw["K"] = _t(z, "l1/K")
+        if "lat" in c["use"]:
+            kw["preds_latent"] = [_t(z, "l1/lat0"), _t(z, "l1/lat1")]
+        p = preds.clone().requires_grad_(True)
+        loss, reg, ortho, metric = WeightedL2Loss(**c["kw"])(p, targets, **kw)
+        (gp,) = torch.autograd.grad((loss + reg + ortho).sum(), p)
+        got = torch.stack([loss.detach().reshape(()), reg.detach().reshape(()), ortho.detach().reshape(()),
+                           torch.tensor(float(metric))])
+        ref = _t(z, f"l1/{i}/out")
+        assert torch.allclose(got, ref, rtol=1e-6, atol=1e-9), (i, c, got, ref)
+        assert rel_l2(gp, _t(z, f"l1/{i}/dpreds")) < 1e-6, (i, c)
+
+
+def test_weighted_l2_loss_2d_matches_reference(host):
+    """reference libs/ft.py:983-1105."""
+    from galerkin_transformer.ft import WeightedL2Loss2d
+    z, idx = host
+    preds, targets = _t(z, "l2/preds"), _t(z, "l2/targets")
+    for i, c in enumerate(idx["loss2d"]):
+        kw = {}
+        if "tprime" in c["use"]:
+            kw["targets_prime"] = _t(z, "l2/tprime")
+        if "pprime" in c["use"]:
+            kw["preds_prime"] = _t(z, "l2/pprime")
+        if "K" in c["use"]:
+            kw["K"] = _t(z, "l2/K")
+        p = preds.clone().requires_grad_(True)
+        loss, reg, metric, norms = WeightedL2Loss2d(**c["kw"])(p, targets, **kw)
+        (gp,) = torch.autograd.grad((loss + reg).sum(), p)
+        got = torch.stack([loss.detach().reshape(()), reg.detach().reshape(()), torch.tensor(float(metric))])
+        assert torch.allclose(got, _t(z, f"l2/{i}/out"), rtol=1e-6, atol=1e-9), (i, c)
+        assert torch.allclose(norms["L2"].detach(), _t(z, f"l2/{i}/L2"), rtol=1e-6)
+        assert rel_l2(gp, _t(z, f"l2/{i}/dpreds")) < 1e-6, (i, c)
+
+
+def test_unit_gaussian_normalizer_matches_reference(host):
+    """reference libs/ft.py UnitGaussianNormalizer: fit_transform on numpy, inverse_transform."""
+    from galerkin_transformer.ft import UnitGaussianNormalizer
+    z, _ = host
+    nz = UnitGaussianNormalizer()
+    y = nz.fit_transform(np.array(z["nz/x"]))
+    assert np.allclose(np.asarray(y), z["nz/y"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(np.asarray(nz.mean), z["nz/mean"], rtol=1e-6) and np.allclose(np.asarray(nz.std), z["nz/std"], rtol=1e-6)
+    inv = nz.inverse_transform(np.array(z["nz/xt"]))
+    assert np.allclose(np.asarray(inv), z["nz/inv_np"], rtol=1e-6, atol=1e-6)
+
+
+def _h(t):
+    return hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()[:16]
+
+
+@pytest.mark.parametrize("case", ["ex1_burgers", "ex1_burgers_d64h4", "ex2_darcy", "ex3_darcy_inv", "ex4_ns_lite"])
+def test_same_seed_initialisation_is_bit_equal_to_reference(case):
+    """Init contract (a8 / a12): building the example models under the reference's default seed gives the
+    reference's parameters bit for bit (layers.py:901-913, 1133-1138; torch default inits elsewhere; deep-copied
+    encoder layers)."""
+    import galerkin_transformer as gt
+    with open(os.path.join(GOLDEN, "host_init_hashes.json")) as f:
+        inv = json.load(f)[case]
+    cfg = dict(inv["config"])
+    for k in ("downscaler_size", "upscaler_size"):
+        if k in cfg and isinstance(cfg[k], list):
+            cfg[k] = tuple(tuple(s) if isinstance(s, list) else s for s in cfg[k])
+    cls = {"ex1": gt.SimpleTransformer, "ex2": gt.FourierTransformer2D, "ex3": gt.FourierTransformer2D,
+           "ex4": gt.FourierTransformer2DLite}[case[:3]]
+    torch.manual_seed(inv["seed"])
+    model = cls(**cfg)
+    sd = model.state_dict()
+    assert set(sd) == set(inv["hashes"])
+    bad = [k for k, v in sd.items() if _h(v) != inv["hashes"][k]]
+    assert not bad, bad[:8]
+    if "n_params" in inv:
+        assert sum(p.numel() for p in model.parameters()) == inv["n_params"] == 862049      # ex4 header comment
+
+
+def test_ns_lite_surface_and_rollout_plumbing():
+    """``from libs.ns_lite import *`` resolves the names ex4 uses; the synthetic dataset has the reference's shapes;
+    train_batch_ns / validate_epoch_ns drive a 10-step rollout with ONE backward (ns_lite.py:205-264), checked here
+    with a CPU stand-in model (the HIP model itself is exercised by tests/test_modules_gpu.py)."""
+    import libs.ns_lite as NS
+    for name in ("NavierStokesDatasetLite", "FourierTransformer2DLite", "train_batch_ns", "validate_epoch_ns",
+                 "WeightedL2Loss2d", "run_train", "get_seed", "OneCycleLR", "DataLoader", "defaultdict"):
+        assert hasattr(NS, name), name
+    ds = NS.NavierStokesDatasetLite(data_path="/nonexistent/ns_V1000_N5000_T50.mat", train_len=6, valid_len=2)
+    it = ds[0]
+    assert len(ds) == 6 and it["node"].shape == (64, 64, 10) and it["target"].shape == (64, 64, 10)
+    assert it["target_grad"].shape == (64, 64, 2, 10) and it["pos"].shape == (4096, 2) and it["grid"].shape == (64, 64, 2)
+    gx, gy = NS.NavierStokesDatasetLite.central_diff(np.arange(16, dtype=np.float64).reshape(1, 4, 4, 1), 0.5)
+    assert gx.shape == (1, 4, 4, 1) and gx[0, 1, 1, 0] == (8 - 0) / 2 / 0.5 and gy[0, 1, 1, 0] == (6 - 4) / 2 / 0.5
+
+    class Tiny(torch.nn.Module):                      # same call signature / return dict as FourierTransformer2DLite
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.linspace(-0.1, 0.1, 10))
+            self.calls = 0
+
+        def forward(self, node, edge, pos, grid=None):
+            self.calls += 1
+            return dict(preds=(node * self.w).sum(-1, keepdim=True))
+
+    model = Tiny()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2)
+    loss_func = NS.WeightedL2Loss2d(regularizer=True, h=1 / 64, gamma=0.1)
+    w0 = model.w.detach().clone()
+    (loss, reg), u_preds, _ = NS.train_batch_ns(model, loss_func, next(iter(loader)), opt, None, "cpu")
+    assert model.calls == 10 and u_preds.shape == (2, 64, 64, 10) and loss > 0 and reg >= 0
+    assert not torch.equal(model.w.detach(), w0)
+    val = NS.validate_epoch_ns(model, NS.WeightedL2Loss2d(regularizer=False, h=1 / 64), loader, "cpu")
+    assert np.isfinite(val["metric"]) and model.calls == 10 + 3 * 10

@@ -464,7 +464,7 @@ def test_conv3x3_resize_fused_equals_unfused(H, gpu_device, B, Cin, Cout, n, siz
     outs = []
     for fused in (True, False):
         H.set_seed(777, dev)
-        ops._salt[0] = 11
+        H._salt[0] = 11
         wg = w.clone().requires_grad_(True)
         if fused:
             y = ops.conv3x3_resize(x, wg, size, p_drop, True)
@@ -574,7 +574,7 @@ def test_fourier_fused_equals_materialised(H, gpu_device, B, n, d, h, p, mode):
     try:
         for need_w in (True, False):
             H.set_seed(4242, dev)
-            ops._salt[0] = 3
+            H._salt[0] = 3
             for prm in attn.parameters():
                 prm.grad = None
             x = x0.clone().requires_grad_(True)
@@ -711,7 +711,7 @@ def test_drop_act_fused_equals_chain(H, gpu_device, n, p1, a1, p2, a2):
         res = []
         for fused in (True, False):
             H.set_seed(77, dev)
-            ops._salt[0] = 11
+            H._salt[0] = 11
             x = x0.clone().requires_grad_(True)
             if fused:
                 y = ops.drop_act(x, p1, a1, training, p2, a2)
@@ -754,7 +754,7 @@ def test_gemm_x3_layouts(H, gpu_device, prec, la, lb, M, N, K):
     dev = gpu_device
     A = rnd(M, K, dev=dev, seed=201) if la == 0 else rnd(K, M, dev=dev, seed=201)
     B = rnd(N, K, dev=dev, seed=202) if lb == 0 else rnd(K, N, dev=dev, seed=202)
-    assert "gemm_x3_kernel" in H.gemm_kernel_name(A, B, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1],
+    assert "gemm_x3" in H.gemm_kernel_name(A, B, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1],
                                                   ldb=B.shape[1], ldc=N, precision=prec)
     Cc = torch.full((M, N), float("nan"), device=dev)
     H.gemm(A, B, Cc, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1], ldb=B.shape[1], ldc=N, precision=prec)

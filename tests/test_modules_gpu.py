@@ -135,7 +135,7 @@ def test_training_dropout_matches_mask_replay(GT, gpu_device):
     Dr = d // h + pos.shape[-1]
     DP = (Dr + 3) // 4 * 4
     _hip.set_seed(4242, dev)
-    ops._salt[0] = 1000
+    _hip._salt[0] = 1000
     GT.set_attention_dropout("reference")
     x = x0.clone().requires_grad_(True)
     y = mod(x, pos)
@@ -163,3 +163,36 @@ def test_training_dropout_matches_mask_replay(GT, gpu_device):
         errs["dW:" + k] = rel_l2(params[k].grad, gr)
     bad = {k: v for k, v in errs.items() if not v < TOL}
     assert not bad, bad
+
+
+def test_ns_rollout_matches_reference_golden(GT, gpu_device):
+    """ex4 training objective (reference libs/ns_lite.py:205-238): 10-step autoregressive rollout of the Lite model,
+    loss + regulariser summed over the steps, ONE backward -- loss, all predictions and every parameter gradient
+    against the fixture recorded from the reference (tests/golden/make_golden_host.py)."""
+    import json
+    import os
+    import numpy as np
+    from _util import GOLDEN
+    from galerkin_transformer.ns_lite import rollout_loss
+    z = np.load(os.path.join(GOLDEN, "host_ns_rollout.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    t = lambda k: torch.from_numpy(np.array(z[k])).to(gpu_device)
+    model = GT.FourierTransformer2DLite(**meta["config"])
+    model.load_state_dict({k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith("sd/")}, strict=True)
+    model = model.to(gpu_device).train()
+    loss_func = GT.WeightedL2Loss2d(regularizer=True, h=meta["h"], gamma=meta["gamma"])
+    GT.set_attention_dropout("off")
+    try:
+        total, reg_total, preds = rollout_loss(model, loss_func, t("in/x"), t("in/pos"), t("in/grid"), t("in/u"),
+                                               t("in/gradu"))
+        total.backward()
+        torch.cuda.synchronize()
+    finally:
+        GT.set_attention_dropout("reference")
+    assert abs(float(total) - float(z["loss_total"])) < 1e-5 * abs(float(z["loss_total"]))
+    assert abs(reg_total - float(z["reg_total"])) < 1e-5 * abs(float(z["reg_total"]))
+    errs = {"preds": rel_l2(torch.cat(preds, -1), torch.from_numpy(np.array(z["preds"])))}
+    for k, p in model.named_parameters():
+        errs["dW:" + k] = rel_l2(p.grad, torch.from_numpy(np.array(z["dparam/" + k])))
+    bad = {k: v for k, v in errs.items() if not v < 3 * TOL}          # ten chained forwards: 3e-5
+    assert not bad, f"{bad} (worst {max(errs.values()):.2e})"

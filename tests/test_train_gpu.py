@@ -70,9 +70,9 @@ def test_graph_step_equals_eager_step(gpu_device):
         batch = bench.synthetic_batch(2, gpu_device, 5)
         tr = bench.Trainer(model, batch, 1, use_graph=graph)
         _hip.set_seed(50, gpu_device)
-        ops._salt[0] = 7
+        _hip._salt[0] = 7
         assert tr.capture(warm=1) == graph      # one eager warm-up step either way, then (maybe) capture
-        _hip.set_seed(99, gpu_device)
+        _hip.set_seed(99, gpu_device, rewind_salts=False)
         tr.step()                                # eager: salts continue where the capture trace started
         torch.cuda.synchronize()
         outs.append([p.detach().clone() for p in model.parameters()])
@@ -99,3 +99,34 @@ def test_bench_two_ranks_on_one_gpu_gloo(gpu_device):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["hip_graph"]
     assert rec["value"] > 0 and np.isfinite(rec["config"]["final_loss"])
+
+
+def test_flat_clip_adam_matches_torch(gpu_device):
+    """optim.FlatClipAdam (gt_grad_sqnorm + gt_adam_clip_step on one flat bucket) == clip_grad_norm_ + torch.optim.Adam
+    (reference libs/utils_ft.py:676-681) over several steps, odd tensor sizes, with and without clipping."""
+    import galerkin_transformer as gt
+    dev = gpu_device
+    shapes = [(7, 13), (129,), (3, 5, 2), (1,), (64, 64)]
+    for max_norm, wd in ((0.99, 0.0), (None, 0.0), (0.05, 1e-2)):
+        g = torch.Generator().manual_seed(5)
+        init = [torch.randn(*s, generator=g) for s in shapes]
+        pa = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        pb = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        opt_a = gt.FlatClipAdam(pa, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, max_norm=max_norm)
+        opt_b = torch.optim.Adam(pb, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        sched_a = torch.optim.lr_scheduler.OneCycleLR(opt_a, max_lr=3e-3, total_steps=8)
+        sched_b = torch.optim.lr_scheduler.OneCycleLR(opt_b, max_lr=3e-3, total_steps=8)
+        for it in range(6):
+            grads = [torch.randn(*s, generator=g) * (3.0 if it % 2 else 0.1) for s in shapes]
+            for p, q, gr in zip(pa, pb, grads):
+                p.grad, q.grad = gr.to(dev).clone(), gr.to(dev).clone()
+            if max_norm:
+                torch.nn.utils.clip_grad_norm_(pb, max_norm)
+            opt_a.step(); opt_b.step()
+            sched_a.step(); sched_b.step()
+        torch.cuda.synchronize()
+        for p, q in zip(pa, pb):
+            assert (p - q).abs().max().item() < 2e-6 * (1 + q.abs().max().item()), (max_norm, wd)
+        if max_norm:
+            ref = torch.sqrt(sum((gr ** 2).sum() for gr in grads)).item()
+            assert abs(opt_a.grad_norm() - ref) < 1e-5 * ref

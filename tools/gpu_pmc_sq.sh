@@ -13,7 +13,7 @@ import csv, glob, collections
 f = glob.glob("$O/sq/**/*counter_collection.csv", recursive=True)[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
-    if "gemm" in r["Kernel_Name"]:
+    if "gemm" in r["Kernel_Name"] or "x3" in r["Kernel_Name"]:
         agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k)
