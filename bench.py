@@ -439,6 +439,29 @@ def cpu_baseline_leg(model_cpu_sd, cfg, budget_s=20.0):
                 sample=f"{n} steps of batch {B} (fwd+MSE+bwd+clip+Adam, {src}), {dt:.1f} s of CPU time")
 
 
+def accuracy_leg(precision):
+    """Second half of the metric: validation rel-L2 after the short synthetic-Darcy training run of
+    tools/accuracy_leg.py on this GPU, next to the reference's own CPU run of the same recipe, seed and data
+    (profiles/accuracy_reference_cpu.json, recorded in the build container where /root/reference exists)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import accuracy_leg as AL
+    res = AL.run("hip")
+    out = {"metric": "validation relative L2 error after %d epochs (%d steps of batch %d) on the synthetic Darcy set"
+                     % (res["epochs"], res["steps"], res["batch"]),
+           "hip": {"val_rel_l2": round(res["val_rel_l2"], 5), "train_loss_last": round(res["train_loss_last"], 5),
+                   "seconds": res["seconds"], "precision": precision},
+           "reference_cpu": None, "data": res["data"]}
+    try:
+        with open(os.path.join(ROOT, "profiles", "accuracy_reference_cpu.json")) as f:
+            ref = json.load(f)
+        out["reference_cpu"] = {"val_rel_l2": round(ref["val_rel_l2"], 5),
+                                "train_loss_last": round(ref["train_loss_last"], 5), "seconds": ref["seconds"],
+                                "source": "profiles/accuracy_reference_cpu.json (tools/accuracy_leg.py --impl reference)"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
 DTYPE_TEXT = {
     "f32": "f32",
     "bf16x3": "f32 (operands split exactly into 3 bf16 terms, 6 plane products on the bf16 MFMA pipe, f32 accumulate; "
@@ -467,6 +490,7 @@ def main():
                     "multi-rank path be exercised with several ranks on one GPU in tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the short convergence run (val rel-L2)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra timed run in the exact fp32 MFMA mode")
     ap.add_argument("--table", default=None, help="write the per-kernel event table to this JSON file")
     a = ap.parse_args()
@@ -538,6 +562,12 @@ def main():
             cpu = cpu_baseline_leg(cpu_sd, cfg)
         except Exception as e:
             print(f"[bench] cpu baseline failed: {type(e).__name__}: {e}", file=sys.stderr)
+    acc = None
+    if rank == 0 and world == 1 and not a.no_accuracy and a.workload == "ex2_darcy141":
+        try:
+            acc = accuracy_leg(precision)
+        except Exception as e:
+            print(f"[bench] accuracy leg failed: {type(e).__name__}: {e}", file=sys.stderr)
     if world > 1:
         dist.barrier()
 
@@ -558,7 +588,7 @@ def main():
                        "dropout": "config.yml (train mode) + reference attention dropout p=0.5",
                        "final_loss": round(loss, 6)},
             "f32_mfma_exact": f32_leg,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "accuracy": acc,
         }
         if a.table and table:
             with open(a.table, "w") as f:

@@ -631,7 +631,8 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
         q.M = d->M; q.N = d->N; q.K = d->K; q.K2 = d->K2;
         q.a_vec = al16(d->A) && m4(d->lda) && m4(d->a_bs0) && m4(d->a_bs1);
         q.b_vec = al16(d->B) && m4(d->ldb) && m4(d->b_bs0) && m4(d->b_bs1);
-        snprintf(buf, n, "%s", x3_kernel_name(q, d->layout_a, d->layout_b, pl.x3));
+        if (d->ep_mode == GT_EP_HEADNORM) snprintf(buf, n, "void gt::gemm_x3r_kernel<0, 0, 3, R, %d>(gt::GemmP)", d->hn_dk);
+        else snprintf(buf, n, "%s", x3_kernel_name(q, d->layout_a, d->layout_b, pl.x3));
     }
     else if (pl.stream)
         snprintf(buf, n, "void gt::gemm_stream_kernel<%d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b, c.mt);
@@ -657,7 +658,15 @@ extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
 static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int64_t ws_bytes, void* stream) {
     if (!d || !d->A || !d->B) return GT_EINVAL;
     if (!d->C && d->ep_mode != GT_EP_ROWDOT) return GT_EINVAL;
-    if (d->ep_mode != GT_EP_NORMAL) {
+    if (d->ep_mode == GT_EP_HEADNORM) {
+        if (d->layout_a || d->layout_b || d->batch0 * d->batch1 != 1 || d->K2 > 0 || d->split_k > 1) return GT_ENOTSUP;
+        if (d->hn_h <= 0 || d->hn_p < 0 || d->N != 3 * d->hn_h * d->hn_dk || (d->hn_norm_mask & ~7)) return GT_EINVAL;
+        if (!d->hn_out || (d->hn_p > 0 && !d->hn_pos)) return GT_EINVAL;
+        if (d->hn_norm_mask && (!d->hn_gamma || !d->hn_beta || !d->hn_stats)) return GT_EINVAL;
+        if (d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res || d->out_scale != 1.f ||
+            d->a_drop.p > 0.f || d->a_colsum)
+            return GT_ENOTSUP;
+    } else if (d->ep_mode != GT_EP_NORMAL) {
         if (d->ep_mode != GT_EP_ROWDOT && d->ep_mode != GT_EP_MLP_BWD) return GT_EINVAL;
         if (d->N > 128 || d->batch0 * d->batch1 != 1 || d->n_out < 1 || d->n_out > 4 || !d->w2) return GT_ENOTSUP;
         if (d->ep_mode == GT_EP_ROWDOT && !d->out2) return GT_EINVAL;
@@ -700,7 +709,13 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     const int64_t mn = (int64_t)d->M * d->N;
     float* dw2_partial = nullptr;
     const int dw2_slabs = pl.tiles_m * kCfgs[pl.cfg].wm;
-    if (d->ep_mode != GT_EP_NORMAL) {
+    if (d->ep_mode == GT_EP_HEADNORM) {
+        if (!pl.x3 || pl.split != 1) return GT_ENOTSUP;
+        p.ep_mode = d->ep_mode;
+        p.hn_gamma = d->hn_gamma; p.hn_beta = d->hn_beta; p.hn_pos = d->hn_pos; p.hn_out = d->hn_out;
+        p.hn_stats = d->hn_stats; p.hn_h = d->hn_h; p.hn_dk = d->hn_dk; p.hn_p = d->hn_p;
+        p.hn_DP = (d->hn_dk + d->hn_p + 3) & ~3; p.hn_mask = d->hn_norm_mask; p.hn_eps = d->hn_eps;
+    } else if (d->ep_mode != GT_EP_NORMAL) {
         if (pl.tiles_n != 1 || pl.split != 1) return GT_ENOTSUP;
         p.ep_mode = d->ep_mode; p.n_out = d->n_out; p.w2 = d->w2; p.ldw2 = d->ldw2; p.b2 = d->b2;
         p.out2 = d->out2; p.g2 = d->g2;

@@ -27,6 +27,9 @@ struct GemmP {
     int K2; const float* A2; int64_t lda2, a2_bs0, a2_bs1; const float* B2; int64_t ldb2, b2_bs0, b2_bs1;
     int a2_vec, b2_vec;
     int light_wait;          // streamed kernel: counted vmcnt after full-tile epilogues (see kernel)
+    // GT_EP_HEADNORM (split-operand ring kernel): head-norm forward fused behind the QKV projection
+    const float* hn_gamma; const float* hn_beta; const float* hn_pos; float* hn_out; float* hn_stats;
+    int hn_h, hn_dk, hn_p, hn_DP, hn_mask; float hn_eps;
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------
@@ -375,6 +378,7 @@ __device__ __forceinline__ void head_epilogue(const GemmP& p, const f32x4 (&acc)
 
 // split-operand bf16 kernel (gt_gemm_x3.hip)
 bool x3_shape_ok(const gt_gemm_desc* d);
+bool x3_headnorm_ok(const GemmP& p, int layout_a, int layout_b, int planes);
 int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned tiles, unsigned split, unsigned batch,
               hipStream_t st);
 const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes);

@@ -134,6 +134,81 @@ __device__ __forceinline__ void x3_epilogue(const GemmP& p, const f32x16 (&acc)[
     }
 }
 
+// GT_EP_HEADNORM epilogue (QKV projection + per-head LayerNorm + position columns, see gt_hip.h): same register map
+// as x3_epilogue.  A head segment (DK columns) of output row m lies inside this wave's 64 columns and is shared by
+// the lane pair (lane, lane ^ 32): each lane holds DK / 2 of its values, so the statistics are a local sum plus ONE
+// cross-lane exchange.  Raw projection -> C, normalised / copied segment -> hn_out, (mean, rstd) -> hn_stats.
+template <int DK>
+__device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&acc)[2][2], int mrow, int ncol, int lh) {
+    constexpr int NSEG = 64 / DK, GPS = DK / 8;              // segments per wave row; 4-column groups per lane per segment
+    const int nwave = ncol - 4 * lh;                          // first column of this wave's 64 (a multiple of 64)
+    const float inv = 1.f / (float)DK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mrow + 32 * i;
+        const bool row_ok = m < p.M;
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            const int nseg = nwave + sg * DK;                 // first column of the segment (wave-uniform)
+            if (nseg >= p.N) continue;
+            const int stream = nseg / (p.hn_h * DK), head = (nseg / DK) % p.hn_h;
+            const bool normed = (p.hn_mask >> stream) & 1;
+            float v[GPS][4];
+#pragma unroll
+            for (int q = 0; q < GPS; ++q) {
+                const int c = sg * DK + 8 * q;                // column offset of this group inside the wave's 64 (+ 4 lh)
+                const int j = c >> 5, g = (c & 31) >> 3;
+                const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nwave + c + 4 * lh) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[q][t] = p.alpha * acc[i][j][4 * g + t] + bv[t];
+                if (row_ok)
+                    *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + nwave + c + 4 * lh) = f32x4{v[q][0], v[q][1], v[q][2], v[q][3]};
+            }
+            float mu = 0.f, rstd = 1.f;
+            if (normed) {                                     // wave-uniform branch: the exchange below is convergent
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < GPS; ++q) sum += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+                sum += __shfl_xor(sum, 32, 64);
+                mu = sum * inv;
+                float ss = 0.f;
+#pragma unroll
+                for (int q = 0; q < GPS; ++q)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { const float c0 = v[q][t] - mu; ss = fmaf(c0, c0, ss); }
+                ss += __shfl_xor(ss, 32, 64);
+                rstd = 1.f / sqrtf(ss * inv + p.hn_eps);
+            }
+            if (!row_ok) continue;
+            const int ni = __popc(p.hn_mask & ((1 << stream) - 1));
+            float* row = p.hn_out + (((int64_t)stream * p.M + m) * p.hn_h + head) * p.hn_DP;
+#pragma unroll
+            for (int q = 0; q < GPS; ++q) {
+                const int dim = 8 * q + 4 * lh;
+                float y[4] = {v[q][0], v[q][1], v[q][2], v[q][3]};
+                if (normed) {
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(p.hn_gamma + (ni * p.hn_h + head) * DK + dim);
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(p.hn_beta + (ni * p.hn_h + head) * DK + dim);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) y[t] = (y[t] - mu) * rstd * gm[t] + bt[t];
+                }
+                float* dst = row + p.hn_p + dim;
+                if ((p.hn_p & 3) == 0) *reinterpret_cast<f32x4*>(dst) = f32x4{y[0], y[1], y[2], y[3]};
+                else if ((p.hn_p & 1) == 0) {
+                    *reinterpret_cast<f32x2*>(dst) = f32x2{y[0], y[1]};
+                    *reinterpret_cast<f32x2*>(dst + 2) = f32x2{y[2], y[3]};
+                } else { dst[0] = y[0]; dst[1] = y[1]; dst[2] = y[2]; dst[3] = y[3]; }
+            }
+            if (lh == 0) {                                    // one lane of the pair: coordinates, padding, statistics
+                for (int jj = 0; jj < p.hn_p; ++jj) row[jj] = p.hn_pos[(int64_t)m * p.hn_p + jj];
+                for (int jj = p.hn_p + DK; jj < p.hn_DP; ++jj) row[jj] = 0.f;
+                if (normed)
+                    *reinterpret_cast<f32x2*>(p.hn_stats + (((int64_t)ni * p.M + m) * p.hn_h + head) * 2) = f32x2{mu, rstd};
+            }
+        }
+    }
+}
+
 template <int LA, int LB, int PLANES>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmP p) {
     constexpr int STAGE = 2 * PLANES * X3_PLANE;                          // A planes then B planes
@@ -331,7 +406,7 @@ __device__ __forceinline__ void x3r_split(const float (&v)[8], bf16x8 (&out)[PLA
         out[pl] = __builtin_bit_cast(bf16x8, u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]});
 }
 
-template <int LA, int LB, int PLANES, int R>
+template <int LA, int LB, int PLANES, int R, int HN = 0>      // HN = head width of the fused head-norm epilogue, 0 = general
 __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[R * X3R_STAGE];
 
@@ -426,7 +501,8 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
             if (lh == 0 && m < p.M) p.acs[((int64_t)blockIdx.y * gridDim.z + z) * p.M + m] = t;
         }
     }
-    x3_epilogue(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, z, b0, b1, (int)blockIdx.y);
+    if (HN > 0) x3_epilogue_hn<(HN > 0 ? HN : 32)>(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, lh);
+    else x3_epilogue(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, z, b0, b1, (int)blockIdx.y);
 }
 
 // operands the ring kernel's direct loads can take (see its header comment)
@@ -440,12 +516,22 @@ static bool x3r_ok(const GemmP& p, int layout_a, int layout_b) {
 
 bool x3_shape_ok(const gt_gemm_desc* d) {
     // whole 128 x 128 tiles dominate (the padding of a partial edge tile is bounded by the sizes below)
-    return d->ep_mode == GT_EP_NORMAL && d->M >= 96 && d->N >= 96 && d->K >= 16;
+    return (d->ep_mode == GT_EP_NORMAL || d->ep_mode == GT_EP_HEADNORM) && d->M >= 96 && d->N >= 96 && d->K >= 16;
 }
 
-// ring depth: 4 stages x 16 KB = 64 KB (two blocks per CU) or 3 x 16 KB = 48 KB (three blocks per CU)
+// the fused head-norm epilogue exists on the ring kernel, three planes, 16-byte aligned everything
+bool x3_headnorm_ok(const GemmP& p, int layout_a, int layout_b, int planes) {
+    if (layout_a || layout_b || planes != 3 || !x3r_ok(p, 0, 0)) return false;
+    if (p.hn_dk != 16 && p.hn_dk != 32 && p.hn_dk != 64) return false;
+    if (!p.c_vec || (p.N & 63)) return false;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return al(p.bias) && al(p.hn_gamma) && al(p.hn_beta) && al(p.hn_out) && al(p.hn_stats);
+}
+
+// ring depth: 3 stages x 16 KB = 48 KB, three blocks per CU (default; measured 38.0 vs 38.35 ms/step at B128) or
+// GT_X3_RING_DEPTH=4: 4 x 16 KB = 64 KB, two blocks per CU
 static int x3_ring_depth() {
-    static const int d = [] { const char* e = getenv("GT_X3_RING_DEPTH"); return (e && atoi(e) == 3) ? 3 : 4; }();
+    static const int d = [] { const char* e = getenv("GT_X3_RING_DEPTH"); return (e && atoi(e) == 4) ? 4 : 3; }();
     return d;
 }
 
@@ -479,6 +565,20 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
     const dim3 grid(tiles, split, batch);
     const int lay = layout_a * 2 + layout_b;
     const bool ring = x3_use_ring(p, layout_a, layout_b);
+    if (p.ep_mode == GT_EP_HEADNORM) {
+        if (!x3_headnorm_ok(p, layout_a, layout_b, planes)) return GT_ENOTSUP;
+        if (x3_ring_depth() == 3) {
+            if (p.hn_dk == 16) hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 3, 3, 16>), grid, dim3(256), 0, st, p);
+            else if (p.hn_dk == 32) hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 3, 3, 32>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 3, 3, 64>), grid, dim3(256), 0, st, p);
+        } else {
+            if (p.hn_dk == 16) hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 3, 4, 16>), grid, dim3(256), 0, st, p);
+            else if (p.hn_dk == 32) hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 3, 4, 32>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 3, 4, 64>), grid, dim3(256), 0, st, p);
+        }
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
     if (lay == 0) x3_launch_planes<0, 0>(p, planes, ring, grid, st);
     else if (lay == 1) x3_launch_planes<0, 1>(p, planes, ring, grid, st);
     else if (lay == 2) x3_launch_planes<1, 0>(p, planes, ring, grid, st);

@@ -15,10 +15,10 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 7          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 8          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
-EP_NORMAL, EP_ROWDOT, EP_MLP_BWD = 0, 1, 2
+EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3, PREC_BF16X2, PREC_BF16 = 0, 1, 2, 3
 PREC_CODE = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x2": PREC_BF16X2, "bf16": PREC_BF16}
 ACT_CODE = {None: ACT_NONE, "none": ACT_NONE, "identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
@@ -57,6 +57,9 @@ class GtGemmDesc(C.Structure):
         ("b2", C.c_void_p), ("out2", C.c_void_p), ("g2", C.c_void_p), ("dw2", C.c_void_p),
         ("K2", C.c_int32), ("A2", C.c_void_p), ("lda2", C.c_int64), ("a2_bs0", C.c_int64), ("a2_bs1", C.c_int64),
         ("B2", C.c_void_p), ("ldb2", C.c_int64), ("b2_bs0", C.c_int64), ("b2_bs1", C.c_int64),
+        ("hn_gamma", C.c_void_p), ("hn_beta", C.c_void_p), ("hn_pos", C.c_void_p), ("hn_out", C.c_void_p),
+        ("hn_stats", C.c_void_p), ("hn_h", C.c_int32), ("hn_dk", C.c_int32), ("hn_p", C.c_int32),
+        ("hn_norm_mask", C.c_int32), ("hn_eps", C.c_float),
         ("precision", C.c_int32),
     ]
 
@@ -367,7 +370,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          out2: Optional[torch.Tensor] = None, g2: Optional[torch.Tensor] = None,
          dw2: Optional[torch.Tensor] = None,
          K2: int = 0, A2: Optional[torch.Tensor] = None, lda2: int = 0, a2_bs=(0, 0),
-         B2: Optional[torch.Tensor] = None, ldb2: int = 0, b2_bs=(0, 0),
+         B2: Optional[torch.Tensor] = None, ldb2: int = 0, b2_bs=(0, 0), hn: Optional[dict] = None,
          precision: Optional[str] = None):
     """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics).  precision=None uses the module mode
     (set_precision)."""
@@ -414,6 +417,12 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         need_f32_cuda(A2, B2)
         d.K2, d.A2, d.lda2, d.a2_bs0, d.a2_bs1 = K2, A2.data_ptr(), lda2, a2_bs[0], a2_bs[1]
         d.B2, d.ldb2, d.b2_bs0, d.b2_bs1 = B2.data_ptr(), ldb2, b2_bs[0], b2_bs[1]
+    if hn is not None:          # GT_EP_HEADNORM: gamma, beta, pos, out, stats, h, dk, p, norm_mask, eps
+        need_f32_cuda(hn.get("gamma"), hn.get("beta"), hn.get("pos"), hn["out"], hn.get("stats"))
+        d.ep_mode = EP_HEADNORM
+        d.hn_gamma, d.hn_beta, d.hn_pos = ptr(hn.get("gamma")), ptr(hn.get("beta")), ptr(hn.get("pos"))
+        d.hn_out, d.hn_stats = hn["out"].data_ptr(), ptr(hn.get("stats"))
+        d.hn_h, d.hn_dk, d.hn_p, d.hn_norm_mask, d.hn_eps = hn["h"], hn["dk"], hn["p"], hn["norm_mask"], hn["eps"]
     need = L.gt_gemm_ws_bytes(C.byref(d))
     wsp, wsn = None, 0
     if need > 0:

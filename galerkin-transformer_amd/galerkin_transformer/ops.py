@@ -40,6 +40,7 @@ def push_attention_masks(masks):
     _attn_masks.extend(masks)
 
 
+_qkvnorm_fused = [True]         # QKV projection + head norm in one launch when the library supports the shape
 _next_salt = H.next_salt        # call-site salt counter (rewound by _hip.set_seed / utils.get_seed)
 
 
@@ -492,8 +493,20 @@ class SimpleAttentionFn(Function):
         wq, wf = _c(wqkv), _c(wfc)
         salt = _next_salt(4)
         qkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
-        H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
-        out3, stats = H.headnorm_fwd(qkv, posc, gamma, beta, T, h, dk, p, norm_mask, eps)
+        out3 = stats = None
+        if _qkvnorm_fused[0] and dk in (16, 32, 64) and bqkv is not None and H.get_precision() == "bf16x3":
+            # head norm on the projection's epilogue (GT_EP_HEADNORM): one pass less over [T, 3d], one launch less
+            out3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
+            stats = torch.empty(2, T, h, 2, dtype=torch.float32, device=dev)
+            try:
+                H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv,
+                       hn=dict(gamma=gamma, beta=beta, pos=posc, out=out3, stats=stats, h=h, dk=dk, p=p,
+                               norm_mask=norm_mask, eps=eps))
+            except H.GtNotSupported:                          # shapes / alignment the fused kernel does not take
+                out3 = None
+        if out3 is None:
+            H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
+            out3, stats = H.headnorm_fwd(qkv, posc, gamma, beta, T, h, dk, p, norm_mask, eps)
         Qp, Kp, Vp = out3[0], out3[1], out3[2]
         hD = h * DP
         out = torch.empty(T, d, dtype=torch.float32, device=dev)

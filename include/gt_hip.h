@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 7
+#define GT_ABI_VERSION 8
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -151,6 +151,18 @@ typedef struct gt_gemm_desc {
     const float* A2; int64_t lda2, a2_bs0, a2_bs1;
     const float* B2; int64_t ldb2, b2_bs0, b2_bs1;
 
+    /* GT_EP_HEADNORM: the packed QKV projection (layers.py:838-840) with the per-head LayerNorm + position columns of
+     * gt_headnorm_fwd (layers.py:841-874) fused behind it.  C [M, N = 3*h*dk] is written as usual (the backward reads
+     * the raw projection) and in the same pass every row's head segments go to hn_out [3][M][h][DP] (normalised where
+     * hn_norm_mask says so, coordinates in columns [0, hn_p), zero pad) and hn_stats [#normed][M][h][2] = (mean,
+     * rstd).  Runs on the split-operand ring kernel only (precision != GT_PREC_F32, 16-byte aligned operands,
+     * K % 4 == 0): dk in {16, 32, 64}, layout_a = layout_b = 0, no batching, no split-K, no other epilogue field but
+     * alpha and bias; anything else returns GT_ENOTSUP and the caller runs gt_gemm + gt_headnorm_fwd. */
+    const float* hn_gamma; const float* hn_beta; const float* hn_pos;
+    float* hn_out; float* hn_stats;
+    int32_t hn_h, hn_dk, hn_p, hn_norm_mask;
+    float hn_eps;
+
     /* Arithmetic of the contraction (GT_PREC_*).  Operands, accumulator and result are fp32 in every mode; what
      * changes is the MFMA instruction the products run on:
      *   GT_PREC_F32    v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 FMA chain (157 TFLOP/s peak);
@@ -174,6 +186,7 @@ typedef struct gt_gemm_desc {
 #define GT_EP_NORMAL  0
 #define GT_EP_ROWDOT  1
 #define GT_EP_MLP_BWD 2
+#define GT_EP_HEADNORM 3
 
 void    gt_gemm_desc_init(gt_gemm_desc* d);            /* zero + alpha=1, out_scale=1, batch=1 */
 int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d);

@@ -99,7 +99,7 @@ def test_c_abi_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(_hip.EXPORTED_SYMBOLS)
-    assert _hip.lib().gt_abi_version() == _hip.ABI_VERSION == 7
+    assert _hip.lib().gt_abi_version() == _hip.ABI_VERSION == 8
     assert _hip.lib().gt_target_arch() == b"gfx950"
 
 
@@ -194,3 +194,28 @@ def test_gemm_desc_layout_matches_header(tmp_path):
     assert int(got["sizeof"]) == ctypes.sizeof(_hip.GtGemmDesc)
     for f in fields:
         assert int(got[f]) == getattr(_hip.GtGemmDesc, f).offset, f
+
+
+def test_device_resident_loader_cpu():
+    """utils_ft.DeviceResidentLoader: one upload, per-epoch permutation + gather; same batches as a DataLoader when
+    not shuffled, every sample exactly once per epoch when shuffled, shared fields stored once."""
+    from torch.utils.data import DataLoader
+    from galerkin_transformer.ft import DarcyDataset
+    from galerkin_transformer.utils_ft import DeviceResidentLoader
+    ds = DarcyDataset(subsample_attn=60, subsample_nodes=20, train_data=True, train_len=10, n_samples_synthetic=12,
+                      synthetic=True)
+    ref = list(DataLoader(ds, batch_size=4, shuffle=False, drop_last=False))
+    got = list(DeviceResidentLoader(ds, 4, "cpu", shuffle=False, drop_last=False))
+    assert len(ref) == len(got) == 3
+    for a, b in zip(ref, got):
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    dl = DeviceResidentLoader(ds, 4, "cpu", shuffle=True, drop_last=True, seed=3)
+    assert len(dl) == 2 and set(dl.shared) == {"pos", "grid", "edge", "mass"}
+    e1 = torch.cat([b["target"] for b in dl])
+    e2 = torch.cat([b["target"] for b in dl])
+    assert e1.shape[0] == 8 and not torch.equal(e1, e2)                 # a new permutation every epoch
+    full = torch.stack([ds[i]["target"] for i in range(10)])
+    for row in e1:
+        assert (full == row).flatten(1).all(1).sum() == 1

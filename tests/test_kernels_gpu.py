@@ -866,3 +866,42 @@ def test_gemm_x3_a_dropout_matches_f32_kernel(H, gpu_device):
             outs[prec] = Cc
         torch.cuda.synchronize()
         assert rel_l2(outs["bf16x3"], outs["f32"]) < KTOL
+
+
+@pytest.mark.parametrize("T,h,dk,p,mask", [(1000, 4, 32, 2, 0b110), (333, 2, 64, 1, 0b011), (4099, 8, 16, 2, 0b110),
+                                           (257, 4, 32, 0, 0b000), (700, 4, 48, 2, 0b110)])
+def test_qkv_headnorm_fused_epilogue(H, gpu_device, T, h, dk, p, mask):
+    """GT_EP_HEADNORM on the split-operand ring kernel: projection + per-head LayerNorm + position columns in one
+    launch == gt_gemm followed by gt_headnorm_fwd (layers.py:838-874).  dk = 48 is outside the fused kernel: the
+    library must say GT_ENOTSUP (the Python mirror then runs the two launches)."""
+    dev = gpu_device
+    d = h * dk
+    x = rnd(T, d, dev=dev, seed=110)
+    w = rnd(3 * d, d, dev=dev, seed=111, scale=0.2)
+    b = rnd(3 * d, dev=dev, seed=112)
+    gamma = 1 + 0.1 * rnd(2, h, dk, dev=dev, seed=113)
+    beta = 0.1 * rnd(2, h, dk, dev=dev, seed=114)
+    pos = rnd(T, p, dev=dev, seed=115) if p else None
+    eps = 1e-7
+    qkv = torch.empty(T, 3 * d, device=dev)
+    H.gemm(x, w, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, precision="bf16x3")
+    out_ref, st_ref = H.headnorm_fwd(qkv, pos, gamma, beta, T, h, dk, p, mask, eps)
+    DP = H.round4(dk + p)
+    qkv2 = torch.full_like(qkv, float("nan"))
+    out3 = torch.full((3, T, h, DP), float("nan"), device=dev)
+    stats = torch.zeros(2, T, h, 2, device=dev)
+    hn = dict(gamma=gamma, beta=beta, pos=pos, out=out3, stats=stats, h=h, dk=dk, p=p, norm_mask=mask, eps=eps)
+    if dk not in (16, 32, 64):
+        with pytest.raises(NotImplementedError):
+            H.gemm(x, w, qkv2, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, hn=hn, precision="bf16x3")
+        return
+    with pytest.raises(NotImplementedError):           # the fused epilogue lives on the split-operand kernel only
+        H.gemm(x, w, qkv2, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, hn=hn, precision="f32")
+    H.gemm(x, w, qkv2, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, hn=hn, precision="bf16x3")
+    torch.cuda.synchronize()
+    assert torch.equal(qkv2, qkv)
+    assert not torch.isnan(out3).any()
+    assert rel_l2(out3, out_ref) < 1e-6
+    nn = bin(mask).count("1")
+    if nn:
+        assert rel_l2(stats[:nn], st_ref[:nn]) < 1e-6

@@ -91,7 +91,7 @@ def test_bench_two_ranks_on_one_gpu_gloo(gpu_device):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
-           "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+           "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-f32-leg"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
@@ -99,6 +99,40 @@ def test_bench_two_ranks_on_one_gpu_gloo(gpu_device):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["hip_graph"]
     assert rec["value"] > 0 and np.isfinite(rec["config"]["final_loss"])
+
+
+def _run_bench_ranks(extra, port, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-f32-leg"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_two_ranks_gloo(gpu_device):
+    """--scaling strong: the global batch is fixed and split over the ranks (two ranks sharing cuda:0 over gloo); also
+    the ex3 inverse-problem workload (BASELINE configs[3]: the DDP configuration) through the same path."""
+    rec = _run_bench_ranks(["--backend", "gloo", "--scaling", "strong", "--global-batch", "4"], 29541)
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2
+    assert rec["config"]["global_batch"] == 4 and rec["config"]["per_gpu_batch"] == 2
+    rec = _run_bench_ranks(["--backend", "gloo", "--workload", "ex3_darcy_inv", "--batch", "2"], 29542)
+    assert rec["config"]["global_batch"] == 4 and np.isfinite(rec["config"]["final_loss"])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs two GPUs (the driver's scaling run has them)")
+def test_bench_two_ranks_rccl(gpu_device):
+    """The same multi-rank step over RCCL (backend nccl), one rank per GPU, whenever the box has two GPUs."""
+    rec = _run_bench_ranks(["--backend", "nccl", "--batch", "2"], 29543)
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0
+    assert np.isfinite(rec["config"]["final_loss"])
 
 
 def test_flat_clip_adam_matches_torch(gpu_device):
