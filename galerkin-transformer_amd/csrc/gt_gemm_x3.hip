@@ -24,6 +24,7 @@
 // row-sum by-product (bias gradients), split-K, batching and the second accumulated product are those of gt_gemm.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "gt_gemm_core.h"
@@ -108,51 +109,81 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 // Epilogue shared by both kernels.  Result registers of the 32x32 MFMA with the N-side tile as its A operand: lane
 // (lr = lane & 31, lh = lane >> 5) holds output row  mrow + 32 i  of accumulator (i, j) and the four 4-column groups
 // ncol + 32 j + 8 g .. + 3  (ncol already includes 4 * lh).
-__device__ __forceinline__ void x3_epilogue(const GemmP& p, const f32x16 (&acc)[2][2], int mrow, int ncol, int z,
-                                            int b0, int b1, int sidx) {
+// The 32x32 MFMA leaves a lane with ONE output row and 4-column groups 32 bytes apart, so stores (and the epilogue's
+// res / aux / add loads) straight from the accumulator layout touch 32-byte pieces of 32 different rows per
+// instruction: rocprofv3 WRITE_SIZE showed 1.4-1.6x the algorithmic bytes on every token GEMM (profiles/
+// r02m_pmc_step_summary.txt).  The wave therefore transposes its 32 x 64 row tile through a private LDS tile first:
+// afterwards 16 consecutive lanes hold one row's 64 columns and every global access of the fused epilogue is a full
+// 256-byte row segment.  mtile0 / ntile0: first row / column of the wave's tile.  stg: 32 x X3_EP_SW floats.
+constexpr int X3_EP_SW = 68;                     // staging row pitch in floats (64 + 4: conflict-free both ways)
+constexpr int X3_EP_STG = 32 * X3_EP_SW;
+
+template <int MI>
+__device__ __forceinline__ void x3_epilogue(const GemmP& p, const f32x16 (&acc)[MI][2], int mtile0, int ntile0, int lane,
+                                            float* __restrict__ stg, int z, int b0, int b1, int sidx) {
     const int64_t coff = b0 * p.c_bs0 + b1 * p.c_bs1 + (int64_t)sidx * p.c_split;
     float* __restrict__ C = p.C + coff;
     const uint32_t dkey = drop_key_dev(p.drop);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int c4 = lane & 15, rsub = lane >> 4;          // read side: 16 lanes per row, 4 rows per instruction
+    const int nb = ntile0 + 4 * c4;
+    const bool col_ok = nb < p.N, full = nb + 4 <= p.N;
+    float biasv[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int t = 0; t < 4; ++t) biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nb = ncol + 32 * j + 8 * g;
-            if (nb >= p.N) continue;
-            const bool full = nb + 4 <= p.N;
-            float biasv[4];
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = mrow + 32 * i;
-                if (m >= p.M) continue;
-                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(stg + lr * X3_EP_SW + 32 * j + 8 * g + 4 * lh) =
+                    f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        // wave-private tile, LDS operations of one wave execute in order: a compiler fence + counter wait is enough
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = 4 * it + rsub, m = mtile0 + 32 * i + r;
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(stg + r * X3_EP_SW + 4 * c4);
+            if (m < p.M && col_ok) {
+                float v[4] = {t4[0], t4[1], t4[2], t4[3]};
                 ep_row<4>(p, v, biasv, C, m, nb, z, b0, b1, full, dkey);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next row tile overwrites the staging
     }
 }
 
 // GT_EP_HEADNORM epilogue (QKV projection + per-head LayerNorm + position columns, see gt_hip.h): same register map
 // as x3_epilogue.  A head segment (DK columns) of output row m lies inside this wave's 64 columns and is shared by
 // the lane pair (lane, lane ^ 32): each lane holds DK / 2 of its values, so the statistics are a local sum plus ONE
-// cross-lane exchange.  Raw projection -> C, normalised / copied segment -> hn_out, (mean, rstd) -> hn_stats.
-template <int DK>
-__device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&acc)[2][2], int mrow, int ncol, int lh) {
+// cross-lane exchange.  Raw projection -> C (16-byte stores).  The head-tile rows ([pos | values | pad], DP floats per
+// head, the wave's 64 / DK heads adjacent in memory) are first assembled in a wave-private LDS tile and then written
+// as whole 16-byte aligned granules, a row at a time: with the coordinates in front the values sit at an 8-byte
+// offset, and storing them straight from the accumulator layout (8-byte pieces of 32 different rows per instruction)
+// cost 1.26 GB of HBM writes for 0.77 GB of data (rocprofv3 WRITE_SIZE, profiles/r02_pmc_step.json).
+constexpr int X3_HN_STG = 32 * 88;               // floats of staging per wave: 32 rows x (4 heads x DP 20 + pad) max
+
+template <int DK, int MI>
+__device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&acc)[MI][2], int mrow, int ncol, int lane,
+                                               float* __restrict__ stg) {
     constexpr int NSEG = 64 / DK, GPS = DK / 8;              // segments per wave row; 4-column groups per lane per segment
+    const int lr = lane & 31, lh = lane >> 5;
     const int nwave = ncol - 4 * lh;                          // first column of this wave's 64 (a multiple of 64)
+    if (nwave >= p.N) return;                                 // wave-uniform: N is a multiple of 64 here
     const float inv = 1.f / (float)DK;
+    const int DP = p.hn_DP, W = NSEG * DP, sw = W + 4, W4 = W >> 2;
+    const int stream = nwave / (p.hn_h * DK), head0 = (nwave / DK) % p.hn_h;
+    const bool normed = (p.hn_mask >> stream) & 1;
+    const int ni = __popc(p.hn_mask & ((1 << stream) - 1));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
         const int m = mrow + 32 * i;
         const bool row_ok = m < p.M;
+        float* srow = stg + lr * sw;
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) {
-            const int nseg = nwave + sg * DK;                 // first column of the segment (wave-uniform)
-            if (nseg >= p.N) continue;
-            const int stream = nseg / (p.hn_h * DK), head = (nseg / DK) % p.hn_h;
-            const bool normed = (p.hn_mask >> stream) & 1;
+            const int head = head0 + sg;
             float v[GPS][4];
 #pragma unroll
             for (int q = 0; q < GPS; ++q) {
@@ -179,9 +210,7 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
                 ss += __shfl_xor(ss, 32, 64);
                 rstd = 1.f / sqrtf(ss * inv + p.hn_eps);
             }
-            if (!row_ok) continue;
-            const int ni = __popc(p.hn_mask & ((1 << stream) - 1));
-            float* row = p.hn_out + (((int64_t)stream * p.M + m) * p.hn_h + head) * p.hn_DP;
+            float* seg = srow + sg * DP;
 #pragma unroll
             for (int q = 0; q < GPS; ++q) {
                 const int dim = 8 * q + 4 * lh;
@@ -192,27 +221,36 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
 #pragma unroll
                     for (int t = 0; t < 4; ++t) y[t] = (y[t] - mu) * rstd * gm[t] + bt[t];
                 }
-                float* dst = row + p.hn_p + dim;
-                if ((p.hn_p & 3) == 0) *reinterpret_cast<f32x4*>(dst) = f32x4{y[0], y[1], y[2], y[3]};
-                else if ((p.hn_p & 1) == 0) {
-                    *reinterpret_cast<f32x2*>(dst) = f32x2{y[0], y[1]};
-                    *reinterpret_cast<f32x2*>(dst + 2) = f32x2{y[2], y[3]};
-                } else { dst[0] = y[0]; dst[1] = y[1]; dst[2] = y[2]; dst[3] = y[3]; }
+                float* dst = seg + p.hn_p + dim;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dst[t] = y[t];
             }
             if (lh == 0) {                                    // one lane of the pair: coordinates, padding, statistics
-                for (int jj = 0; jj < p.hn_p; ++jj) row[jj] = p.hn_pos[(int64_t)m * p.hn_p + jj];
-                for (int jj = p.hn_p + DK; jj < p.hn_DP; ++jj) row[jj] = 0.f;
-                if (normed)
+                for (int jj = 0; jj < p.hn_p; ++jj) seg[jj] = row_ok ? p.hn_pos[(int64_t)m * p.hn_p + jj] : 0.f;
+                for (int jj = p.hn_p + DK; jj < DP; ++jj) seg[jj] = 0.f;
+                if (normed && row_ok)
                     *reinterpret_cast<f32x2*>(p.hn_stats + (((int64_t)ni * p.M + m) * p.hn_h + head) * 2) = f32x2{mu, rstd};
             }
         }
+        // the tile is wave-private and LDS operations of one wave execute in order: a compiler fence is enough
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int mbase = mrow - lr + 32 * i;
+        for (int e = lane; e < 32 * W4; e += 64) {
+            const int r = e / W4, c4 = e - r * W4;
+            if (mbase + r < p.M) {
+                const f32x4 val = *reinterpret_cast<const f32x4*>(stg + r * sw + 4 * c4);
+                *reinterpret_cast<f32x4*>(p.hn_out + (((int64_t)stream * p.M + mbase + r) * p.hn_h + head0) * DP + 4 * c4) = val;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next row tile overwrites the staging
     }
 }
 
 template <int LA, int LB, int PLANES>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmP p) {
     constexpr int STAGE = 2 * PLANES * X3_PLANE;                          // A planes then B planes
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int SMEM = (2 * STAGE > 4 * X3_EP_STG * 4) ? 2 * STAGE : 4 * X3_EP_STG * 4;   // stages, later staging tiles
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -336,7 +374,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmP p) {
             p.acs[((int64_t)blockIdx.y * gridDim.z + z) * p.M + m0 + tid] = part[tid] + part[X3_BM + tid];
     }
 
-    x3_epilogue(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, z, b0, b1, (int)blockIdx.y);
+    __syncthreads();                               // every wave is done with the stages: they become staging tiles
+    x3_epilogue<2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * X3_EP_STG, z, b0, b1,
+                   (int)blockIdx.y);
 }
 
 // =================================================================================================================
@@ -501,8 +541,15 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
             if (lh == 0 && m < p.M) p.acs[((int64_t)blockIdx.y * gridDim.z + z) * p.M + m] = t;
         }
     }
-    if (HN > 0) x3_epilogue_hn<(HN > 0 ? HN : 32)>(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, lh);
-    else x3_epilogue(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, z, b0, b1, (int)blockIdx.y);
+    if (HN > 0) {
+        __syncthreads();                           // every wave is done with the ring: its first slots become staging
+        x3_epilogue_hn<(HN > 0 ? HN : 32), 2>(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, lane,
+                                               reinterpret_cast<float*>(smem) + wave * X3_HN_STG);
+    } else {
+        __syncthreads();                           // every wave is done with the ring: its first slots become staging
+        x3_epilogue<2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * X3_EP_STG, z, b0,
+                       b1, (int)blockIdx.y);
+    }
 }
 
 // operands the ring kernel's direct loads can take (see its header comment)
@@ -523,7 +570,7 @@ bool x3_shape_ok(const gt_gemm_desc* d) {
 bool x3_headnorm_ok(const GemmP& p, int layout_a, int layout_b, int planes) {
     if (layout_a || layout_b || planes != 3 || !x3r_ok(p, 0, 0)) return false;
     if (p.hn_dk != 16 && p.hn_dk != 32 && p.hn_dk != 64) return false;
-    if (!p.c_vec || (p.N & 63)) return false;
+    if (!p.c_vec || (p.N & 63) || (64 / p.hn_dk) * p.hn_DP + 4 > 88) return false;      // staging row fits X3_HN_STG
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     return al(p.bias) && al(p.hn_gamma) && al(p.hn_beta) && al(p.hn_out) && al(p.hn_stats);
 }
@@ -590,7 +637,7 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
 const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes) {
     static thread_local char buf[112];
     if (x3_use_ring(p, layout_a, layout_b))
-        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<%d, %d, %d, %d>(gt::GemmP)", layout_a, layout_b, planes,
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<%d, %d, %d, %d, 0>(gt::GemmP)", layout_a, layout_b, planes,
                  x3_ring_depth());
     else
         snprintf(buf, sizeof(buf), "void gt::gemm_x3_kernel<%d, %d, %d>(gt::GemmP)", layout_a, layout_b, planes);

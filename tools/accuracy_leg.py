@@ -50,7 +50,10 @@ def config(train):
     return cfg
 
 
-def run(impl: str, epochs: int = EPOCHS, log=None):
+def run(impl: str, epochs: int = EPOCHS, log=None, optimizer: str = "flat", attn_dropout: str = "reference",
+        dropout_seed: int = SEED):
+    """dropout_seed reseeds ONLY the dropout streams (after the model is built from SEED): same data order, same
+    initial weights, a different realisation of the training noise."""
     from torch.utils.data import DataLoader
     train, valid = datasets()
     cfg = config(train)
@@ -67,6 +70,7 @@ def run(impl: str, epochs: int = EPOCHS, log=None):
         cfg = dict(cfg, normalizer=nz.to(device))                 # ex2_darcy.py:73: normalizer_y.to(device)
         torch.manual_seed(SEED)
         model = M.FourierTransformer2D(**cfg)
+        torch.manual_seed(dropout_seed)
         Loss, train_batch, validate = FT.WeightedL2Loss2d, UF.train_batch_darcy, UF.validate_epoch_darcy
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     else:
@@ -76,10 +80,11 @@ def run(impl: str, epochs: int = EPOCHS, log=None):
         cfg = dict(cfg, normalizer=train.normalizer_y.to(device))
         torch.manual_seed(SEED)
         model = gt.FourierTransformer2D(**cfg).to(device)
-        gt.set_attention_dropout("reference")
-        gt.get_seed(SEED, printout=False)
+        gt.set_attention_dropout(attn_dropout)
+        gt.get_seed(dropout_seed, printout=False)
         Loss, train_batch, validate = gt.WeightedL2Loss2d, UF.train_batch_darcy, UF.validate_epoch_darcy
-        opt = gt.FlatClipAdam(model.parameters(), lr=1e-3, max_norm=0.99)
+        opt = (gt.FlatClipAdam(model.parameters(), lr=1e-3, max_norm=0.99) if optimizer == "flat"
+               else torch.optim.Adam(model.parameters(), lr=1e-3))
     g = torch.Generator().manual_seed(SEED)
     tl = DataLoader(train, batch_size=BATCH, shuffle=True, drop_last=True, generator=g)
     vl = DataLoader(valid, batch_size=BATCH, shuffle=False, drop_last=False)
@@ -101,7 +106,7 @@ def run(impl: str, epochs: int = EPOCHS, log=None):
             print(f"[{impl}] epoch {ep + 1}/{epochs}  train loss {np.mean(losses):.4f}  val rel-L2 {val:.4f}", file=log,
                   flush=True)
     return dict(impl=impl, device=str(device), epochs=epochs, steps=steps, batch=BATCH, n_train=N_TRAIN, n_valid=N_VALID,
-                seed=SEED, val_rel_l2=hist[-1]["val_rel_l2"], train_loss_last=hist[-1]["train_loss"], history=hist,
+                seed=SEED, dropout_seed=dropout_seed, val_rel_l2=hist[-1]["val_rel_l2"], train_loss_last=hist[-1]["train_loss"], history=hist,
                 seconds=round(time.perf_counter() - t0, 1),
                 data="DarcyDataset(synthetic=True) 141x141 fine / 43x43 coarse; recipe of examples/ex2_darcy.py")
 
@@ -111,8 +116,12 @@ if __name__ == "__main__":
     ap.add_argument("--impl", default="hip", choices=["hip", "reference"])
     ap.add_argument("--epochs", type=int, default=EPOCHS)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"], help="hip only (debugging)")
+    ap.add_argument("--attn-dropout", default="reference", choices=["reference", "off"], help="hip only (debugging)")
+    ap.add_argument("--dropout-seed", type=int, default=SEED)
     a = ap.parse_args()
-    res = run(a.impl, a.epochs, log=sys.stderr)
+    res = run(a.impl, a.epochs, log=sys.stderr, optimizer=a.optimizer, attn_dropout=a.attn_dropout,
+              dropout_seed=a.dropout_seed)
     txt = json.dumps(res, indent=1)
     if a.out:
         with open(a.out, "w") as f:
