@@ -439,23 +439,28 @@ def cpu_baseline_leg(model_cpu_sd, cfg, budget_s=20.0):
                 sample=f"{n} steps of batch {B} (fwd+MSE+bwd+clip+Adam, {src}), {dt:.1f} s of CPU time")
 
 
-def accuracy_leg(precision):
+def accuracy_leg(precision, seeds=(1, 2, 3)):
     """Second half of the metric: validation rel-L2 after the short synthetic-Darcy training run of
-    tools/accuracy_leg.py on this GPU, next to the reference's own CPU run of the same recipe, seed and data
-    (profiles/accuracy_reference_cpu.json, recorded in the build container where /root/reference exists)."""
+    tools/accuracy_leg.py on this GPU, next to the reference's own CPU runs of the same recipe, data, initial weights
+    and dropout seeds (profiles/accuracy_reference_cpu.json, recorded in the build container where /root/reference
+    exists).  The 128-step run peaks at lr 1e-3 and is noise-sensitive (individual runs land between 0.08 and 0.29 for
+    BOTH implementations), so several dropout seeds are run and the spread is reported, not one number."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import accuracy_leg as AL
-    res = AL.run("hip")
+    runs = [AL.run("hip", dropout_seed=sd) for sd in seeds]
+    vals = [r["val_rel_l2"] for r in runs]
     out = {"metric": "validation relative L2 error after %d epochs (%d steps of batch %d) on the synthetic Darcy set"
-                     % (res["epochs"], res["steps"], res["batch"]),
-           "hip": {"val_rel_l2": round(res["val_rel_l2"], 5), "train_loss_last": round(res["train_loss_last"], 5),
-                   "seconds": res["seconds"], "precision": precision},
-           "reference_cpu": None, "data": res["data"]}
+                     % (runs[0]["epochs"], runs[0]["steps"], runs[0]["batch"]),
+           "hip": {"val_rel_l2_mean": round(sum(vals) / len(vals), 5), "val_rel_l2_runs": [round(v, 5) for v in vals],
+                   "dropout_seeds": list(seeds), "seconds_per_run": runs[0]["seconds"], "precision": precision},
+           "reference_cpu": None, "data": runs[0]["data"]}
     try:
         with open(os.path.join(ROOT, "profiles", "accuracy_reference_cpu.json")) as f:
             ref = json.load(f)
-        out["reference_cpu"] = {"val_rel_l2": round(ref["val_rel_l2"], 5),
-                                "train_loss_last": round(ref["train_loss_last"], 5), "seconds": ref["seconds"],
+        rv = [r["val_rel_l2"] for r in ref["runs"]]
+        out["reference_cpu"] = {"val_rel_l2_mean": round(sum(rv) / len(rv), 5), "val_rel_l2_runs": [round(v, 5) for v in rv],
+                                "dropout_seeds": [r["dropout_seed"] for r in ref["runs"]],
+                                "seconds_per_run": ref["runs"][0]["seconds"],
                                 "source": "profiles/accuracy_reference_cpu.json (tools/accuracy_leg.py --impl reference)"}
     except (OSError, ValueError, KeyError):
         pass

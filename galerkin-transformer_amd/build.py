@@ -34,7 +34,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(emu=False, verbose=False, force=False, tag=None, defines=()):
+def build(emu=False, verbose=False, force=False, tag=None, defines=(), only=None):
     """tag/defines: extra named variants (ablation builds for tools/ablate_gemm.sh), e.g.
     build(tag="_nomfma", defines=["GT_ABL_NOMFMA"])."""
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -49,6 +49,9 @@ def build(emu=False, verbose=False, force=False, tag=None, defines=()):
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if only is not None and src not in only:       # variant builds recompile only the files the define touches
+            objs.append(os.path.join(CSRC, ".obj", src.replace(".hip", ".o")))
+            continue
         if force or _stale(o, [s] + HEADERS):
             cmd = [_hipcc()] + flags + ["-c", s, "-o", o]
             if verbose:
@@ -69,11 +72,17 @@ if __name__ == "__main__":
     ap.add_argument("--emu", action="store_true")
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="also build the GEMM ablation variants")
+    ap.add_argument("--ablate-x3", action="store_true", help="also build the split-operand GEMM ablation variants")
     ap.add_argument("-v", "--verbose", action="store_true")
     a = ap.parse_args()
     print(build(False, a.verbose, a.force))
     if a.emu:
         print(build(True, a.verbose, a.force))
+    if a.ablate_x3:
+        for t, d in (("_x3nomfma", ["GT_ABL_X3_NOMFMA"]), ("_x3nosplit", ["GT_ABL_X3_NOSPLIT_A", "GT_ABL_X3_NOSPLIT_B"]),
+                     ("_x3nosplitb", ["GT_ABL_X3_NOSPLIT_B"]), ("_x3nostore", ["GT_ABL_X3_NOSTORE"]),
+                     ("_x3onlyload", ["GT_ABL_X3_NOMFMA", "GT_ABL_X3_NOSPLIT_A", "GT_ABL_X3_NOSPLIT_B", "GT_ABL_X3_NOSTORE"])):
+            print(build(False, a.verbose, a.force, tag=t, defines=d, only=["gt_gemm_x3.hip"]))
     if a.ablate:
         for t, d in (("_nomfma", ["GT_ABL_NOMFMA"]), ("_noload", ["GT_ABL_NOLOAD"]),
                      ("_nostore", ["GT_ABL_NOSTORE"]), ("_onlymfma", ["GT_ABL_NOLOAD", "GT_ABL_NOSTORE"])):

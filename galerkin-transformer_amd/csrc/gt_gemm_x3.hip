@@ -103,6 +103,10 @@ __device__ __forceinline__ void x3_store8(char* __restrict__ img, int row, int k
 }
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef GT_ABL_X3_NOMFMA          // ablation build: keep the operands live, skip the matrix pipe
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
@@ -511,13 +515,21 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
             x3r_frag<LA>(sa, row, lh, v);
             if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, adoff, m0 + row, kbase, v);
             if (LA == 1 && do_acs) asum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#ifdef GT_ABL_X3_NOSPLIT_A       // ablation builds (tools/ablate_x3.sh): timing only, results are wrong
+            for (int pl = 0; pl < PLANES; ++pl) am[i][pl] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(v[0]), __float_as_uint(v[2]), __float_as_uint(v[4]), __float_as_uint(v[6])});
+#else
             x3r_split<PLANES>(v, am[i]);
+#endif
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float v[8];
             x3r_frag<LB>(sb, wn * 64 + 32 * j + lr, lh, v);
+#ifdef GT_ABL_X3_NOSPLIT_B
+            for (int pl = 0; pl < PLANES; ++pl) bn[j][pl] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(v[1]), __float_as_uint(v[3]), __float_as_uint(v[5]), __float_as_uint(v[7])});
+#else
             x3r_split<PLANES>(v, bn[j]);
+#endif
         }
 #pragma unroll
         for (int s = PLANES - 1; s >= 0; --s) {          // plane pairs (pa, pb) with pa + pb = s <= PLANES - 1
@@ -532,6 +544,9 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
             }
         }
     }
+#ifdef GT_ABL_X3_NOSTORE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
 
     if (LA == 1 && do_acs) {        // row sums of the (masked) A operand: combine the two k-halves of a row
 #pragma unroll

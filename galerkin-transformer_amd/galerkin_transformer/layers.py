@@ -11,6 +11,8 @@ import copy
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
