@@ -631,8 +631,8 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
         q.M = d->M; q.N = d->N; q.K = d->K; q.K2 = d->K2;
         q.a_vec = al16(d->A) && m4(d->lda) && m4(d->a_bs0) && m4(d->a_bs1);
         q.b_vec = al16(d->B) && m4(d->ldb) && m4(d->b_bs0) && m4(d->b_bs1);
-        if (d->ep_mode == GT_EP_HEADNORM) snprintf(buf, n, "void gt::gemm_x3r_kernel<0, 0, 3, R, %d>(gt::GemmP)", d->hn_dk);
-        else snprintf(buf, n, "%s", x3_kernel_name(q, d->layout_a, d->layout_b, pl.x3));
+        snprintf(buf, n, "%s", x3_kernel_name(q, d->layout_a, d->layout_b, pl.x3,
+                                              d->ep_mode == GT_EP_HEADNORM ? d->hn_dk : 0));
     }
     else if (pl.stream)
         snprintf(buf, n, "void gt::gemm_stream_kernel<%d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b, c.mt);

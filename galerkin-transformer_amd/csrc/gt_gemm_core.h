@@ -381,6 +381,6 @@ bool x3_shape_ok(const gt_gemm_desc* d);
 bool x3_headnorm_ok(const GemmP& p, int layout_a, int layout_b, int planes);
 int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned tiles, unsigned split, unsigned batch,
               hipStream_t st);
-const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes);
+const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes, int hn_dk = 0);
 
 }  // namespace gt

@@ -649,8 +649,12 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
     return 0;
 }
 
-const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes) {
+const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes, int hn_dk) {
     static thread_local char buf[112];
+    if (hn_dk > 0) {
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<0, 0, 3, %d, %d>(gt::GemmP)", x3_ring_depth(), hn_dk);
+        return buf;
+    }
     if (x3_use_ring(p, layout_a, layout_b))
         snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<%d, %d, %d, %d, 0>(gt::GemmP)", layout_a, layout_b, planes,
                  x3_ring_depth());

@@ -53,6 +53,37 @@ def test_run_train_synthetic_darcy(gpu_device, tmp_path):
     assert np.isfinite(m)
 
 
+def test_run_train_ns_rollout_device_loader_flat_adam(gpu_device, tmp_path):
+    """ex4 flow end to end (examples/ex4_navier_stokes_2+1d.py:9-106 at reduced size): synthetic NS trajectories ->
+    DeviceResidentLoader (dataset uploaded once) -> FourierTransformer2DLite -> FlatClipAdam + OneCycleLR ->
+    run_train with train_batch_ns / validate_epoch_ns (10-step rollout, one backward)."""
+    import galerkin_transformer as gt
+    from libs import OneCycleLR, WeightedL2Loss2d, get_seed, run_train
+    from libs.ns_lite import (DeviceResidentLoader, FourierTransformer2DLite, NavierStokesDatasetLite, train_batch_ns,
+                              validate_epoch_ns)
+    get_seed(1127802, printout=False)
+    train = NavierStokesDatasetLite(train_data=True, train_len=16, valid_len=4, synthetic_len=20)
+    valid = NavierStokesDatasetLite(train_data=False, train_len=16, valid_len=4, synthetic_len=20)
+    cfg = dict(node_feats=12, pos_dim=2, n_targets=1, n_hidden=24, num_encoder_layers=2, n_head=1, dim_feedforward=48,
+               attention_type="galerkin", layer_norm=True, attn_norm=False, xavier_init=0.01, diagonal_weight=0.01,
+               encoder_dropout=0.0, ffn_dropout=0.05, dropout=0.0, decoder_dropout=0.0, decoder_type="ifft2",
+               freq_dim=12, num_regressor_layers=2, fourier_modes=8, spacial_dim=2, spacial_fc=False, debug=False)
+    model = FourierTransformer2DLite(**cfg).to(gpu_device)
+    tl = DeviceResidentLoader(train, 4, gpu_device, shuffle=True, drop_last=True)
+    vl = DeviceResidentLoader(valid, 4, gpu_device)
+    assert next(iter(tl))["node"].is_cuda and len(tl) == 4
+    epochs = 5
+    opt = gt.FlatClipAdam(model.parameters(), lr=2e-3, max_norm=0.99)
+    sched = OneCycleLR(opt, max_lr=2e-3, div_factor=1e2, final_div_factor=1e2, steps_per_epoch=len(tl), epochs=epochs)
+    res = run_train(model, WeightedL2Loss2d(regularizer=True, h=1 / 64, gamma=0.1),
+                    WeightedL2Loss2d(regularizer=False, h=1 / 64), tl, vl, opt, sched, train_batch=train_batch_ns,
+                    validate_epoch=validate_epoch_ns, epochs=epochs, patience=None, tqdm_mode='epoch',
+                    model_name='ns.pt', result_name='ns.pkl', model_save_path=str(tmp_path), device=gpu_device)
+    lt = res["loss_train"][:, 0]
+    assert np.all(np.isfinite(lt)) and lt[-1] < 0.9 * lt[0]
+    assert np.isfinite(res["best_val_metric"])
+
+
 def test_graph_step_equals_eager_step(gpu_device):
     """Same seed => the captured training step (fwd+bwd+clip+Adam, all dropouts on) updates the
     parameters exactly like the eager step."""

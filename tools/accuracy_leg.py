@@ -31,7 +31,18 @@ SEED = 1127802
 N_TRAIN, N_VALID, BATCH, EPOCHS = 64, 16, 4, 8
 
 
+_DATASETS = None
+
+
 def datasets():
+    """(train, valid), built once per process (6 s of CPU for the 421-grid synthesis)."""
+    global _DATASETS
+    if _DATASETS is None:
+        _DATASETS = _build_datasets()
+    return _DATASETS
+
+
+def _build_datasets():
     from galerkin_transformer.ft import DarcyDataset
     kw = dict(subsample_attn=10, subsample_nodes=3, synthetic=True, n_samples_synthetic=N_TRAIN + N_VALID,
               random_state=SEED)
