@@ -219,6 +219,7 @@ class Trainer:
             from galerkin_transformer.distributed import FlatGradAllReducer
             self.reducer = FlatGradAllReducer(self.params)
         self.loss = torch.zeros((), device=self.dev)
+        self.comm_enabled = True
         self.g_fb = self.g_opt = None
         self.use_graph = use_graph
 
@@ -231,6 +232,8 @@ class Trainer:
             self.opt.gather_grads()          # grads -> the flat bucket the collective and the optimizer work on
 
     def comm(self):
+        if not self.comm_enabled:            # rank-local profiling step (roofline leg): no collective
+            return
         if self.flat:
             self.opt.all_reduce()            # ONE flat RCCL sum-all-reduce per step, in place, no copy back
         else:
@@ -315,8 +318,12 @@ def roofline_leg(trainer, precision):
     """Per-launch HIP-event timing of one eager step, then the dominant hot-path kernel re-timed back-to-back on the
     launch stream; plus the per-leg table (head norm, K^T V, FFN, Q.P) the north star asks for."""
     from galerkin_transformer import _hip
-    with _hip.Profile() as prof:
-        trainer.eager_step()
+    trainer.comm_enabled = False             # only rank 0 runs this leg: its profiled step must not enter a collective
+    try:
+        with _hip.Profile() as prof:
+            trainer.eager_step()
+    finally:
+        trainer.comm_enabled = True
     torch.cuda.synchronize()
     table = prof.table()
     if not table:

@@ -122,7 +122,8 @@ def test_bench_two_ranks_on_one_gpu_gloo(gpu_device):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
-           "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-f32-leg"]
+           "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]      # roofline + f32 legs stay on:
+    # rank 0's profiling step must not enter a collective the other rank never joins
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
@@ -130,6 +131,7 @@ def test_bench_two_ranks_on_one_gpu_gloo(gpu_device):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["hip_graph"]
     assert rec["value"] > 0 and np.isfinite(rec["config"]["final_loss"])
+    assert rec["roofline"] and rec["f32_mfma_exact"]["value"] > 0
 
 
 def _run_bench_ranks(extra, port, timeout=900):
