@@ -812,8 +812,11 @@ __global__ __launch_bounds__(256) void modemix_fwd_kernel(const float* __restric
         sWr[e] = w.x;
         sWi[e] = w.y;
     }
-    for (int bb = 0; bb < B; bb += MM_BCH) {
-        const int nb = min(MM_BCH, B - bb);
+    // the batch is cut into gridDim.y slices: Q = m*m blocks alone (144 for the Darcy decoder) leave the chip half empty
+    const int bchunk = (B + gridDim.y - 1) / gridDim.y;
+    const int bend = min(B, (int)(blockIdx.y + 1) * bchunk);
+    for (int bb = blockIdx.y * bchunk; bb < bend; bb += MM_BCH) {
+        const int nb = min(MM_BCH, bend - bb);
         __syncthreads();
         for (int e = threadIdx.x; e < nb * 2 * Cin; e += blockDim.x) {
             const int b = e / (2 * Cin), ri = (e / Cin) & 1, i = e % Cin;
@@ -857,8 +860,10 @@ __global__ __launch_bounds__(256) void modemix_bwd_kernel(
     float gr[MAXP], gi[MAXP];
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) gr[k] = gi[k] = 0.f;
-    for (int bb = 0; bb < B; bb += MM_BCH) {
-        const int nb = min(MM_BCH, B - bb);
+    const int bchunk = (B + gridDim.y - 1) / gridDim.y;      // batch slice of this block (dW: one partial per slice)
+    const int bend = min(B, (int)(blockIdx.y + 1) * bchunk);
+    for (int bb = blockIdx.y * bchunk; bb < bend; bb += MM_BCH) {
+        const int nb = min(MM_BCH, bend - bb);
         __syncthreads();
         for (int e = threadIdx.x; e < nb * 2 * Cin; e += blockDim.x) {
             const int b = e / (2 * Cin), ri = (e / Cin) & 1, i = e % Cin;
@@ -899,13 +904,17 @@ __global__ __launch_bounds__(256) void modemix_bwd_kernel(
             }
         }
     }
+    float* dWs = dW + (int64_t)blockIdx.y * Cin * Cout * Q * 2;       // slab of this batch slice (gridDim.y == 1: dW itself)
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
         const int e = threadIdx.x + k * 256;
         if (e < Cin * Cout)
-            *reinterpret_cast<float2*>(dW + ((int64_t)e * Q + q) * 2) = make_float2(gr[k], gi[k]);
+            *reinterpret_cast<float2*>(dWs + ((int64_t)e * Q + q) * 2) = make_float2(gr[k], gi[k]);
     }
 }
+
+// batch slices per mode block: enough blocks for ~3 per CU, at least 8 samples per slice
+static inline int modemix_slices(int B, int Q) { return std::max(1, std::min(ceil_div(768, Q), ceil_div(B, 8))); }
 
 // kernels whose dynamic LDS may exceed 64 KiB opt in once (host-side attribute, not a stream op)
 template <typename K>
@@ -1174,16 +1183,21 @@ extern "C" int gt_modemix_fwd(const float* X, const float* W, int32_t B, int32_t
     if ((reinterpret_cast<uintptr_t>(W) & 7) != 0) return GT_EALIGN;
     const size_t lds = ((size_t)2 * Cin * Cout + (size_t)MM_BCH * 2 * Cin) * sizeof(float);
     if (int rc = allow_big_lds(modemix_fwd_kernel, lds)) return rc;
-    hipLaunchKernelGGL(modemix_fwd_kernel, dim3(Q), dim3(256), lds, (hipStream_t)stream, X, W, B, Q, Cin,
-                       Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, Y);
+    hipLaunchKernelGGL(modemix_fwd_kernel, dim3(Q, modemix_slices(B, Q)), dim3(256), lds, (hipStream_t)stream, X, W, B,
+                       Q, Cin, Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, Y);
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int64_t gt_modemix_bwd_ws_bytes(int32_t B, int32_t Q, int32_t Cin, int32_t Cout) {
+    const int S = modemix_slices(B, Q);
+    return S > 1 ? (int64_t)S * Cin * Cout * Q * 2 * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int gt_modemix_bwd(const float* X, const float* W, const float* dY, int32_t B, int32_t Q,
                               int32_t Cin, int32_t Cout, int64_t x_bstride, int64_t y_bstride,
                               int32_t q_total_x, int32_t q_total_y, int32_t q_off, float* dX, float* dW,
-                              void* stream) {
+                              void* ws, int64_t ws_bytes, void* stream) {
     if (!X || !W || !dY || !dX || !dW || B <= 0 || Q <= 0 || Cin <= 0 || Cout <= 0 || q_off < 0 ||
         q_off + Q > q_total_x || q_off + Q > q_total_y)
         return GT_EINVAL;
@@ -1191,16 +1205,26 @@ extern "C" int gt_modemix_bwd(const float* X, const float* W, const float* dY, i
     if (Cin * Cout > 24 * 256) return GT_ENOTSUP;          // 96 x 48 (ex1 as shipped) = 18 pairs per thread
     const size_t lds =
         ((size_t)2 * Cin * Cout + (size_t)MM_BCH * 2 * Cin + (size_t)MM_BCH * 2 * Cout) * sizeof(float);
+    const int S = modemix_slices(B, Q);
+    const int64_t nW = (int64_t)Cin * Cout * Q * 2;
+    float* dWk = dW;                                       // S == 1: the kernel writes dW directly
+    if (S > 1) {
+        if (!ws || ws_bytes < gt_modemix_bwd_ws_bytes(B, Q, Cin, Cout)) return GT_EWS;
+        if (reinterpret_cast<uintptr_t>(ws) & 7) return GT_EALIGN;
+        dWk = reinterpret_cast<float*>(ws);
+    }
+    const dim3 grid((unsigned)Q, (unsigned)S);
     if (Cin * Cout <= 8 * 256) {
         if (int rc = allow_big_lds(modemix_bwd_kernel<8>, lds)) return rc;
-        hipLaunchKernelGGL(modemix_bwd_kernel<8>, dim3(Q), dim3(256), lds, (hipStream_t)stream, X, W, dY, B, Q, Cin,
-                           Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, dX, dW);
+        hipLaunchKernelGGL(modemix_bwd_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, X, W, dY, B, Q, Cin,
+                           Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, dX, dWk);
     } else {
         if (int rc = allow_big_lds(modemix_bwd_kernel<24>, lds)) return rc;
-        hipLaunchKernelGGL(modemix_bwd_kernel<24>, dim3(Q), dim3(256), lds, (hipStream_t)stream, X, W, dY, B, Q, Cin,
-                           Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, dX, dW);
+        hipLaunchKernelGGL(modemix_bwd_kernel<24>, grid, dim3(256), lds, (hipStream_t)stream, X, W, dY, B, Q, Cin,
+                           Cout, x_bstride, y_bstride, q_total_x, q_total_y, q_off, dX, dWk);
     }
     GT_LAUNCH_CHECK();
+    if (S > 1) return gt_slab_reduce(dWk, nW, S, nW, 1.f, dW, stream);      // fixed order: deterministic
     return 0;
 }
 

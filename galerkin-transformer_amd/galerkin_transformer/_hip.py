@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 8          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 9          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -117,8 +117,9 @@ _PROTOS = {
     "gt_layernorm_bwd_ws_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "gt_modemix_fwd": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_int64, C.c_int64] +
                        [C.c_int32] * 3 + [C.c_void_p, C.c_void_p]),
+    "gt_modemix_bwd_ws_bytes": (C.c_int64, [C.c_int32] * 4),
     "gt_modemix_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_int64, C.c_int64] +
-                       [C.c_int32] * 3 + [C.c_void_p] * 3),
+                       [C.c_int32] * 3 + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]),
     "gt_bilinear2d_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p]),
     "gt_bilinear2d_fwd_affine": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.POINTER(GtResizeAffine),
                                                                                 C.c_void_p]),
@@ -626,9 +627,11 @@ def modemix_fwd(X: torch.Tensor, W: torch.Tensor, Y: torch.Tensor, B: int, Q: in
 def modemix_bwd(X: torch.Tensor, W: torch.Tensor, dY: torch.Tensor, dX: torch.Tensor, dW: torch.Tensor,
                 B: int, Q: int, Cin: int, Cout: int, q_total: int, q_off: int):
     need_f32_cuda(X, W, dY, dX, dW)
+    need = lib().gt_modemix_bwd_ws_bytes(B, Q, Cin, Cout)
+    ws = workspace(X.device, need) if need > 0 else None
     check(_timed("gt_modemix_bwd", 0, 0, lambda: lib().gt_modemix_bwd(X.data_ptr(), W.data_ptr(), dY.data_ptr(), B, Q, Cin, Cout, 2 * q_total * Cin,
                                2 * q_total * Cout, q_total, q_total, q_off, dX.data_ptr(), dW.data_ptr(),
-                               stream_ptr())), "gt_modemix_bwd")
+                               ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())), "gt_modemix_bwd")
     return dX, dW
 
 

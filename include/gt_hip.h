@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 8
+#define GT_ABI_VERSION 9
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -325,14 +325,17 @@ int64_t gt_layernorm_bwd_ws_bytes(int32_t T, int32_t d);
  * W layout:    [Cin][Cout][Q][2]  (the reference's parameter layout; for 2-D the two corner
  *              blocks are passed as two calls or as Q = modes*modes each via `w_qstride`).
  * Backward: dX from dY and W ;  dW from X and dY (summed over the batch).
+ * The batch is cut into slices so that Q x slices blocks fill the chip; the backward's dW partials (one per slice) go
+ * through ws (gt_modemix_bwd_ws_bytes, 0 when one slice suffices) and are summed in a fixed order.
  * ------------------------------------------------------------------------------------------- */
 int gt_modemix_fwd(const float* X, const float* W, int32_t B, int32_t Q, int32_t Cin, int32_t Cout,
                    int64_t x_bstride, int64_t y_bstride, int32_t q_total_x, int32_t q_total_y,
                    int32_t q_off, float* Y, void* stream);
+int64_t gt_modemix_bwd_ws_bytes(int32_t B, int32_t Q, int32_t Cin, int32_t Cout);
 int gt_modemix_bwd(const float* X, const float* W, const float* dY, int32_t B, int32_t Q,
                    int32_t Cin, int32_t Cout, int64_t x_bstride, int64_t y_bstride,
                    int32_t q_total_x, int32_t q_total_y, int32_t q_off,
-                   float* dX, float* dW, void* stream);
+                   float* dX, float* dW, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Bilinear resize, align_corners=True (F.interpolate at layers.py:483-512, 658-670), with the

@@ -281,7 +281,8 @@ def test_layernorm(H, gpu_device):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,Q,qtot,qoff", [(4, 32, 32, 144, 288, 144), (3, 8, 16, 16, 16, 0),
-                                                    (20, 20, 12, 36, 72, 0)])
+                                                    (20, 20, 12, 36, 72, 0), (40, 32, 32, 144, 288, 0),
+                                                    (33, 8, 8, 16, 16, 0), (9, 64, 48, 16, 16, 0)])
 def test_modemix(H, gpu_device, B, Cin, Cout, Q, qtot, qoff):
     dev = gpu_device
     X = rnd(B, 2, qtot, Cin, dev=dev, seed=35)
