@@ -8,7 +8,7 @@ With --last-ms X : only dispatches that start in the last X ms of the trace (the
 steps of bench.py), aggregated from *_kernel_trace.csv."""
 import csv, glob, os, sys
 from collections import defaultdict
-argv = sys.argv[1:]
+argv = [a for a in sys.argv[1:] if a != "--by-grid"]
 last_ms = None
 if "--last-ms" in argv:
     i = argv.index("--last-ms")
@@ -28,7 +28,9 @@ if stats and last_ms is None:
 tr = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
 if not tr:
     print("no rocprofv3 csv found under", d); sys.exit(1)
-rows = [(r["Kernel_Name"], float(r["Start_Timestamp"]), float(r["End_Timestamp"])) for r in csv.DictReader(open(tr[0]))]
+by_grid = "--by-grid" in sys.argv        # split a symbol by launch geometry (e.g. the MIOpen kernels of different layers)
+rows = [(r["Kernel_Name"] + (f"  grid={r.get('Grid_Size_X', r.get('Grid_Size', '?'))}" if by_grid else ""),
+         float(r["Start_Timestamp"]), float(r["End_Timestamp"])) for r in csv.DictReader(open(tr[0]))]
 t_end = max(r[2] for r in rows)
 if last_ms is not None:
     rows = [r for r in rows if r[1] >= t_end - last_ms * 1e6]
