@@ -628,7 +628,7 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
     if (pl.x3) {
         GemmP q;
         memset(&q, 0, sizeof(q));
-        q.M = d->M; q.N = d->N; q.K = d->K; q.K2 = d->K2;
+        q.M = d->M; q.N = d->N; q.K = d->K; q.K2 = d->K2; q.cv_C = d->cv_c;
         q.a_vec = al16(d->A) && m4(d->lda) && m4(d->a_bs0) && m4(d->a_bs1);
         q.b_vec = al16(d->B) && m4(d->ldb) && m4(d->b_bs0) && m4(d->b_bs1);
         snprintf(buf, n, "%s", x3_kernel_name(q, d->layout_a, d->layout_b, pl.x3,
@@ -674,6 +674,14 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
         if (d->a_colsum || d->a_drop.p > 0.f) return GT_ENOTSUP;
     }
     if ((d->layout_a | d->layout_b) & ~1) return GT_EINVAL;
+    if (d->cv_c != 0) {                               // implicit 3x3 convolution on A (gt_hip.h: cv_*)
+        if (d->cv_c < 0 || d->cv_h <= 0 || d->cv_w <= 0 || d->K != 9 * d->cv_c ||
+            d->M % ((int64_t)d->cv_h * d->cv_w) != 0)
+            return GT_EINVAL;
+        if (d->layout_a || d->layout_b || (d->cv_c & 15) || d->batch0 * d->batch1 != 1 || d->split_k != 1 ||
+            d->a_drop.p > 0.f || d->a_colsum || d->K2 > 0 || d->ep_mode != GT_EP_NORMAL)
+            return GT_ENOTSUP;
+    }
     if (d->C && !getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return tsmm_run(d, ws, ws_bytes, stream);
     if (d->rp < 0 || d->rp > 8) return GT_EINVAL;
     if ((d->a_drop.p > 0.f && !d->a_drop.seed) || (d->drop.p > 0.f && !d->drop.seed)) return GT_EINVAL;
@@ -698,6 +706,12 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     p.b_vec = al16(d->B) && m4(d->ldb) && m4(d->b_bs0) && m4(d->b_bs1);
     p.a_drop = make_drop(&d->a_drop, d->a_drop_sign);
     p.a_drop_ld = d->a_drop_ld; p.a_drop_bstride = d->a_drop_bstride;
+    if (d->cv_c > 0) {
+        if (!pl.x3 || pl.split != 1) return GT_ENOTSUP;
+        p.cv_H = d->cv_h; p.cv_W = d->cv_w; p.cv_C = d->cv_c;
+        p.lda = d->cv_c;
+        p.a_vec = al16(d->A);
+    }
 
     if (d->K2 > 0) {
         if (!d->A2 || !d->B2 || d->a_drop.p > 0.f || d->a_colsum || pl.split != 1) return GT_ENOTSUP;

@@ -450,7 +450,23 @@ __device__ __forceinline__ void x3r_split(const float (&v)[8], bf16x8 (&out)[PLA
         out[pl] = __builtin_bit_cast(bf16x8, u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]});
 }
 
-template <int LA, int LB, int PLANES, int R, int HN = 0>      // HN = head width of the fused head-norm epilogue, 0 = general
+// Implicit 3x3 convolution (gt_hip.h: cv_*): the k-contiguous A image of a stage is the 16 channels [c0, c0 + 16) of
+// tap (dy, dx) of the tile's 128 pixels -- a lane's granule comes from its pixel's neighbour row, or from x3_zero
+// outside the picture.  A stage never straddles two taps (cv_C % 16 == 0).  `ok` = the lane's pixel's 9 tap-valid bits.
+__device__ __forceinline__ void x3r_issue_conv(const float* const (&rowp)[2], const int (&ok)[2], int tap, int c0, int W,
+                                               int C, char* img, int wave, int lane) {
+    const int shift = ((tap / 3 - 1) * W + (tap % 3 - 1)) * C + c0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave * 2 + i;
+        const int row = 16 * q + (lane >> 2), g = (lane & 3) ^ ((row >> 2) & 3);
+        const float* src = ((ok[i] >> tap) & 1) ? rowp[i] + shift + 4 * g : x3_zero;
+        __builtin_amdgcn_global_load_lds((x3_glb_ptr)src, (x3_lds_ptr)(img + q * 1024), 16, 0, 0);
+    }
+}
+
+// HN = head width of the fused head-norm epilogue (0 = general epilogue); CV = implicit 3x3 convolution on A
+template <int LA, int LB, int PLANES, int R, int HN = 0, bool CV = false>
 __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[R * X3R_STAGE];
 
@@ -484,10 +500,35 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
     float asum[2] = {0.f, 0.f};
 
     const int nk = (kend > kbeg) ? (kend - kbeg + X3_BK - 1) / X3_BK : 0;
+    // convolution: this lane's two pixels of the A image (fixed over the stages), and the running (tap, channel) of
+    // the next stage to request (stages are requested in order)
+    const float* cv_row[2] = {A, A};
+    int cv_ok[2] = {0, 0}, cv_tap = 0, cv_c0 = 0;
+    if (CV) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + 16 * (wave * 2 + i) + (lane >> 2);
+            if (m < p.M) {
+                const int pix = m % (p.cv_H * p.cv_W), y = pix / p.cv_W, x = pix - y * p.cv_W;
+                int ok = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    ok |= (((unsigned)(y + t / 3 - 1) < (unsigned)p.cv_H) && ((unsigned)(x + t % 3 - 1) < (unsigned)p.cv_W)) << t;
+                cv_ok[i] = ok;
+                cv_row[i] = A + (int64_t)m * p.cv_C;
+            }
+        }
+    }
     auto issue = [&](int s) {                      // stage s -> slot s % R : 4 load instructions per wave
         char* st = smem + (s % R) * X3R_STAGE;
         const int k0 = kbeg + s * X3_BK;
-        x3r_issue<LA>(A, p.lda, m0, p.M, k0, kend, st, wave, lane);
+        if (CV) {
+            x3r_issue_conv(cv_row, cv_ok, cv_tap, cv_c0, p.cv_W, p.cv_C, st, wave, lane);
+            cv_c0 += X3_BK;
+            if (cv_c0 == p.cv_C) { cv_c0 = 0; ++cv_tap; }
+        } else {
+            x3r_issue<LA>(A, p.lda, m0, p.M, k0, kend, st, wave, lane);
+        }
         x3r_issue<LB>(Bm, p.ldb, n0, p.N, k0, kend, st + X3R_OP, wave, lane);
     };
 #pragma unroll
@@ -641,6 +682,14 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
         GT_LAUNCH_CHECK();
         return 0;
     }
+    if (p.cv_C > 0) {                              // implicit convolution: ring kernel, depth 3
+        if (lay != 0 || !x3r_ok(p, 0, 0) || (p.cv_C & 15) || split != 1 || batch != 1) return GT_ENOTSUP;
+        if (planes == 1) hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 1, 3, 0, true>), grid, dim3(256), 0, st, p);
+        else if (planes == 2) hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 2, 3, 0, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 3, 3, 0, true>), grid, dim3(256), 0, st, p);
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
     if (lay == 0) x3_launch_planes<0, 0>(p, planes, ring, grid, st);
     else if (lay == 1) x3_launch_planes<0, 1>(p, planes, ring, grid, st);
     else if (lay == 2) x3_launch_planes<1, 0>(p, planes, ring, grid, st);
@@ -652,11 +701,13 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
 const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes, int hn_dk) {
     static thread_local char buf[112];
     if (hn_dk > 0) {
-        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<0, 0, 3, %d, %d>(gt::GemmP)", x3_ring_depth(), hn_dk);
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<0, 0, 3, %d, %d, false>(gt::GemmP)", x3_ring_depth(), hn_dk);
         return buf;
     }
-    if (x3_use_ring(p, layout_a, layout_b))
-        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<%d, %d, %d, %d, 0>(gt::GemmP)", layout_a, layout_b, planes,
+    if (p.cv_C > 0)
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<0, 0, %d, 3, 0, true>(gt::GemmP)", planes);
+    else if (x3_use_ring(p, layout_a, layout_b))
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<%d, %d, %d, %d, 0, false>(gt::GemmP)", layout_a, layout_b, planes,
                  x3_ring_depth());
     else
         snprintf(buf, sizeof(buf), "void gt::gemm_x3_kernel<%d, %d, %d>(gt::GemmP)", layout_a, layout_b, planes);

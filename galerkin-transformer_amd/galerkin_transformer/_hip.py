@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 9          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 10          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -61,6 +61,7 @@ class GtGemmDesc(C.Structure):
         ("hn_stats", C.c_void_p), ("hn_h", C.c_int32), ("hn_dk", C.c_int32), ("hn_p", C.c_int32),
         ("hn_norm_mask", C.c_int32), ("hn_eps", C.c_float),
         ("precision", C.c_int32),
+        ("cv_h", C.c_int32), ("cv_w", C.c_int32), ("cv_c", C.c_int32),
     ]
 
 
@@ -372,9 +373,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          dw2: Optional[torch.Tensor] = None,
          K2: int = 0, A2: Optional[torch.Tensor] = None, lda2: int = 0, a2_bs=(0, 0),
          B2: Optional[torch.Tensor] = None, ldb2: int = 0, b2_bs=(0, 0), hn: Optional[dict] = None,
-         precision: Optional[str] = None):
+         precision: Optional[str] = None, conv: Optional[Tuple[int, int, int]] = None):
     """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics).  precision=None uses the module mode
-    (set_precision)."""
+    (set_precision).  conv=(H, W, C): A is a channels-last [B, H, W, C] image and the product is the implicit 3x3
+    convolution (K = 9*C; gt_hip.h: cv_*)."""
     need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, a_colsum)
     L = lib()
     d = GtGemmDesc()
@@ -424,6 +426,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         d.hn_gamma, d.hn_beta, d.hn_pos = ptr(hn.get("gamma")), ptr(hn.get("beta")), ptr(hn.get("pos"))
         d.hn_out, d.hn_stats = hn["out"].data_ptr(), ptr(hn.get("stats"))
         d.hn_h, d.hn_dk, d.hn_p, d.hn_norm_mask, d.hn_eps = hn["h"], hn["dk"], hn["p"], hn["norm_mask"], hn["eps"]
+    if conv is not None:
+        d.cv_h, d.cv_w, d.cv_c = conv
     need = L.gt_gemm_ws_bytes(C.byref(d))
     wsp, wsn = None, 0
     if need > 0:
@@ -440,7 +444,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         key = nm.value.decode().replace("void gt::", "").replace("(gt::GemmP)", "").replace("(gt::TsmmP)", "")
         key += "+splitk" if (sp.value > 1 and "tsmm" not in key) else ""
         flops = 2.0 * M * N * (K + K2) * nb
-        nbytes = 4.0 * nb * (M * K + K * N + M * N * (1 + (res is not None) + (aux is not None) +
+        nbytes = 4.0 * nb * (M * (conv[2] if conv else K) + K * N + M * N * (1 + (res is not None) + (aux is not None) +
                                                       (add is not None) + (pre is not None)))
         keep = (A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, d)
         st = stream_ptr()

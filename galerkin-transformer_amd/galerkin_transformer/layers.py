@@ -218,15 +218,25 @@ class Interp2dUpsample(nn.Module):
         self.interp_mode = interp_mode
         self.debug = debug
 
-    def forward_features(self, x, in_nhwc=False):
-        """Everything but the final resize: (B, C, H1, W1) channels-first at the intermediate size."""
+    def features_nhwc(self) -> bool:
+        """True when the conv block runs channels-last on the implicit-GEMM convolution (ops.conv3x3_nhwc): the
+        intermediate feature map is then (B, H1, W1, C) and no layout change happens anywhere in the scaler."""
+        return (self.conv_block and self.interp_mode == "bilinear" and self.conv[0].plain()
+                and ops.conv3x3_nhwc_ok(self.conv[0].conv[0]))
+
+    def forward_features(self, x, in_nhwc=False, out_nhwc=False):
+        """Everything but the final resize, at the intermediate size: (B, C, H1, W1) channels-first, or (B, H1, W1, C)
+        with ``out_nhwc`` (only when ``features_nhwc()``)."""
         if self.interp_mode != "bilinear":
             raise NotImplementedError(f"interp_mode={self.interp_mode!r}: only bilinear has a HIP path")
-        x = _resize(x, self.interp_size[0], None, in_nhwc=in_nhwc)
+        if out_nhwc and not self.features_nhwc():
+            raise ValueError("Interp2dUpsample: channels-last features need the implicit-GEMM conv block")
+        x = _resize(x, self.interp_size[0], None, in_nhwc=in_nhwc, out_nhwc=out_nhwc)
         if self.conv_block:
             blk = self.conv[0]
             if blk.plain():       # conv -> drop -> act -> drop -> act: the four elementwise stages in one pass
-                x = ops.drop_act(blk.conv[0](x), blk.conv[1].p, _act_name(blk.activation), self.training,
+                y = ops.conv3x3_nhwc(x, blk.conv[0].weight) if out_nhwc else blk.conv[0](x)
+                x = ops.drop_act(y, blk.conv[1].p, _act_name(blk.activation), self.training,
                                  self.dropout.p, _act_name(self.activation))
             else:
                 x = ops.drop_act(blk(x), self.dropout.p, _act_name(self.activation), self.training)
@@ -234,7 +244,9 @@ class Interp2dUpsample(nn.Module):
 
     def forward(self, x, in_nhwc=False, out_nhwc=False):
         """x (B, C, H, W), or (B, H, W, C) with ``in_nhwc``; the layout changes ride on the resizes."""
-        return _resize(self.forward_features(x, in_nhwc), self.interp_size[1], None, out_nhwc=out_nhwc)
+        mid = self.features_nhwc()
+        return _resize(self.forward_features(x, in_nhwc, mid), self.interp_size[1], None, in_nhwc=mid,
+                       out_nhwc=out_nhwc)
 
 
 # --------------------------------------------------------------------------------------- attention (HIP)

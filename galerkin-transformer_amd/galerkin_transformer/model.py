@@ -157,13 +157,13 @@ class SpectralRegressor(nn.Module):
         self.return_latent = return_latent
         self.debug = debug
 
-    def forward(self, x, edge=None, pos=None, grid=None, upsample_to=None):
-        """``upsample_to=(Ho, Wo)``: x is the channels-first (B, C, H1, W1) feature map BEFORE the scaler's
-        final bilinear resize; the resize is then commuted behind ``fc`` (ops.upsample_fc)."""
+    def forward(self, x, edge=None, pos=None, grid=None, upsample_to=None, x_nhwc=False):
+        """``upsample_to=(Ho, Wo)``: x is the (B, C, H1, W1) feature map -- (B, H1, W1, C) with ``x_nhwc`` -- BEFORE the
+        scaler's final bilinear resize; the resize is then commuted behind ``fc`` (ops.upsample_fc)."""
         x_latent = []
         if upsample_to is not None:
             assert self.spacial_fc
-            x = ops.upsample_fc(x, upsample_to, self.fc.weight, self.fc.bias, grid)
+            x = ops.upsample_fc(x, upsample_to, self.fc.weight, self.fc.bias, grid, x_nhwc=x_nhwc)
         elif self.spacial_fc:
             x = ops.linear(x, self.fc.weight, self.fc.bias, extra=grid)
         for layer in self.spectral_conv:
@@ -426,8 +426,9 @@ class FourierTransformer2D(_ConfiguredModel):
                 and grid is not None and not (self.training and self.dpo.p > 0)):
             # nothing sits between the upscaler's last resize and the regressor's fc: run fc at the coarse
             # resolution and interpolate its freq_dim channels instead of the n_hidden ones
-            x = self.regressor(up.forward_features(x, in_nhwc=True), grid=grid,
-                               upsample_to=tuple(up.interp_size[1]))
+            mid = up.features_nhwc()
+            x = self.regressor(up.forward_features(x, in_nhwc=True, out_nhwc=mid), grid=grid,
+                               upsample_to=tuple(up.interp_size[1]), x_nhwc=mid)
         else:
             x = self.upscaler(x)
             if self.return_latent:

@@ -7,6 +7,7 @@ backward; torch only owns the tensors and the autograd graph.  Reference call si
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -171,32 +172,38 @@ class UpsampleFcFn(Function):
 
         fc(cat[up(x), grid]) = up(x W_x^T) + grid W_g^T + b
 
-    x: (B, K, Hi, Wi) channels-first (what the scaler's conv block produces); weight (N, K+p); grid
-    (B, Ho, Wo, p).  Returns (B, Ho, Wo, N).  Only valid when nothing (dropout) sits between the resize and
-    the Linear -- the caller checks."""
+    x: (B, K, Hi, Wi) channels-first, or (B, Hi, Wi, K) with ``x_nhwc`` (what the scaler's conv block produces on
+    its NCHW / implicit-GEMM path); weight (N, K+p); grid (B, Ho, Wo, p).  Returns (B, Ho, Wo, N).  Only valid when
+    nothing (dropout) sits between the resize and the Linear -- the caller checks."""
 
     @staticmethod
-    def forward(ctx, x, size, weight, bias, grid):
+    def forward(ctx, x, size, weight, bias, grid, x_nhwc):
         H.need_f32_cuda(x, weight, bias, grid)
-        B, K, Hi, Wi = x.shape
+        if x_nhwc:
+            B, Hi, Wi, K = x.shape
+        else:
+            B, K, Hi, Wi = x.shape
         N, p = weight.shape[0], grid.shape[-1]
         assert weight.shape[1] == K + p
         Ho, Wo = size
         xc, w, gc = _c(x), _c(weight), _c(grid)
         dev, HW = x.device, Hi * Wi
         z = torch.empty(B, Hi, Wi, N, dtype=torch.float32, device=dev)
-        H.gemm(xc, w, z, HW, N, K, layout_a=1, lda=HW, ldb=K + p, ldc=N, batch=(B, 1), a_bs=(K * HW, 0),
-               c_bs=(HW * N, 0))
+        if x_nhwc:
+            H.gemm(xc, w, z, B * HW, N, K, lda=K, ldb=K + p, ldc=N)
+        else:
+            H.gemm(xc, w, z, HW, N, K, layout_a=1, lda=HW, ldb=K + p, ldc=N, batch=(B, 1), a_bs=(K * HW, 0),
+                   c_bs=(HW * N, 0))
         out = H.bilinear2d_fwd(z, (Ho, Wo), True, True, H.ACT_NONE, bias=bias, rp_a=gc.reshape(B, Ho, Wo, p),
                                rp_b=w[:, K:], rp_ldb=K + p)
         ctx.save_for_backward(xc, w, gc)
-        ctx.cfg = (B, K, Hi, Wi, Ho, Wo, N, p, bias is not None)
+        ctx.cfg = (B, K, Hi, Wi, Ho, Wo, N, p, bias is not None, x_nhwc)
         return out
 
     @staticmethod
     def backward(ctx, g):
         xc, w, gc = ctx.saved_tensors
-        B, K, Hi, Wi, Ho, Wo, N, p, has_b = ctx.cfg
+        B, K, Hi, Wi, Ho, Wo, N, p, has_b, x_nhwc = ctx.cfg
         dev, HW, To = g.device, Hi * Wi, B * Ho * Wo
         gg = _c(g)
         f32 = dict(dtype=torch.float32, device=dev)
@@ -206,6 +213,16 @@ class UpsampleFcFn(Function):
         # d W_g = g^T grid  (+ d bias = column sums of g as a by-product)
         H.gemm(gg, gc, dw[:, K:], N, p, To, layout_a=1, layout_b=1, lda=N, ldb=p, ldc=K + p, split_k=0,
                a_colsum=db)
+        dx = None
+        if x_nhwc:
+            # d W_x^T [K, N] = x^T dz over all B*HW pixels: the tall-skinny reduction (gt_tsmm.hip)
+            dwxt = torch.empty(K, N, **f32)
+            H.gemm(xc, dz, dwxt, K, N, B * HW, layout_a=1, layout_b=1, lda=K, ldb=N, ldc=N, split_k=0)
+            dw[:, :K].copy_(dwxt.t())
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(B, Hi, Wi, K, **f32)
+                H.gemm(dz, w, dx, B * HW, K, N, layout_b=1, lda=N, ldb=K + p, ldc=K)
+            return dx, None, dw, db, None, None
         # d W_x = sum_b dz_b^T x_b^T : one [N, K] slab per batch entry, reduced in a fixed order
         slabs = torch.empty(B, N, K, **f32)
         H.gemm(dz, xc, slabs, N, K, HW, layout_a=1, layout_b=0, lda=N, ldb=HW, ldc=K, batch=(B, 1),
@@ -213,19 +230,83 @@ class UpsampleFcFn(Function):
         dwx = torch.empty(N, K, **f32)
         H.slab_reduce(slabs, B, N * K, N * K, dwx)
         dw[:, :K].copy_(dwx)
-        dx = None
         if ctx.needs_input_grad[0]:
             # dx_b [K, HW] = W_x^T dz_b^T
             dx = torch.empty(B, K, Hi, Wi, **f32)
             H.gemm(w, dz, dx, K, HW, N, layout_a=1, layout_b=0, lda=K + p, ldb=N, ldc=HW, batch=(B, 1),
                    b_bs=(HW * N, 0), c_bs=(K * HW, 0))
-        return dx, None, dw, db, None
+        return dx, None, dw, db, None, None
 
 
-def upsample_fc(x_cf, size, weight, bias, grid):
+def upsample_fc(x, size, weight, bias, grid, x_nhwc: bool = False):
     if grid.requires_grad:
         raise NotImplementedError("ops.upsample_fc: `grid` gets no gradient")
-    return UpsampleFcFn.apply(x_cf, (int(size[0]), int(size[1])), weight, bias, grid)
+    return UpsampleFcFn.apply(x, (int(size[0]), int(size[1])), weight, bias, grid, bool(x_nhwc))
+
+
+# ----------------------------------------------------------------------------------- 3x3 convolution, channels-last
+def conv3x3_nhwc_ok(conv: torch.nn.Conv2d) -> bool:
+    """True when ``conv`` is a scaler-block convolution the implicit-GEMM path covers: 3x3, stride 1, zero padding 1,
+    no bias / groups / dilation, both channel counts multiples of 16 and >= 96 (whole tiles of the split-operand ring
+    kernel in the forward AND the data-gradient product), and a split-operand arithmetic mode."""
+    return (isinstance(conv, torch.nn.Conv2d) and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
+            and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and conv.bias is None and conv.padding_mode == "zeros"
+            and conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0
+            and conv.in_channels >= 96 and conv.out_channels >= 96 and H.get_precision() != "f32"
+            and _conv_implicit[0])
+
+
+_conv_implicit = [os.environ.get("GT_CONV_IMPLICIT", "1") != "0"]        # A/B switch (tools / tests)
+
+
+class Conv3x3NhwcFn(Function):
+    """y = conv2d(x, weight, padding=1) on channels-last activations, as implicit GEMMs on the split-operand ring kernel.
+
+    Replaces ``nn.Conv2d(C, C', 3, padding=1, bias=False)`` of the scaler blocks (layers.py:98-100 inside
+    Interp2dUpsample, layers.py:624-670) where the channel counts fill the 128 x 128 tiles (the up-scaler's
+    n_hidden -> n_hidden convolution).  Forward: [pixels, 9 C] x [C', 9 C]^T with the nine shifted views of x read in
+    place (gt_hip.h: cv_*).  Data gradient: the same product on gy with the taps reversed and the channel roles
+    swapped.  Weight gradient: the library's channels-last wrw convolution kernel (MIOpen) on the same buffers -- the only
+    piece of the convolution that is not this repo's kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        H.need_f32_cuda(x, weight)
+        B, Hh, Ww, Cin = x.shape
+        Cout = weight.shape[0]
+        xc = _c(x)
+        wf = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()       # [Cout][tap][Cin]
+        y = torch.empty(B, Hh, Ww, Cout, dtype=torch.float32, device=x.device)
+        H.gemm(xc, wf, y, B * Hh * Ww, Cout, 9 * Cin, lda=Cin, ldb=9 * Cin, ldc=Cout, conv=(Hh, Ww, Cin))
+        ctx.save_for_backward(xc, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, weight = ctx.saved_tensors
+        B, Hh, Ww, Cin = xc.shape
+        Cout = weight.shape[0]
+        g = _c(gy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dx[pix][ci] = sum_tap sum_co gy[pix - shift(tap)][co] W[co][ci][tap]: tap' = 8 - tap has the opposite shift
+            wd = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()      # [Cin][tap'][Cout]
+            dx = torch.empty(B, Hh, Ww, Cin, dtype=torch.float32, device=g.device)
+            H.gemm(g, wd, dx, B * Hh * Ww, Cin, 9 * Cout, lda=Cout, ldb=9 * Cout, ldc=Cin, conv=(Hh, Ww, Cout))
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(
+                g.permute(0, 3, 1, 2), xc.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last),
+                None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].contiguous()
+        return dx, dw
+
+
+def conv3x3_nhwc(x, weight):
+    """x (B, H, W, Cin) channels-last, weight (Cout, Cin, 3, 3) -> (B, H, W, Cout); see Conv3x3NhwcFn.  Less than one
+    tile of pixels (< 96) goes to the library convolution on the same buffers."""
+    if x.shape[0] * x.shape[1] * x.shape[2] < 96:
+        return torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), weight, padding=1).permute(0, 2, 3, 1).contiguous()
+    return Conv3x3NhwcFn.apply(x, weight)
 
 
 # ----------------------------------------------------------------------------------- Linear

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 9
+#define GT_ABI_VERSION 10
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -176,6 +176,16 @@ typedef struct gt_gemm_desc {
      * (fused heads, head-norm epilogue, narrow or tiny problems, the tall-skinny path) stays on the fp32 pipe in
      * every mode. */
     int32_t precision;
+
+    /* Implicit 3x3 convolution (stride 1, zero padding 1) on channels-last activations: cv_c > 0 makes A a
+     * [B, cv_h, cv_w, cv_c] image, M = B*cv_h*cv_w its pixels, K = 9*cv_c, and the contraction index k = tap*cv_c + c
+     * with tap = 3*(dy+1) + (dx+1) reads A[pixel + (dy, dx)][c] (zero outside the image) -- the im2col matrix is never
+     * written.  B is then the filter as [N][9*cv_c] (layout_b = 0), i.e. an nn.Conv2d weight in channels-last memory
+     * for the forward product (layers.py:98-100 `nn.Conv2d(.., kernel_size=3, padding=1, bias=False)` of the scaler
+     * blocks), or the tap-reversed, in/out-swapped filter for the data gradient.  Split-operand ring kernel only:
+     * precision != GT_PREC_F32, layout_a = layout_b = 0, cv_c % 16 == 0, no batching, no split-K, no A dropout,
+     * M, N >= 96; anything else returns GT_ENOTSUP (the caller then uses its library convolution). */
+    int32_t cv_h, cv_w, cv_c;
 } gt_gemm_desc;
 
 #define GT_PREC_F32    0

@@ -906,3 +906,95 @@ def test_qkv_headnorm_fused_epilogue(H, gpu_device, T, h, dk, p, mask):
     nn = bin(mask).count("1")
     if nn:
         assert rel_l2(stats[:nn], st_ref[:nn]) < 1e-6
+
+
+@pytest.mark.parametrize("B,Hh,Ww,Cin,Cout", [(3, 13, 11, 128, 128), (1, 77, 77, 96, 144), (2, 5, 40, 112, 96),
+                                              (1, 1, 100, 128, 128), (1, 1, 7, 128, 128), (4, 16, 16, 256, 128)])
+def test_conv3x3_implicit_gemm(H, gpu_device, B, Hh, Ww, Cin, Cout):
+    """ops.conv3x3_nhwc (implicit GEMM on the split-operand ring kernel: forward and data gradient; MIOpen wrw for the
+    weight gradient) == F.conv2d(padding=1) in fp64 on the CPU (layers.py:98-100 inside Interp2dUpsample), outputs and
+    both gradients.  Shapes cover partial pixel tiles, one-row images (every vertical tap masked) and the N = 144 width
+    split; the 7-pixel image is below one tile and takes the library convolution."""
+    import torch.nn.functional as F
+    from galerkin_transformer import ops
+    x = rnd(B, Cin, Hh, Ww, dev="cpu", seed=120).double().requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, dev="cpu", seed=121, scale=0.05).double().requires_grad_(True)
+    ref = F.conv2d(x, w, padding=1)
+    cot = rnd(*ref.shape, dev="cpu", seed=122).double()
+    gx, gw = torch.autograd.grad(ref, (x, w), cot)
+    xg = x.detach().float().permute(0, 2, 3, 1).contiguous().to(gpu_device).requires_grad_(True)
+    wg = w.detach().float().to(gpu_device).requires_grad_(True)
+    y = ops.conv3x3_nhwc(xg, wg)
+    y.backward(cot.float().permute(0, 2, 3, 1).contiguous().to(gpu_device))
+    torch.cuda.synchronize()
+    assert rel_l2(y.permute(0, 3, 1, 2), ref) < KTOL
+    assert rel_l2(xg.grad.permute(0, 3, 1, 2), gx) < KTOL
+    assert wg.grad.shape == w.shape and wg.grad.is_contiguous()
+    assert rel_l2(wg.grad, gw) < 1e-5          # the library's wrw kernel (own accumulation order)
+
+
+def test_conv3x3_implicit_gemm_rejects_what_it_does_not_cover(H, gpu_device):
+    """cv_c must be a multiple of 16, K = 9 cv_c, no split-K / batching, split-operand arithmetic only."""
+    dev = gpu_device
+    x = rnd(2, 8, 8, 128, dev=dev, seed=130)
+    w = rnd(128, 9 * 128, dev=dev, seed=131)
+    y = torch.empty(2, 8, 8, 128, device=dev)
+    kw = dict(lda=128, ldb=9 * 128, ldc=128)
+    with pytest.raises(NotImplementedError):
+        H.gemm(x, w, y, 128, 128, 9 * 128, conv=(8, 8, 128), precision="f32", **kw)
+    with pytest.raises(NotImplementedError):
+        H.gemm(x, w, y, 128, 128, 9 * 128, conv=(8, 8, 128), split_k=2, **kw)
+    with pytest.raises(H.GtError, match="EINVAL"):
+        H.gemm(x, w, y, 128, 128, 8 * 128, conv=(8, 8, 128), **kw)           # K != 9 C
+    with pytest.raises(H.GtError, match="EINVAL"):
+        H.gemm(x, w, y, 100, 128, 9 * 128, conv=(8, 8, 128), **kw)           # M not whole images
+    x24 = rnd(2, 8, 8, 24, dev=dev, seed=132)
+    with pytest.raises(NotImplementedError):
+        H.gemm(x24, w, y, 128, 128, 9 * 24, conv=(8, 8, 24), lda=24, ldb=9 * 24, ldc=128)
+
+
+def test_upsample_fc_channels_last_equals_channels_first(H, gpu_device):
+    """ops.upsample_fc(x_nhwc=True) (plain token GEMMs + the tall-skinny weight gradient) == the channels-first
+    formulation on the same numbers, outputs and all gradients."""
+    from galerkin_transformer import ops
+    dev = gpu_device
+    B, K, Hi, Ho, N, p = 3, 128, 20, 37, 32, 2
+    x = rnd(B, K, Hi, Hi, dev=dev, seed=140)
+    W = rnd(N, K + p, dev=dev, seed=141, scale=0.2)
+    b = rnd(N, dev=dev, seed=142)
+    grid = rnd(B, Ho, Ho, p, dev=dev, seed=143)
+    cot = rnd(B, Ho, Ho, N, dev=dev, seed=144)
+    res = []
+    for nhwc in (False, True):
+        xx = (x.permute(0, 2, 3, 1).contiguous() if nhwc else x.clone()).requires_grad_(True)
+        Wg, bg = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        out = ops.upsample_fc(xx, (Ho, Ho), Wg, bg, grid, x_nhwc=nhwc)
+        out.backward(cot)
+        res.append((out, xx.grad.permute(0, 3, 1, 2) if nhwc else xx.grad, Wg.grad, bg.grad))
+    for a, c in zip(*res):
+        assert rel_l2(a, c) < 2e-6
+
+
+def test_upscaler_channels_last_path_equals_channels_first(H, gpu_device):
+    """Interp2dUpsample (layers.py:624-670) with the implicit-GEMM conv block (all channels-last) == the same module on
+    the library convolution (channels-first), forward and every gradient, dropout off."""
+    from galerkin_transformer import layers, ops
+    dev = gpu_device
+    torch.manual_seed(5)
+    up = layers.Interp2dUpsample(128, 128, interp_size=((19, 19), (31, 31)), dropout=0.0).to(dev)
+    x = rnd(2, 11, 11, 128, dev=dev, seed=150)
+    cot = rnd(2, 31, 31, 128, dev=dev, seed=151)
+    res = []
+    for implicit in (True, False):
+        ops._conv_implicit[0] = implicit
+        try:
+            assert up.features_nhwc() == implicit
+            up.zero_grad()
+            xx = x.clone().requires_grad_(True)
+            y = up(xx, in_nhwc=True, out_nhwc=True)
+            y.backward(cot)
+            res.append((y, xx.grad, up.conv[0].conv[0].weight.grad.clone()))
+        finally:
+            ops._conv_implicit[0] = True
+    for a, c in zip(*res):
+        assert rel_l2(a, c) < 5e-6
