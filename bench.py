@@ -398,15 +398,16 @@ def roofline_leg(trainer, precision):
     except (OSError, ValueError):
         pmc = {}
     legs = {}
-    for label, key, sym in (("qkv_proj+headnorm_fwd", "gemm_x3r_kernel<0, 0, 3, 3, 32, false>", "gt::gemm_x3r_kernel<0, 0, 3, 3, 32, false>"),
+    for label, key, sym in (("qkv_proj+headnorm_fwd", "gemm_x3r_kernel<0, 0, 3, 3, 32, 0>", "gt::gemm_x3r_kernel<0, 0, 3, 3, 32, 0>"),
                             ("headnorm_fwd", "gt_headnorm_fwd", "gt::headnorm_fwd_v2_kernel"),
                             ("headnorm_bwd", "gt_headnorm_bwd", "gt::headnorm_bwd_v2_kernel"),
                             ("galerkin_ktv", "gt_galerkin_ktv", "gt::galerkin_ktv_kernel<2>"),
                             ("galerkin_dkv", "gt_galerkin_dkv", "gt::galerkin_dkv_kernel<2>"),
-                            ("token_gemm_KN", "gemm_x3r_kernel<0, 1, 3, 3, 0, false>", "gt::gemm_x3r_kernel<0, 1, 3, 3, 0, false>"),
-                            ("token_gemm_NK(ffn)", "gemm_x3r_kernel<0, 0, 3, 3, 0, false>", "gt::gemm_x3r_kernel<0, 0, 3, 3, 0, false>"),
-                            ("conv3x3_implicit", "gemm_x3r_kernel<0, 0, 3, 3, 0, true>", "gt::gemm_x3r_kernel<0, 0, 3, 3, 0, true>"),
-                            ("weight_gradients", "gemm_x3r_kernel<1, 1, 3, 3, 0, false>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, false>")):
+                            ("token_gemm_KN", "gemm_x3r_kernel<0, 1, 3, 3, 0, 0>", "gt::gemm_x3r_kernel<0, 1, 3, 3, 0, 0>"),
+                            ("token_gemm_NK(ffn)", "gemm_x3r_kernel<0, 0, 3, 3, 0, 0>", "gt::gemm_x3r_kernel<0, 0, 3, 3, 0, 0>"),
+                            ("conv3x3_implicit", "gemm_x3r_kernel<0, 0, 3, 3, 0, 1>", "gt::gemm_x3r_kernel<0, 0, 3, 3, 0, 1>"),
+                            ("conv3x3_wgrad", "gemm_x3r_kernel<1, 1, 3, 3, 0, 2>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 2>"),
+                            ("weight_gradients", "gemm_x3r_kernel<1, 1, 3, 3, 0, 0>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 0>")):
         t = table.get(key) or table.get(key.replace("+splitk", ""))
         if not t or t["ms"] <= 0:
             continue

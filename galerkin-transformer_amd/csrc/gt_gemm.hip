@@ -570,6 +570,8 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
             if (split < 1) split = 1;
         }
     }
+    if (d->cv_c > 0 && d->cv_wgrad)                   // nine taps per chunk: ~3 resident blocks per CU, whole XCD groups
+        split = (int)std::max<int64_t>(1, std::min<int64_t>((768 + blocks - 1) / blocks, d->K / (4 * pl->bk)));
     if (split > 1 && has_epilogue(d)) return GT_ENOTSUP;
     if (split > 1024) split = 1024;
     int chunk = ceil_div(std::max(d->K, 1), split);
@@ -628,7 +630,7 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
     if (pl.x3) {
         GemmP q;
         memset(&q, 0, sizeof(q));
-        q.M = d->M; q.N = d->N; q.K = d->K; q.K2 = d->K2; q.cv_C = d->cv_c;
+        q.M = d->M; q.N = d->N; q.K = d->K; q.K2 = d->K2; q.cv_C = d->cv_c; q.cv_wgrad = d->cv_wgrad != 0;
         q.a_vec = al16(d->A) && m4(d->lda) && m4(d->a_bs0) && m4(d->a_bs1);
         q.b_vec = al16(d->B) && m4(d->ldb) && m4(d->b_bs0) && m4(d->b_bs1);
         snprintf(buf, n, "%s", x3_kernel_name(q, d->layout_a, d->layout_b, pl.x3,
@@ -675,12 +677,19 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     }
     if ((d->layout_a | d->layout_b) & ~1) return GT_EINVAL;
     if (d->cv_c != 0) {                               // implicit 3x3 convolution on A (gt_hip.h: cv_*)
-        if (d->cv_c < 0 || d->cv_h <= 0 || d->cv_w <= 0 || d->K != 9 * d->cv_c ||
-            d->M % ((int64_t)d->cv_h * d->cv_w) != 0)
-            return GT_EINVAL;
-        if (d->layout_a || d->layout_b || (d->cv_c & 15) || d->batch0 * d->batch1 != 1 || d->split_k != 1 ||
-            d->a_drop.p > 0.f || d->a_colsum || d->K2 > 0 || d->ep_mode != GT_EP_NORMAL)
-            return GT_ENOTSUP;
+        if (d->cv_c < 0 || d->cv_h <= 0 || d->cv_w <= 0) return GT_EINVAL;
+        if (d->cv_wgrad) {
+            if (d->K % ((int64_t)d->cv_h * d->cv_w) != 0 || d->N != d->cv_c || d->batch0 != 9 || d->batch1 != 1)
+                return GT_EINVAL;
+            if (d->layout_a != 1 || d->layout_b != 1 || d->split_k != 0 || d->cv_w < 16 || has_epilogue(d) ||
+                d->a_drop.p > 0.f || d->a_colsum)
+                return GT_ENOTSUP;
+        } else {
+            if (d->K != 9 * d->cv_c || d->M % ((int64_t)d->cv_h * d->cv_w) != 0) return GT_EINVAL;
+            if (d->layout_a || d->layout_b || (d->cv_c & 15) || d->batch0 * d->batch1 != 1 || d->split_k != 1 ||
+                d->a_drop.p > 0.f || d->a_colsum || d->K2 > 0 || d->ep_mode != GT_EP_NORMAL)
+                return GT_ENOTSUP;
+        }
     }
     if (d->C && !getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return tsmm_run(d, ws, ws_bytes, stream);
     if (d->rp < 0 || d->rp > 8) return GT_EINVAL;
@@ -707,10 +716,15 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     p.a_drop = make_drop(&d->a_drop, d->a_drop_sign);
     p.a_drop_ld = d->a_drop_ld; p.a_drop_bstride = d->a_drop_bstride;
     if (d->cv_c > 0) {
-        if (!pl.x3 || pl.split != 1) return GT_ENOTSUP;
-        p.cv_H = d->cv_h; p.cv_W = d->cv_w; p.cv_C = d->cv_c;
-        p.lda = d->cv_c;
-        p.a_vec = al16(d->A);
+        if (!pl.x3 || (!d->cv_wgrad && pl.split != 1)) return GT_ENOTSUP;
+        p.cv_H = d->cv_h; p.cv_W = d->cv_w; p.cv_C = d->cv_c; p.cv_wgrad = d->cv_wgrad != 0;
+        if (d->cv_wgrad) {
+            p.ldb = d->cv_c; p.b_bs0 = p.b_bs1 = 0;
+            p.b_vec = al16(d->B) && m4(d->cv_c);
+        } else {
+            p.lda = d->cv_c;
+            p.a_vec = al16(d->A);
+        }
     }
 
     if (d->K2 > 0) {
@@ -858,7 +872,8 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
     const int rem = d->N % 128;
     Plan pl;
     // only when the aligned part alone fills the chip: two half-empty launches would serialise instead
-    if (d->N > 128 && rem != 0 && rem <= 64 && d->ep_mode == GT_EP_NORMAL && make_plan(d, &pl) == 0 && pl.split == 1 &&
+    if (d->N > 128 && rem != 0 && rem <= 64 && d->ep_mode == GT_EP_NORMAL && d->cv_c == 0 && make_plan(d, &pl) == 0 &&
+        pl.split == 1 &&
         pl.bn == 128 &&
         (int64_t)pl.tiles_m * (d->N / 128) * d->batch0 * d->batch1 >= 512) {
         const int n_main = d->N - rem;

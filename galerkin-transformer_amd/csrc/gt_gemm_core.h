@@ -30,7 +30,7 @@ struct GemmP {
     // GT_EP_HEADNORM (split-operand ring kernel): head-norm forward fused behind the QKV projection
     const float* hn_gamma; const float* hn_beta; const float* hn_pos; float* hn_out; float* hn_stats;
     int hn_h, hn_dk, hn_p, hn_DP, hn_mask; float hn_eps;
-    int cv_H, cv_W, cv_C;            // implicit 3x3 convolution on the A operand (gt_hip.h: cv_*), 0 = plain GEMM
+    int cv_H, cv_W, cv_C, cv_wgrad;  // implicit 3x3 convolution (gt_hip.h: cv_*), cv_C = 0: plain GEMM
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------

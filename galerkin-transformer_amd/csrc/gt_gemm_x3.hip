@@ -465,30 +465,56 @@ __device__ __forceinline__ void x3r_issue_conv(const float* const (&rowp)[2], co
     }
 }
 
-// HN = head width of the fused head-norm epilogue (0 = general epilogue); CV = implicit 3x3 convolution on A
-template <int LA, int LB, int PLANES, int R, int HN = 0, bool CV = false>
+// Weight-gradient flavour (cv_wgrad): the x-contiguous B image of a stage is 16 consecutive pixels p of the tap-shifted
+// activations, B(p, n) = X[p + (dy, dx)][n]; rows whose neighbour falls outside the picture (or p >= kend) read zero.
+// (y, x) = the lane's two pixels of the current stage; W >= 16, so one stage wraps at most one image row.
+__device__ __forceinline__ void x3r_issue_convw(const float* __restrict__ X, int C, int n0, int N, int k0, int kend,
+                                                const int (&py)[2], const int (&px)[2], int dy, int dx, int H, int W,
+                                                char* img, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave * 2 + i;
+        const int kr = 2 * q + (lane >> 5), xx = n0 + 4 * (lane & 31), k = k0 + kr;
+        const bool ok = k < kend && xx < N && (unsigned)(py[i] + dy) < (unsigned)H && (unsigned)(px[i] + dx) < (unsigned)W;
+        const float* src = ok ? X + ((int64_t)k + dy * W + dx) * C + xx : x3_zero;
+        __builtin_amdgcn_global_load_lds((x3_glb_ptr)src, (x3_lds_ptr)(img + q * 1024), 16, 0, 0);
+    }
+}
+
+// HN = head width of the fused head-norm epilogue (0 = general epilogue)
+// CV = 0 plain GEMM, 1 implicit 3x3 convolution on A (forward / data gradient), 2 on B, one tap per block (weight gradient)
+template <int LA, int LB, int PLANES, int R, int HN = 0, int CV = 0>
 __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[R * X3R_STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
-    int tile;
-    {
+    int tile, by, z;
+    if (CV == 2) {
+        // 1-D grid: the nine taps of one (K chunk, tile) sit next to each other on ONE XCD, so the dY and X rows they
+        // share come out of that XCD's L2 instead of HBM nine times
+        const int tiles = p.tiles_m * p.tiles_n;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int ct = (j / 9) * 8 + xcd;
+        if (ct >= p.n_split * tiles) return;
+        z = j % 9; by = ct / tiles; tile = ct % tiles;
+    } else {
         const int tiles = gridDim.x, q = tiles >> 3, r = tiles & 7;
         const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+        by = blockIdx.y; z = blockIdx.z;
     }
     const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
     const int m0 = tm * X3_BM, n0 = tn * X3_BN;
-    const int z = blockIdx.z, b0 = z / p.batch1, b1 = z % p.batch1;
-    const int kbeg = blockIdx.y * p.k_chunk;
+    const int b0 = z / p.batch1, b1 = z % p.batch1;
+    const int kbeg = by * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
     const float* A = p.A + b0 * p.a_bs0 + b1 * p.a_bs1;
     const float* Bm = p.B + b0 * p.b_bs0 + b1 * p.b_bs1;
     const uint32_t akey = drop_key_dev(p.a_drop);
     const int64_t adoff = (int64_t)z * p.a_drop_bstride;
-    const bool do_acs = (LA == 1) && p.acs != nullptr && tn == 0 && wn == 0;
+    const bool do_acs = (LA == 1) && p.acs != nullptr && tn == 0 && wn == 0 && CV != 2;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -504,7 +530,16 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
     // the next stage to request (stages are requested in order)
     const float* cv_row[2] = {A, A};
     int cv_ok[2] = {0, 0}, cv_tap = 0, cv_c0 = 0;
-    if (CV) {
+    int cw_y[2] = {0, 0}, cw_x[2] = {0, 0};        // CV == 2: (y, x) of this lane's two k-rows (pixels) of the next stage
+    if (CV == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pix = (kbeg + 2 * (wave * 2 + i) + (lane >> 5)) % (p.cv_H * p.cv_W);
+            cw_y[i] = pix / p.cv_W;
+            cw_x[i] = pix - cw_y[i] * p.cv_W;
+        }
+    }
+    if (CV == 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + 16 * (wave * 2 + i) + (lane >> 2);
@@ -522,14 +557,27 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
     auto issue = [&](int s) {                      // stage s -> slot s % R : 4 load instructions per wave
         char* st = smem + (s % R) * X3R_STAGE;
         const int k0 = kbeg + s * X3_BK;
-        if (CV) {
+        if (CV == 1) {
             x3r_issue_conv(cv_row, cv_ok, cv_tap, cv_c0, p.cv_W, p.cv_C, st, wave, lane);
             cv_c0 += X3_BK;
             if (cv_c0 == p.cv_C) { cv_c0 = 0; ++cv_tap; }
         } else {
             x3r_issue<LA>(A, p.lda, m0, p.M, k0, kend, st, wave, lane);
         }
-        x3r_issue<LB>(Bm, p.ldb, n0, p.N, k0, kend, st + X3R_OP, wave, lane);
+        if (CV == 2) {
+            x3r_issue_convw(p.B, p.cv_C, n0, p.N, k0, kend, cw_y, cw_x, z / 3 - 1, z % 3 - 1, p.cv_H, p.cv_W,
+                            st + X3R_OP, wave, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {          // the next stage's pixels: 16 further along the row-major image
+                cw_x[i] += X3_BK;
+                if (cw_x[i] >= p.cv_W) {
+                    cw_x[i] -= p.cv_W;
+                    if (++cw_y[i] == p.cv_H) cw_y[i] = 0;
+                }
+            }
+        } else {
+            x3r_issue<LB>(Bm, p.ldb, n0, p.N, k0, kend, st + X3R_OP, wave, lane);
+        }
     };
 #pragma unroll
     for (int s = 0; s < R - 1; ++s)
@@ -594,7 +642,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
         for (int i = 0; i < 2; ++i) {
             const float t = asum[i] + __shfl_xor(asum[i], 32, 64);
             const int m = m0 + wm * 64 + 32 * i + lr;
-            if (lh == 0 && m < p.M) p.acs[((int64_t)blockIdx.y * gridDim.z + z) * p.M + m] = t;
+            if (lh == 0 && m < p.M) p.acs[((int64_t)by * gridDim.z + z) * p.M + m] = t;
         }
     }
     if (HN > 0) {
@@ -604,7 +652,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
     } else {
         __syncthreads();                           // every wave is done with the ring: its first slots become staging
         x3_epilogue<2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * X3_EP_STG, z, b0,
-                       b1, (int)blockIdx.y);
+                       b1, by);
     }
 }
 
@@ -682,11 +730,20 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
         GT_LAUNCH_CHECK();
         return 0;
     }
+    if (p.cv_C > 0 && p.cv_wgrad) {                // convolution weight gradient: nine taps x K chunks, 1-D grid
+        if (lay != 3 || !x3r_ok(p, 1, 1) || batch != 9 || p.cv_W < X3_BK) return GT_ENOTSUP;
+        const dim3 g1((unsigned)(72 * ((tiles * split + 7) / 8)));
+        if (planes == 1) hipLaunchKernelGGL((gemm_x3r_kernel<1, 1, 1, 3, 0, 2>), g1, dim3(256), 0, st, p);
+        else if (planes == 2) hipLaunchKernelGGL((gemm_x3r_kernel<1, 1, 2, 3, 0, 2>), g1, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_x3r_kernel<1, 1, 3, 3, 0, 2>), g1, dim3(256), 0, st, p);
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
     if (p.cv_C > 0) {                              // implicit convolution: ring kernel, depth 3
         if (lay != 0 || !x3r_ok(p, 0, 0) || (p.cv_C & 15) || split != 1 || batch != 1) return GT_ENOTSUP;
-        if (planes == 1) hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 1, 3, 0, true>), grid, dim3(256), 0, st, p);
-        else if (planes == 2) hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 2, 3, 0, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 3, 3, 0, true>), grid, dim3(256), 0, st, p);
+        if (planes == 1) hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 1, 3, 0, 1>), grid, dim3(256), 0, st, p);
+        else if (planes == 2) hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 2, 3, 0, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_x3r_kernel<0, 0, 3, 3, 0, 1>), grid, dim3(256), 0, st, p);
         GT_LAUNCH_CHECK();
         return 0;
     }
@@ -701,13 +758,15 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
 const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes, int hn_dk) {
     static thread_local char buf[112];
     if (hn_dk > 0) {
-        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<0, 0, 3, %d, %d, false>(gt::GemmP)", x3_ring_depth(), hn_dk);
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<0, 0, 3, %d, %d, 0>(gt::GemmP)", x3_ring_depth(), hn_dk);
         return buf;
     }
-    if (p.cv_C > 0)
-        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<0, 0, %d, 3, 0, true>(gt::GemmP)", planes);
+    if (p.cv_C > 0 && p.cv_wgrad)
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<1, 1, %d, 3, 0, 2>(gt::GemmP)", planes);
+    else if (p.cv_C > 0)
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<0, 0, %d, 3, 0, 1>(gt::GemmP)", planes);
     else if (x3_use_ring(p, layout_a, layout_b))
-        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<%d, %d, %d, %d, 0, false>(gt::GemmP)", layout_a, layout_b, planes,
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<%d, %d, %d, %d, 0, 0>(gt::GemmP)", layout_a, layout_b, planes,
                  x3_ring_depth());
     else
         snprintf(buf, sizeof(buf), "void gt::gemm_x3_kernel<%d, %d, %d>(gt::GemmP)", layout_a, layout_b, planes);

@@ -61,7 +61,7 @@ class GtGemmDesc(C.Structure):
         ("hn_stats", C.c_void_p), ("hn_h", C.c_int32), ("hn_dk", C.c_int32), ("hn_p", C.c_int32),
         ("hn_norm_mask", C.c_int32), ("hn_eps", C.c_float),
         ("precision", C.c_int32),
-        ("cv_h", C.c_int32), ("cv_w", C.c_int32), ("cv_c", C.c_int32),
+        ("cv_h", C.c_int32), ("cv_w", C.c_int32), ("cv_c", C.c_int32), ("cv_wgrad", C.c_int32),
     ]
 
 
@@ -373,10 +373,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          dw2: Optional[torch.Tensor] = None,
          K2: int = 0, A2: Optional[torch.Tensor] = None, lda2: int = 0, a2_bs=(0, 0),
          B2: Optional[torch.Tensor] = None, ldb2: int = 0, b2_bs=(0, 0), hn: Optional[dict] = None,
-         precision: Optional[str] = None, conv: Optional[Tuple[int, int, int]] = None):
+         precision: Optional[str] = None, conv: Optional[Tuple[int, int, int]] = None, conv_wgrad: bool = False):
     """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics).  precision=None uses the module mode
     (set_precision).  conv=(H, W, C): A is a channels-last [B, H, W, C] image and the product is the implicit 3x3
-    convolution (K = 9*C; gt_hip.h: cv_*)."""
+    convolution (K = 9*C; gt_hip.h: cv_*); with conv_wgrad, B is that image and the nine batch entries are the taps of the
+    weight gradient."""
     need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, a_colsum)
     L = lib()
     d = GtGemmDesc()
@@ -428,6 +429,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         d.hn_h, d.hn_dk, d.hn_p, d.hn_norm_mask, d.hn_eps = hn["h"], hn["dk"], hn["p"], hn["norm_mask"], hn["eps"]
     if conv is not None:
         d.cv_h, d.cv_w, d.cv_c = conv
+        d.cv_wgrad = int(conv_wgrad)
     need = L.gt_gemm_ws_bytes(C.byref(d))
     wsp, wsn = None, 0
     if need > 0:
@@ -444,7 +446,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         key = nm.value.decode().replace("void gt::", "").replace("(gt::GemmP)", "").replace("(gt::TsmmP)", "")
         key += "+splitk" if (sp.value > 1 and "tsmm" not in key) else ""
         flops = 2.0 * M * N * (K + K2) * nb
-        nbytes = 4.0 * nb * (M * (conv[2] if conv else K) + K * N + M * N * (1 + (res is not None) + (aux is not None) +
+        if conv_wgrad:
+            nb = 1.0 + 8.0 * (M * N) / (M * K + K * N + M * N)     # both operands are read once for the nine taps
+        nbytes = 4.0 * nb * (M * (conv[2] if conv and not conv_wgrad else K) + K * N + M * N * (1 + (res is not None) + (aux is not None) +
                                                       (add is not None) + (pre is not None)))
         keep = (A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, d)
         st = stream_ptr()

@@ -257,7 +257,8 @@ def conv3x3_nhwc_ok(conv: torch.nn.Conv2d) -> bool:
             and _conv_implicit[0])
 
 
-_conv_implicit = [os.environ.get("GT_CONV_IMPLICIT", "1") != "0"]        # A/B switch (tools / tests)
+_conv_implicit = [os.environ.get("GT_CONV_IMPLICIT", "1") != "0"]        # A/B switches (tools / tests)
+_conv_wgrad = [os.environ.get("GT_CONV_WGRAD", "1") != "0"]
 
 
 class Conv3x3NhwcFn(Function):
@@ -267,8 +268,8 @@ class Conv3x3NhwcFn(Function):
     Interp2dUpsample, layers.py:624-670) where the channel counts fill the 128 x 128 tiles (the up-scaler's
     n_hidden -> n_hidden convolution).  Forward: [pixels, 9 C] x [C', 9 C]^T with the nine shifted views of x read in
     place (gt_hip.h: cv_*).  Data gradient: the same product on gy with the taps reversed and the channel roles
-    swapped.  Weight gradient: the library's channels-last wrw convolution kernel (MIOpen) on the same buffers -- the only
-    piece of the convolution that is not this repo's kernel."""
+    swapped.  Weight gradient: nine pixel-contracted products, one per tap, cut into K chunks on one launch (images at
+    least 16 pixels wide; narrower ones use the library's channels-last wrw kernel on the same buffers)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -295,9 +296,17 @@ class Conv3x3NhwcFn(Function):
             dx = torch.empty(B, Hh, Ww, Cin, dtype=torch.float32, device=g.device)
             H.gemm(g, wd, dx, B * Hh * Ww, Cin, 9 * Cout, lda=Cout, ldb=9 * Cout, ldc=Cin, conv=(Hh, Ww, Cout))
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(
-                g.permute(0, 3, 1, 2), xc.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last),
-                None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].contiguous()
+            # dw[co][ci][tap] = sum_pix gy[pix][co] x[pix + shift(tap)][ci]: nine [Cout, Cin] products over the pixels,
+            # K chunks x taps on one launch + a fixed-order reduce (gt_hip.h: cv_wgrad)
+            if Ww >= 16 and _conv_wgrad[0]:
+                dw9 = torch.empty(9, Cout, Cin, dtype=torch.float32, device=g.device)
+                H.gemm(g, xc, dw9, Cout, Cin, B * Hh * Ww, layout_a=1, layout_b=1, lda=Cout, ldb=Cin, ldc=Cin,
+                       batch=(9, 1), c_bs=(Cout * Cin, 0), split_k=0, conv=(Hh, Ww, Cin), conv_wgrad=True)
+                dw = dw9.view(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
+            else:                   # narrow images: the library's channels-last wrw kernel on the same buffers
+                dw = torch.ops.aten.convolution_backward(
+                    g.permute(0, 3, 1, 2), xc.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last),
+                    None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].contiguous()
         return dx, dw
 
 

@@ -184,8 +184,15 @@ typedef struct gt_gemm_desc {
      * for the forward product (layers.py:98-100 `nn.Conv2d(.., kernel_size=3, padding=1, bias=False)` of the scaler
      * blocks), or the tap-reversed, in/out-swapped filter for the data gradient.  Split-operand ring kernel only:
      * precision != GT_PREC_F32, layout_a = layout_b = 0, cv_c % 16 == 0, no batching, no split-K, no A dropout,
-     * M, N >= 96; anything else returns GT_ENOTSUP (the caller then uses its library convolution). */
-    int32_t cv_h, cv_w, cv_c;
+     * M, N >= 96; anything else returns GT_ENOTSUP (the caller then uses its library convolution).
+     *
+     * cv_wgrad != 0 selects the weight gradient of the same convolution instead:
+     *     C_tap[m][n] = sum_pixels A[pixel][m] * X[pixel + (dy, dx)][n]          tap = 0..8 = the batch index
+     * with A = the output gradient [pixels, M] (layout_a = 1, lda = M's row length), B = X the channels-last input
+     * [B, cv_h, cv_w, cv_c] (layout_b = 1, N = cv_c), K = the pixel count, batch0 = 9, batch1 = 1, C = [9][M][N]
+     * (c_bs0 = the tap stride), split_k = 0 (the library cuts K into chunks; the nine taps of a chunk run next to each
+     * other on one XCD and share its L2).  cv_w >= 16, no epilogue fields. */
+    int32_t cv_h, cv_w, cv_c, cv_wgrad;
 } gt_gemm_desc;
 
 #define GT_PREC_F32    0

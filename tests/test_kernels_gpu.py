@@ -909,7 +909,7 @@ def test_qkv_headnorm_fused_epilogue(H, gpu_device, T, h, dk, p, mask):
 
 
 @pytest.mark.parametrize("B,Hh,Ww,Cin,Cout", [(3, 13, 11, 128, 128), (1, 77, 77, 96, 144), (2, 5, 40, 112, 96),
-                                              (1, 1, 100, 128, 128), (1, 1, 7, 128, 128), (4, 16, 16, 256, 128)])
+                                              (1, 1, 100, 128, 128), (1, 1, 7, 128, 128), (4, 16, 16, 256, 128), (12, 77, 77, 96, 144)])
 def test_conv3x3_implicit_gemm(H, gpu_device, B, Hh, Ww, Cin, Cout):
     """ops.conv3x3_nhwc (implicit GEMM on the split-operand ring kernel: forward and data gradient; MIOpen wrw for the
     weight gradient) == F.conv2d(padding=1) in fp64 on the CPU (layers.py:98-100 inside Interp2dUpsample), outputs and
@@ -930,7 +930,15 @@ def test_conv3x3_implicit_gemm(H, gpu_device, B, Hh, Ww, Cin, Cout):
     assert rel_l2(y.permute(0, 3, 1, 2), ref) < KTOL
     assert rel_l2(xg.grad.permute(0, 3, 1, 2), gx) < KTOL
     assert wg.grad.shape == w.shape and wg.grad.is_contiguous()
-    assert rel_l2(wg.grad, gw) < 1e-5          # the library's wrw kernel (own accumulation order)
+    assert rel_l2(wg.grad, gw) < KTOL          # nine-tap pixel contraction on the ring kernel (Ww >= 16), else MIOpen wrw
+    if Ww >= 16:                               # and the library's channels-last wrw kernel behind the same switch
+        ops._conv_wgrad[0] = False
+        try:
+            xg.grad = wg.grad = None
+            ops.conv3x3_nhwc(xg, wg).backward(cot.float().permute(0, 2, 3, 1).contiguous().to(gpu_device))
+        finally:
+            ops._conv_wgrad[0] = True
+        assert rel_l2(wg.grad, gw) < 1e-5
 
 
 def test_conv3x3_implicit_gemm_rejects_what_it_does_not_cover(H, gpu_device):
@@ -951,6 +959,12 @@ def test_conv3x3_implicit_gemm_rejects_what_it_does_not_cover(H, gpu_device):
     x24 = rnd(2, 8, 8, 24, dev=dev, seed=132)
     with pytest.raises(NotImplementedError):
         H.gemm(x24, w, y, 128, 128, 9 * 24, conv=(8, 8, 24), lda=24, ldb=9 * 24, ldc=128)
+    dw9 = torch.empty(9, 128, 128, device=dev)
+    wkw = dict(layout_a=1, layout_b=1, lda=128, ldb=128, ldc=128, batch=(9, 1), c_bs=(128 * 128, 0), conv_wgrad=True)
+    with pytest.raises(NotImplementedError):                                 # images narrower than one stage
+        H.gemm(y, x, dw9, 128, 128, 128, conv=(8, 8, 128), split_k=0, **wkw)
+    with pytest.raises(H.GtError, match="EINVAL"):                           # the nine taps are the batch
+        H.gemm(y, x, dw9, 128, 128, 128, conv=(8, 8, 128), split_k=0, **dict(wkw, batch=(3, 1)))
 
 
 def test_upsample_fc_channels_last_equals_channels_first(H, gpu_device):
