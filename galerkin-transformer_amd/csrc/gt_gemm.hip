@@ -631,6 +631,7 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
         GemmP q;
         memset(&q, 0, sizeof(q));
         q.M = d->M; q.N = d->N; q.K = d->K; q.K2 = d->K2; q.cv_C = d->cv_c; q.cv_wgrad = d->cv_wgrad != 0;
+        if (x3_packed_ok(d, pl.x3, pl.split)) q.Bp = d->B;
         q.a_vec = al16(d->A) && m4(d->lda) && m4(d->a_bs0) && m4(d->a_bs1);
         q.b_vec = al16(d->B) && m4(d->ldb) && m4(d->b_bs0) && m4(d->b_bs1);
         snprintf(buf, n, "%s", x3_kernel_name(q, d->layout_a, d->layout_b, pl.x3,
@@ -649,6 +650,7 @@ extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
     Plan pl;
     if (d && !getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return tsmm_ws_bytes(d);
     if (make_plan(d, &pl)) return 0;
+    if (pl.x3 && x3_packed_ok(d, pl.x3, pl.split)) return x3_packed_bytes(d);
     const int64_t parts = acs_parts(d, pl);
     if (d->ep_mode == GT_EP_MLP_BWD)
         return (int64_t)pl.tiles_m * kCfgs[pl.cfg].wm * d->n_out * d->N * (int64_t)sizeof(float);
@@ -802,6 +804,10 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split, (unsigned)batch);
     const int lay = d->layout_a * 2 + d->layout_b;
     if (pl.x3) {
+        if (x3_packed_ok(d, pl.x3, pl.split)) {
+            int rcp = x3_pack_b(d, p, ws, ws_bytes, st);
+            if (rcp) return rcp;
+        }
         int rcx = x3_launch(p, d->layout_a, d->layout_b, pl.x3, (unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split,
                             (unsigned)batch, st);
         if (rcx) return rcx;

@@ -31,6 +31,7 @@ struct GemmP {
     const float* hn_gamma; const float* hn_beta; const float* hn_pos; float* hn_out; float* hn_stats;
     int hn_h, hn_dk, hn_p, hn_DP, hn_mask; float hn_eps;
     int cv_H, cv_W, cv_C, cv_wgrad;  // implicit 3x3 convolution (gt_hip.h: cv_*), cv_C = 0: plain GEMM
+    const void* Bp; int bp_NT, bp_KS;        // packed-B kernel (gt_gemm_x3.hip): bf16 planes of B in fragment order
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------
@@ -383,5 +384,10 @@ bool x3_headnorm_ok(const GemmP& p, int layout_a, int layout_b, int planes);
 int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned tiles, unsigned split, unsigned batch,
               hipStream_t st);
 const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes, int hn_dk = 0);
+// packed-B variant: eligibility for descriptor d (x3 planes already chosen), bytes of the plane buffer, and the pack
+// launch (fills ws, sets p.Bp / bp_NT / bp_KS)
+bool x3_packed_ok(const gt_gemm_desc* d, int planes, int split);
+int64_t x3_packed_bytes(const gt_gemm_desc* d);
+int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipStream_t st);
 
 }  // namespace gt

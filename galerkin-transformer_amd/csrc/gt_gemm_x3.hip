@@ -656,6 +656,194 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Packed-B variant: when B is small next to A (a weight matrix against many token rows), every block would split the
+// same B values again -- the in-situ ablation put the B split alone at 2.5 of 37.5 ms/step (tools/ablate_x3.sh).
+// x3_pack_b_kernel splits B ONCE into its three bf16 planes, stored in MFMA fragment order
+//     Bp[plane][n-tile of 32][k-stage of 16][lane 0..63] = 8 bf16  (k = 16 ks + 8 (lane >> 5) + e, n = 32 nt + (lane & 31)),
+// zero beyond N and K, n-tiles padded to whole 128-column block tiles.  A wave then reads a B fragment of a stage as ONE
+// coalesced 1-KB global load straight into the registers the MFMA takes it from (the planes stay L2-resident: 3 x 2 bytes
+// per weight), B needs no LDS, and the ring holds A only (8 KB per stage, depth 4).  The loads of stage kt + 1 are
+// issued behind the MFMAs of stage kt, so their latency sits under the next barrier and A split.
+// Counted waits (VMEM retires in order):  top of iteration kt -- A(kt) must have landed; requested after it are the A
+// stages kt+1 .. kt+R-2 (2 loads each) and B(kt) (6 loads): vmcnt(2 newer + 6);  before the MFMAs -- B(kt) must have
+// landed; after it only A(kt+R-1) (2 loads) was requested: the compiler's own vmcnt(2) (vmcnt(0) in the tail loop).
+constexpr int X3P_R = 4;
+
+__global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K,
+                                                        int NT, int KS, u32x4* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NT * KS * 64) return;
+    const int lane = idx & 63, t = idx >> 6, ks = t % KS, nt = t / KS;
+    const int n = nt * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        v[e] = (n < N && k < K) ? (layout_b == 0 ? B[(int64_t)n * ldb + k] : B[(int64_t)k * ldb + n]) : 0.f;
+    }
+    uint32_t q[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_pair<3>(v[2 * i], v[2 * i + 1], q[i]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        out[(((int64_t)pl * NT + nt) * KS + ks) * 64 + lane] = u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
+}
+
+template <int LA, int HN, int CV>                  // CV: 0 plain, 1 implicit 3x3 convolution on A
+__global__ __launch_bounds__(256, 3) void gemm_x3p_kernel(const GemmP p) {
+    constexpr int R = X3P_R, PLANES = 3;
+    constexpr int STG = (HN > 0 ? X3_HN_STG : X3_EP_STG) * 4 * 4;       // bytes of epilogue staging, four waves
+    constexpr int SMEM = R * X3R_OP > STG ? R * X3R_OP : STG;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    int tile;
+    {
+        const int tiles = gridDim.x, q = tiles >> 3, r = tiles & 7;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * X3_BM, n0 = tn * X3_BN;
+    const int kend = p.K;
+    const float* A = p.A;
+    const uint32_t akey = drop_key_dev(p.a_drop);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (kend + X3_BK - 1) / X3_BK;
+    const float* cv_row[2] = {A, A};
+    int cv_ok[2] = {0, 0}, cv_tap = 0, cv_c0 = 0;
+    if (CV == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + 16 * (wave * 2 + i) + (lane >> 2);
+            if (m < p.M) {
+                const int pix = m % (p.cv_H * p.cv_W), y = pix / p.cv_W, x = pix - y * p.cv_W;
+                int ok = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    ok |= (((unsigned)(y + t / 3 - 1) < (unsigned)p.cv_H) && ((unsigned)(x + t % 3 - 1) < (unsigned)p.cv_W)) << t;
+                cv_ok[i] = ok;
+                cv_row[i] = A + (int64_t)m * p.cv_C;
+            }
+        }
+    }
+    auto issue = [&](int s) {                      // A stage s -> slot s % R : 2 load instructions per wave
+        char* st = smem + (s % R) * X3R_OP;
+        if (CV == 1) {
+            x3r_issue_conv(cv_row, cv_ok, cv_tap, cv_c0, p.cv_W, p.cv_C, st, wave, lane);
+            cv_c0 += X3_BK;
+            if (cv_c0 == p.cv_C) { cv_c0 = 0; ++cv_tap; }
+        } else {
+            x3r_issue<LA>(A, p.lda, m0, p.M, s * X3_BK, kend, st, wave, lane);
+        }
+    };
+    // this wave's two 32-column B fragments of stage ks: plane pl, fragment j at bbase + pl * bplane + (j * KS + ks) KiB
+    // (wave-uniform address in SGPRs + the lane's 16-byte slot).  The loads are inline asm on purpose: hipcc's own
+    // scoreboard answers a register load inside this loop with s_waitcnt vmcnt(0) before the MFMAs, which also drains
+    // the A stage requested a moment earlier (measured in the ISA); here the wait is the counted one below.
+    const int wn_u = __builtin_amdgcn_readfirstlane(wn);
+    const char* bbase = reinterpret_cast<const char*>(p.Bp) + (int64_t)((n0 + wn_u * 64) >> 5) * p.bp_KS * 1024;
+    const int64_t bplane = (int64_t)p.bp_NT * p.bp_KS * 1024;
+    const uint32_t voff = lane * 16;
+    bf16x8 bn[2][PLANES];
+    auto loadb = [&](int ks) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) {
+#ifdef GT_ABL_X3_NOSPLIT_B       // ablation: every stage reads the same (cache-resident) fragment
+                const char* sp = bbase + pl * bplane + (int64_t)j * p.bp_KS * 1024;
+#else
+                const char* sp = bbase + pl * bplane + ((int64_t)j * p.bp_KS + ks) * 1024;
+#endif
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bn[j][pl]) : "v"(voff), "s"(sp));
+            }
+    };
+    bf16x8 am[2][PLANES];
+    auto splita = [&](int kt) {
+        const char* sa = smem + (kt % R) * X3R_OP;
+        const int kbase = kt * X3_BK + 8 * lh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v[8];
+            const int row = wm * 64 + 32 * i + lr;
+            x3r_frag<LA>(sa, row, lh, v);
+            if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, 0, m0 + row, kbase, v);
+#ifdef GT_ABL_X3_NOSPLIT_A       // ablation builds (tools/ablate_x3.sh): timing only, results are wrong
+            for (int pl = 0; pl < PLANES; ++pl) am[i][pl] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(v[0]), __float_as_uint(v[2]), __float_as_uint(v[4]), __float_as_uint(v[6])});
+#else
+            x3r_split<PLANES>(v, am[i]);
+#endif
+        }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int s = PLANES - 1; s >= 0; --s) {          // plane pairs (pa, pb) with pa + pb = s, smallest terms first
+#pragma unroll
+            for (int pa = 0; pa < PLANES; ++pa) {
+                const int pb = s - pa;
+                if (pb < 0 || pb >= PLANES) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(bn[j][pb], am[i][pa], acc[i][j]);
+            }
+        }
+    };
+    // B(kt) has landed once at most `N` younger loads are outstanding; tying bn to the statement keeps the MFMAs behind it
+#define X3P_WAIT_B(N)                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                             \
+                 : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[0][2]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(bn[1][2]))
+
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s)
+        if (s < nk) issue(s);
+    if (nk > 0) loadb(0);
+
+    const int nfast = nk - (R - 1);                // iterations that still request a new A stage
+    int kt = 0;
+    for (; kt < nfast; ++kt) {
+        asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");       // 2 (R - 2) newer A loads + 6 of B(kt)
+        issue(kt + R - 1);
+        splita(kt);
+        X3P_WAIT_B(2);
+        mfmas();
+        loadb(kt + 1);
+    }
+    for (; kt < nk; ++kt) {
+        const int newer = nk - 1 - kt;             // 0 .. R - 2 A stages still in flight behind A(kt)
+        if (newer >= 2) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        splita(kt);
+        X3P_WAIT_B(0);
+        mfmas();
+        if (kt + 1 < nk) loadb(kt + 1);
+    }
+#undef X3P_WAIT_B
+#ifdef GT_ABL_X3_NOSTORE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+
+    __syncthreads();                               // every wave is done with the ring: its first slots become staging
+    if (HN > 0)
+        x3_epilogue_hn<(HN > 0 ? HN : 32), 2>(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, lane,
+                                               reinterpret_cast<float*>(smem) + wave * X3_HN_STG);
+    else
+        x3_epilogue<2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * X3_EP_STG, 0, 0, 0, 0);
+}
+
 // operands the ring kernel's direct loads can take (see its header comment)
 static bool x3r_ok(const GemmP& p, int layout_a, int layout_b) {
     if (p.K2 > 0 || !p.a_vec || !p.b_vec) return false;
@@ -716,6 +904,18 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
     const dim3 grid(tiles, split, batch);
     const int lay = layout_a * 2 + layout_b;
     const bool ring = x3_use_ring(p, layout_a, layout_b);
+    if (p.Bp) {                                    // packed-B kernel (x3_packed_ok said yes)
+        const int hn = p.ep_mode == GT_EP_HEADNORM ? p.hn_dk : 0;
+        if (hn && !x3_headnorm_ok(p, layout_a, 0, planes)) return GT_ENOTSUP;
+        if (p.cv_C > 0) hipLaunchKernelGGL((gemm_x3p_kernel<0, 0, 1>), grid, dim3(256), 0, st, p);
+        else if (hn == 16) hipLaunchKernelGGL((gemm_x3p_kernel<0, 16, 0>), grid, dim3(256), 0, st, p);
+        else if (hn == 32) hipLaunchKernelGGL((gemm_x3p_kernel<0, 32, 0>), grid, dim3(256), 0, st, p);
+        else if (hn == 64) hipLaunchKernelGGL((gemm_x3p_kernel<0, 64, 0>), grid, dim3(256), 0, st, p);
+        else if (layout_a == 0) hipLaunchKernelGGL((gemm_x3p_kernel<0, 0, 0>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_x3p_kernel<1, 0, 0>), grid, dim3(256), 0, st, p);
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
     if (p.ep_mode == GT_EP_HEADNORM) {
         if (!x3_headnorm_ok(p, layout_a, layout_b, planes)) return GT_ENOTSUP;
         if (x3_ring_depth() == 3) {
@@ -755,8 +955,43 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
     return 0;
 }
 
+// ---- packed-B path: host side ---------------------------------------------------------------------------------------
+// B small next to A (a weight against >= 2048 token rows), three planes, one launch (no batching, split-K, second
+// product or row-sum by-product), operands the direct loads can take.  GT_X3_PACKED=0 switches it off (A/B runs).
+bool x3_packed_ok(const gt_gemm_desc* d, int planes, int split) {
+    static const int on = [] { const char* e = getenv("GT_X3_PACKED"); return e ? atoi(e) : 1; }();
+    if (!on || planes != 3 || split != 1 || d->batch0 * d->batch1 != 1 || d->K2 > 0 || d->a_colsum) return false;
+    if (d->cv_c > 0 && d->cv_wgrad) return false;
+    if (d->M < 2048 || d->M < 8 * (int64_t)d->N) return false;
+    const bool a16 = (reinterpret_cast<uintptr_t>(d->A) & 15) == 0;
+    if (d->cv_c > 0) return a16 && d->layout_a == 0 && (d->cv_c & 15) == 0;
+    if (!a16 || (d->lda & 3)) return false;
+    return d->layout_a == 0 ? (d->K & 3) == 0 : (d->M & 3) == 0;
+}
+
+static inline int x3p_nt(int N) { return ((N + X3_BN - 1) / X3_BN) * (X3_BN / 32); }
+static inline int x3p_ks(int K) { return (K + X3_BK - 1) / X3_BK; }
+
+int64_t x3_packed_bytes(const gt_gemm_desc* d) { return (int64_t)3 * x3p_nt(d->N) * x3p_ks(d->K) * 1024; }
+
+int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipStream_t st) {
+    if (!ws || ws_bytes < x3_packed_bytes(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) return GT_EWS;
+    const int NT = x3p_nt(d->N), KS = x3p_ks(d->K);
+    const int threads = NT * KS * 64;
+    hipLaunchKernelGGL(x3_pack_b_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, d->B, d->layout_b, d->ldb, d->N,
+                       d->K, NT, KS, reinterpret_cast<u32x4*>(ws));
+    GT_LAUNCH_CHECK();
+    p.Bp = ws; p.bp_NT = NT; p.bp_KS = KS;
+    return 0;
+}
+
 const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes, int hn_dk) {
     static thread_local char buf[112];
+    if (p.Bp) {
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3p_kernel<%d, %d, %d>(gt::GemmP)", p.cv_C > 0 ? 0 : layout_a, hn_dk,
+                 p.cv_C > 0 ? 1 : 0);
+        return buf;
+    }
     if (hn_dk > 0) {
         snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<0, 0, 3, %d, %d, 0>(gt::GemmP)", x3_ring_depth(), hn_dk);
         return buf;
