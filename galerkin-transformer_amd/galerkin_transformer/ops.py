@@ -258,7 +258,10 @@ def conv3x3_nhwc_ok(conv: torch.nn.Conv2d) -> bool:
 
 
 _conv_implicit = [os.environ.get("GT_CONV_IMPLICIT", "1") != "0"]        # A/B switches (tools / tests)
-_conv_wgrad = [os.environ.get("GT_CONV_WGRAD", "1") != "0"]
+# weight gradient of the implicit convolution: "miopen" (default) = the library's channels-last wrw kernel on the same
+# buffers, "hip" = the nine-tap pixel contraction on the ring kernel.  Same box, back to back (tools/gpu_ab.sh, B = 128):
+# 34.23 vs 34.42 ms/step -- the ring kernel's x-contiguous flavour is VALU-bound on the operand split
+_conv_wgrad = [os.environ.get("GT_CONV_WGRAD", "miopen") == "hip"]
 
 
 class Conv3x3NhwcFn(Function):
@@ -268,8 +271,9 @@ class Conv3x3NhwcFn(Function):
     Interp2dUpsample, layers.py:624-670) where the channel counts fill the 128 x 128 tiles (the up-scaler's
     n_hidden -> n_hidden convolution).  Forward: [pixels, 9 C] x [C', 9 C]^T with the nine shifted views of x read in
     place (gt_hip.h: cv_*).  Data gradient: the same product on gy with the taps reversed and the channel roles
-    swapped.  Weight gradient: nine pixel-contracted products, one per tap, cut into K chunks on one launch (images at
-    least 16 pixels wide; narrower ones use the library's channels-last wrw kernel on the same buffers)."""
+    swapped.  Weight gradient: the library's channels-last wrw kernel on the same buffers (no layout change), or with
+    GT_CONV_WGRAD=hip nine pixel-contracted products, one per tap, cut into K chunks on one launch of the ring kernel
+    (images at least 16 pixels wide) -- measured 0.6 % of a step slower, so it is the opt-in."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -296,14 +300,14 @@ class Conv3x3NhwcFn(Function):
             dx = torch.empty(B, Hh, Ww, Cin, dtype=torch.float32, device=g.device)
             H.gemm(g, wd, dx, B * Hh * Ww, Cin, 9 * Cout, lda=Cout, ldb=9 * Cout, ldc=Cin, conv=(Hh, Ww, Cout))
         if ctx.needs_input_grad[1]:
-            # dw[co][ci][tap] = sum_pix gy[pix][co] x[pix + shift(tap)][ci]: nine [Cout, Cin] products over the pixels,
-            # K chunks x taps on one launch + a fixed-order reduce (gt_hip.h: cv_wgrad)
-            if Ww >= 16 and _conv_wgrad[0]:
+            # dw[co][ci][tap] = sum_pix gy[pix][co] x[pix + shift(tap)][ci]
+            if Ww >= 16 and _conv_wgrad[0]:   # nine [Cout, Cin] products over the pixels, K chunks x taps on one launch
+                                              # + a fixed-order reduce (gt_hip.h: cv_wgrad)
                 dw9 = torch.empty(9, Cout, Cin, dtype=torch.float32, device=g.device)
                 H.gemm(g, xc, dw9, Cout, Cin, B * Hh * Ww, layout_a=1, layout_b=1, lda=Cout, ldb=Cin, ldc=Cin,
                        batch=(9, 1), c_bs=(Cout * Cin, 0), split_k=0, conv=(Hh, Ww, Cin), conv_wgrad=True)
                 dw = dw9.view(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
-            else:                   # narrow images: the library's channels-last wrw kernel on the same buffers
+            else:                   # the library's channels-last wrw kernel on the same buffers
                 dw = torch.ops.aten.convolution_backward(
                     g.permute(0, 3, 1, 2), xc.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last),
                     None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].contiguous()
