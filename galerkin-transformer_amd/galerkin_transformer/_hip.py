@@ -305,6 +305,54 @@ def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     return buf
 
 
+# ----------------------------------------------------------------------------------- second stream
+# A weight gradient (K = tokens, few output tiles, VALU-bound on the operand split) and the data gradient of the same
+# layer (memory-phase bound) are independent and want different resources: the backward passes put the weight gradient
+# on a side stream between a fork and a join, so the two kernels share the chip.  Inside a graph capture the fork/join
+# become parallel branches of the graph.  GT_DUAL_STREAM=0 (or a hip-event profile in progress) keeps one stream.
+_dual_stream = [os.environ.get("GT_DUAL_STREAM", "1") != "0"]
+_side_streams = {}
+_side_pending = set()
+
+
+def _side_stream(dev: int) -> "torch.cuda.Stream":
+    st = _side_streams.get(dev)
+    if st is None:
+        st = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+class side_branch:
+    """``with side_branch(device): launch(...)``: the body runs on the device's side stream, after everything already
+    queued on the current stream.  ``join_side(device)`` makes the current stream wait for it; every user joins before
+    its outputs leave the function."""
+
+    def __init__(self, device: torch.device):
+        self.dev = device.index if device.index is not None else torch.cuda.current_device()
+        self.ctx = None
+
+    def __enter__(self):
+        if _dual_stream[0] and _prof is None and not _DEBUG_SYNC:
+            side = _side_stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            _side_pending.add(self.dev)
+        return False
+
+
+def join_side(device: torch.device):
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    if dev in _side_pending:
+        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+        _side_pending.discard(dev)
+
+
 _seed_cache = {}
 
 

@@ -294,11 +294,13 @@ class Conv3x3NhwcFn(Function):
         Cout = weight.shape[0]
         g = _c(gy)
         dx = dw = None
+        dev = g.device
         if ctx.needs_input_grad[0]:
             # dx[pix][ci] = sum_tap sum_co gy[pix - shift(tap)][co] W[co][ci][tap]: tap' = 8 - tap has the opposite shift
             wd = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()      # [Cin][tap'][Cout]
             dx = torch.empty(B, Hh, Ww, Cin, dtype=torch.float32, device=g.device)
-            H.gemm(g, wd, dx, B * Hh * Ww, Cin, 9 * Cout, lda=Cout, ldb=9 * Cout, ldc=Cin, conv=(Hh, Ww, Cout))
+            with H.side_branch(dev):    # the data gradient next to the weight gradient below
+                H.gemm(g, wd, dx, B * Hh * Ww, Cin, 9 * Cout, lda=Cout, ldb=9 * Cout, ldc=Cin, conv=(Hh, Ww, Cout))
         if ctx.needs_input_grad[1]:
             # dw[co][ci][tap] = sum_pix gy[pix][co] x[pix + shift(tap)][ci]
             if Ww >= 16 and _conv_wgrad[0]:   # nine [Cout, Cin] products over the pixels, K chunks x taps on one launch
@@ -311,6 +313,7 @@ class Conv3x3NhwcFn(Function):
                 dw = torch.ops.aten.convolution_backward(
                     g.permute(0, 3, 1, 2), xc.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last),
                     None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].contiguous()
+        H.join_side(dev)
         return dx, dw
 
 
@@ -377,22 +380,24 @@ class LinearFn(Function):
             else:
                 gp = H.dropout_apply(g, H.dropout_desc(p_drop, salt, dev))
         dx = de = dw = db = None
+        want_db = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:     # weight gradient on the side stream, next to the data gradient (H.side_branch)
+            dw = torch.empty(N, K + pe, dtype=torch.float32, device=dev)
+            if want_db:         # the bias gradient rides on the weight-gradient GEMM (row sums of its A)
+                db = torch.empty(N, dtype=torch.float32, device=dev)
+            with H.side_branch(dev):
+                H.gemm(gp, x2, dw, N, K, T, layout_a=1, layout_b=1, lda=N, ldb=K, ldc=K + pe, split_k=0,
+                       a_colsum=db)
+                if pe:
+                    H.gemm(gp, e2, dw[:, K:], N, pe, T, layout_a=1, layout_b=1, lda=N, ldb=pe, ldc=K + pe,
+                           split_k=0)
+        elif want_db:
+            db = H.colsum(gp, T, N, N)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, K, dtype=torch.float32, device=dev)
             H.gemm(gp, w, dx, T, K, N, layout_b=1, lda=N, ldb=K + pe, ldc=K)
             dx = dx.reshape(xshape)
-        want_db = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty(N, K + pe, dtype=torch.float32, device=dev)
-            if want_db:         # the bias gradient rides on the weight-gradient GEMM (row sums of its A)
-                db = torch.empty(N, dtype=torch.float32, device=dev)
-            H.gemm(gp, x2, dw, N, K, T, layout_a=1, layout_b=1, lda=N, ldb=K, ldc=K + pe, split_k=0,
-                   a_colsum=db)
-            if pe:
-                H.gemm(gp, e2, dw[:, K:], N, pe, T, layout_a=1, layout_b=1, lda=N, ldb=pe, ldc=K + pe,
-                       split_k=0)
-        elif want_db:
-            db = H.colsum(gp, T, N, N)
+        H.join_side(dev)
         return dx, dw, db, de, None, None
 
 
@@ -532,6 +537,13 @@ class FeedForwardFn(Function):
         gm = H.dropout_apply(g, H.dropout_desc(p_out, salt + 1, dev)) if p_out > 0 else g
         # gh = (gm W2) * mask_h * act'(pre)
         gh = torch.empty(T, f, dtype=torch.float32, device=dev)
+        # bias gradients ride on the weight-gradient GEMMs (row sums of their A operand); the weight gradients run on
+        # the side stream next to the data-gradient GEMMs (H.side_branch)
+        dw2 = torch.empty(dout, f, dtype=torch.float32, device=dev)
+        db2 = torch.empty(dout, dtype=torch.float32, device=dev) if hb2 else None
+        with H.side_branch(dev):
+            H.gemm(gm, hid, dw2, dout, f, T, layout_a=1, layout_b=1, lda=dout, ldb=f, ldc=f, split_k=0,
+                   a_colsum=db2)
         if act == H.ACT_RELU:
             H.gemm(gm, w2c, gh, T, f, dout, layout_b=1, lda=dout, ldb=f, ldc=f,
                    aux_op=H.AUX_GT0, aux=hid, ldaux=f, aux_scale=1.0 / (1.0 - p_h))
@@ -539,17 +551,14 @@ class FeedForwardFn(Function):
             H.gemm(gm, w2c, gh, T, f, dout, layout_b=1, lda=dout, ldb=f, ldc=f,
                    aux_op=H.AUX_DSILU, aux=pre, ldaux=f,
                    drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None)
-        # bias gradients ride on the weight-gradient GEMMs (row sums of their A operand)
-        dw2 = torch.empty(dout, f, dtype=torch.float32, device=dev)
-        db2 = torch.empty(dout, dtype=torch.float32, device=dev) if hb2 else None
-        H.gemm(gm, hid, dw2, dout, f, T, layout_a=1, layout_b=1, lda=dout, ldb=f, ldc=f, split_k=0,
-               a_colsum=db2)
         dw1 = torch.empty(f, d, dtype=torch.float32, device=dev)
         db1 = torch.empty(f, dtype=torch.float32, device=dev) if hb1 else None
-        H.gemm(gh, xc, dw1, f, d, T, layout_a=1, layout_b=1, lda=f, ldb=d, ldc=d, split_k=0, a_colsum=db1)
         dx = torch.empty(T, d, dtype=torch.float32, device=dev)
+        with H.side_branch(dev):
+            H.gemm(gh, xc, dw1, f, d, T, layout_a=1, layout_b=1, lda=f, ldb=d, ldc=d, split_k=0, a_colsum=db1)
         same = has_res and dout == d
         H.gemm(gh, w1c, dx, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=g if same else None, ldr=d)
+        H.join_side(dev)
         dx = dx.reshape(xshape)
         # the residual input is x itself: its gradient g is already folded into dx (res epilogue above), so the
         # `res` slot contributes nothing (None) -- no zero fill, no extra add in autograd
@@ -670,14 +679,16 @@ class SimpleAttentionFn(Function):
             Qp, Kp, Vp = out3[0], out3[1], out3[2]
             # dP^T[b] = (sign*g*mask1)^T[b] Q'[b]        [B, d, h*DP]
             dPt = torch.empty(B, d, hD, dtype=torch.float32, device=dev)
-            H.gemm(g, Qp, dPt, d, hD, n, layout_a=1, layout_b=1, lda=d, ldb=hD, ldc=hD, batch=(B, 1),
-                   a_bs=(n * d, 0), b_bs=(n * hD, 0), c_bs=(d * hD, 0), split_k=0, a_drop=d_out,
-                   a_drop_sign=sign, a_drop_ld=d, a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0),
-                   a_colsum=dbfc)       # + d(fc bias) = column sums of the masked, signed g
+            with H.side_branch(dev):    # the token-contracted product next to the token-row product below
+                H.gemm(g, Qp, dPt, d, hD, n, layout_a=1, layout_b=1, lda=d, ldb=hD, ldc=hD, batch=(B, 1),
+                       a_bs=(n * d, 0), b_bs=(n * hD, 0), c_bs=(d * hD, 0), split_k=0, a_drop=d_out,
+                       a_drop_sign=sign, a_drop_ld=d, a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0),
+                       a_colsum=dbfc)       # + d(fc bias) = column sums of the masked, signed g
             # dQ'[b] = (sign*g*mask1)[b] P[b]^T
             H.gemm(g, P, dO3[0], n, hD, d, lda=d, ldb=d, ldc=hD, batch=(B, 1), a_bs=(n * d, 0),
                    b_bs=(hD * d, 0), c_bs=(n * hD, 0), a_drop=d_out, a_drop_sign=sign, a_drop_ld=d,
                    a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0))
+            H.join_side(dev)
             dM, dWs = H.galerkin_finalize_bwd(dPt, Mt, mask, d_attn, wf, B, h, DP, Dr, d, n)
             dwfc = torch.empty(d, h * Dr, dtype=torch.float32, device=dev)
             H.slab_reduce(dWs, B, d * h * Dr, d * h * Dr, dwfc)
@@ -724,11 +735,13 @@ class SimpleAttentionFn(Function):
         dqkv, dgamma, dbeta = H.headnorm_bwd(dO3, qkv, gamma, stats, T, h, dk, p, norm_mask)
         dwqkv = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
         dbqkv = torch.empty(3 * d, dtype=torch.float32, device=dev) if hbq else None
-        H.gemm(dqkv, xc, dwqkv, 3 * d, d, T, layout_a=1, layout_b=1, lda=3 * d, ldb=d, ldc=d, split_k=0,
-               a_colsum=dbqkv)
         dx = torch.empty(T, d, dtype=torch.float32, device=dev)
+        with H.side_branch(dev):        # weight gradient next to the data gradient
+            H.gemm(dqkv, xc, dwqkv, 3 * d, d, T, layout_a=1, layout_b=1, lda=3 * d, ldb=d, ldc=d, split_k=0,
+                   a_colsum=dbqkv)
         H.gemm(dqkv, wq, dx, T, d, 3 * d, layout_b=1, lda=3 * d, ldb=d, ldc=d, res=g_in if has_res else None,
                ldr=d)
+        H.join_side(dev)
         dres = None                                          # folded into dx (res is x): contributes nothing
         if not norm_mask:
             dgamma = dbeta = None
