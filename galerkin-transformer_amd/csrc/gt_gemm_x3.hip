@@ -668,7 +668,14 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
 // Counted waits (VMEM retires in order):  top of iteration kt -- A(kt) must have landed; requested after it are the A
 // stages kt+1 .. kt+R-2 (2 loads each) and B(kt) (6 loads): vmcnt(2 newer + 6);  before the MFMAs -- B(kt) must have
 // landed; after it only A(kt+R-1) (2 loads) was requested: the compiler's own vmcnt(2) (vmcnt(0) in the tail loop).
-constexpr int X3P_R = 4;
+#ifndef GT_X3P_RING                                // A-ring depth of the packed-B kernel (stages of 8 KB)
+#define GT_X3P_RING 4
+#endif
+constexpr int X3P_R = GT_X3P_RING;
+static_assert(X3P_R >= 3 && X3P_R <= 6, "the counted waits below are written out for ring depths 3..6");
+#define X3P_STR2(x) #x
+#define X3P_STR(x) X3P_STR2(x)
+#define X3P_WAIT_A(N) asm volatile("s_waitcnt vmcnt(" X3P_STR(N) ")\n\ts_barrier" ::: "memory")
 
 __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K,
                                                         int NT, int KS, u32x4* __restrict__ out) {
@@ -690,8 +697,11 @@ __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict_
         out[(((int64_t)pl * NT + nt) * KS + ks) * 64 + lane] = u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
 }
 
+#ifndef GT_X3P_BLOCKS                              // resident blocks per CU the general instances are compiled for
+#define GT_X3P_BLOCKS 3
+#endif
 template <int LA, int HN, int CV>                  // CV: 0 plain, 1 implicit 3x3 convolution on A
-__global__ __launch_bounds__(256, 3) void gemm_x3p_kernel(const GemmP p) {
+__global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_kernel(const GemmP p) {
     constexpr int R = X3P_R, PLANES = 3;
     constexpr int STG = (HN > 0 ? X3_HN_STG : X3_EP_STG) * 4 * 4;       // bytes of epilogue staging, four waves
     constexpr int SMEM = R * X3R_OP > STG ? R * X3R_OP : STG;
@@ -814,7 +824,10 @@ __global__ __launch_bounds__(256, 3) void gemm_x3p_kernel(const GemmP p) {
     const int nfast = nk - (R - 1);                // iterations that still request a new A stage
     int kt = 0;
     for (; kt < nfast; ++kt) {
-        asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");       // 2 (R - 2) newer A loads + 6 of B(kt)
+        if (R == 3) X3P_WAIT_A(8);                 // 2 (R - 2) newer A loads + 6 of B(kt)
+        else if (R == 4) X3P_WAIT_A(10);
+        else if (R == 5) X3P_WAIT_A(12);
+        else X3P_WAIT_A(14);
         issue(kt + R - 1);
         splita(kt);
         X3P_WAIT_B(2);
@@ -823,9 +836,11 @@ __global__ __launch_bounds__(256, 3) void gemm_x3p_kernel(const GemmP p) {
     }
     for (; kt < nk; ++kt) {
         const int newer = nk - 1 - kt;             // 0 .. R - 2 A stages still in flight behind A(kt)
-        if (newer >= 2) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
-        else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        if (newer >= 4) X3P_WAIT_A(14);
+        else if (newer == 3) X3P_WAIT_A(12);
+        else if (newer == 2) X3P_WAIT_A(10);
+        else if (newer == 1) X3P_WAIT_A(8);
+        else X3P_WAIT_A(6);
         splita(kt);
         X3P_WAIT_B(0);
         mfmas();

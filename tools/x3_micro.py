@@ -24,12 +24,13 @@ def main():
     shapes = [("plain   N128 K128", 128, 128, 0, {}), ("bias+res N128 K128", 128, 128, 0, dict(bias=1, res=1)),
               ("silu+pre N256 K128", 256, 128, 0, dict(bias=1, act=1, pre=1)), ("plain   N128 K256", 128, 256, 0, {}),
               ("dgrad   N128 K384", 128, 384, 1, {}), ("dgrad+aux N128 K256", 128, 256, 1, dict(aux=1)),
-              ("plain   N384 K128", 384, 128, 0, dict(bias=1))]
+              ("plain   N384 K128", 384, 128, 0, dict(bias=1)),
+              ("A^T     N128 K128", 128, 128, 0, dict(la=1)), ("A^T     N128 K384", 128, 384, 0, dict(la=1))]
     out = {"lib": os.environ.get("GT_HIP_LIB", "libgt_hip.so"), "T": T}
     for name, N, K, lb, ep in shapes:
         sets = []
         for r in range(3):
-            A = torch.randn(T, K, device=dev)
+            A = torch.randn((K, T) if ep.get("la") else (T, K), device=dev)
             Bm = torch.randn((N, K) if lb == 0 else (K, N), device=dev) * 0.1
             C = torch.empty(T, N, device=dev)
             kw = {}
@@ -44,7 +45,8 @@ def main():
             if ep.get("aux"):
                 kw.update(aux_op=H.AUX_DSILU, aux=torch.randn(T, N, device=dev), ldaux=N)
             sets.append((A, Bm, C, kw))
-        fn = lambda i: H.gemm(sets[i % 3][0], sets[i % 3][1], sets[i % 3][2], T, N, K, layout_b=lb, lda=K,
+        fn = lambda i: H.gemm(sets[i % 3][0], sets[i % 3][1], sets[i % 3][2], T, N, K, layout_a=int(bool(ep.get("la"))),
+                              layout_b=lb, lda=(T if ep.get("la") else K),
                               ldb=sets[i % 3][1].shape[1], ldc=N, **sets[i % 3][3])
         for i in range(3):
             fn(i)
