@@ -258,10 +258,20 @@ def conv3x3_nhwc_ok(conv: torch.nn.Conv2d) -> bool:
 
 
 _conv_implicit = [os.environ.get("GT_CONV_IMPLICIT", "1") != "0"]        # A/B switches (tools / tests)
-# weight gradient of the implicit convolution: "miopen" (default) = the library's channels-last wrw kernel on the same
-# buffers, "hip" = the nine-tap pixel contraction on the ring kernel.  Same box, back to back (tools/gpu_ab.sh, B = 128):
-# 34.23 vs 34.42 ms/step -- the ring kernel's x-contiguous flavour is VALU-bound on the operand split
-_conv_wgrad = [os.environ.get("GT_CONV_WGRAD", "miopen") == "hip"]
+# weight gradient of the implicit convolution: "hip" (default) = the nine-tap pixel contraction on the ring kernel,
+# "miopen" = the library's channels-last wrw kernel on the same buffers.  Same box, back to back at B = 128 with the
+# two-stream backward (tools/gpu_ab.sh): 33.31 / 33.46 vs 33.31 / 33.33 ms/step -- a tie; the library kernel is not
+# the default because its solver choice is not ours: at B = 4 MIOpen has been seen to answer this layout with
+# naive_conv_ab_nonpacked_wrw_nhwc (34 ms per call, profiles/README.md).
+_conv_wgrad = [os.environ.get("GT_CONV_WGRAD", "hip") != "miopen"]
+
+
+def _conv_k_order(w):
+    """[N, 9 taps, C] filter -> [N, 9 C] in the contraction order of the implicit-GEMM kernel (gt_hip.h: cv_*): channel
+    blocks of CB outermost, the nine taps of a block adjacent."""
+    N, _, Cc = w.shape
+    cb = 32 if Cc % 32 == 0 else 16
+    return w.reshape(N, 9, Cc // cb, cb).permute(0, 2, 1, 3).reshape(N, 9 * Cc).contiguous()
 
 
 class Conv3x3NhwcFn(Function):
@@ -271,9 +281,9 @@ class Conv3x3NhwcFn(Function):
     Interp2dUpsample, layers.py:624-670) where the channel counts fill the 128 x 128 tiles (the up-scaler's
     n_hidden -> n_hidden convolution).  Forward: [pixels, 9 C] x [C', 9 C]^T with the nine shifted views of x read in
     place (gt_hip.h: cv_*).  Data gradient: the same product on gy with the taps reversed and the channel roles
-    swapped.  Weight gradient: the library's channels-last wrw kernel on the same buffers (no layout change), or with
-    GT_CONV_WGRAD=hip nine pixel-contracted products, one per tap, cut into K chunks on one launch of the ring kernel
-    (images at least 16 pixels wide) -- measured 0.6 % of a step slower, so it is the opt-in."""
+    swapped.  Weight gradient: nine pixel-contracted products, one per tap, cut into K chunks on one launch of the ring
+    kernel (images at least 16 pixels wide); GT_CONV_WGRAD=miopen (and narrower images) use the library's channels-last
+    wrw kernel on the same buffers instead -- the two tie at B = 128."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -281,7 +291,7 @@ class Conv3x3NhwcFn(Function):
         B, Hh, Ww, Cin = x.shape
         Cout = weight.shape[0]
         xc = _c(x)
-        wf = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()       # [Cout][tap][Cin]
+        wf = _conv_k_order(weight.permute(0, 2, 3, 1).reshape(Cout, 9, Cin))       # [Cout][tap][Cin] -> k order
         y = torch.empty(B, Hh, Ww, Cout, dtype=torch.float32, device=x.device)
         H.gemm(xc, wf, y, B * Hh * Ww, Cout, 9 * Cin, lda=Cin, ldb=9 * Cin, ldc=Cout, conv=(Hh, Ww, Cin))
         ctx.save_for_backward(xc, weight)
@@ -297,7 +307,7 @@ class Conv3x3NhwcFn(Function):
         dev = g.device
         if ctx.needs_input_grad[0]:
             # dx[pix][ci] = sum_tap sum_co gy[pix - shift(tap)][co] W[co][ci][tap]: tap' = 8 - tap has the opposite shift
-            wd = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()      # [Cin][tap'][Cout]
+            wd = _conv_k_order(weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9, Cout))     # [Cin][tap'][Cout]
             dx = torch.empty(B, Hh, Ww, Cin, dtype=torch.float32, device=g.device)
             with H.side_branch(dev):    # the data gradient next to the weight gradient below
                 H.gemm(g, wd, dx, B * Hh * Ww, Cin, 9 * Cout, lda=Cout, ldb=9 * Cout, ldc=Cin, conv=(Hh, Ww, Cout))

@@ -178,9 +178,11 @@ typedef struct gt_gemm_desc {
     int32_t precision;
 
     /* Implicit 3x3 convolution (stride 1, zero padding 1) on channels-last activations: cv_c > 0 makes A a
-     * [B, cv_h, cv_w, cv_c] image, M = B*cv_h*cv_w its pixels, K = 9*cv_c, and the contraction index k = tap*cv_c + c
-     * with tap = 3*(dy+1) + (dx+1) reads A[pixel + (dy, dx)][c] (zero outside the image) -- the im2col matrix is never
-     * written.  B is then the filter as [N][9*cv_c] (layout_b = 0), i.e. an nn.Conv2d weight in channels-last memory
+     * [B, cv_h, cv_w, cv_c] image, M = B*cv_h*cv_w its pixels, K = 9*cv_c, and the contraction index
+     *     k = (c / CB) * 9*CB + tap * CB + (c % CB),      CB = 32 if cv_c % 32 == 0 else 16,  tap = 3*(dy+1) + (dx+1)
+     * reads A[pixel + (dy, dx)][c] (zero outside the image) -- the im2col matrix is never written; the nine taps of a
+     * channel block are adjacent in k so that they hit the same cache lines back to back.  B is the filter as
+     * [N][9*cv_c] in that k order (layout_b = 0): an nn.Conv2d weight [N][c][3][3] -> [N][c/CB][tap][CB]
      * for the forward product (layers.py:98-100 `nn.Conv2d(.., kernel_size=3, padding=1, bias=False)` of the scaler
      * blocks), or the tap-reversed, in/out-swapped filter for the data gradient.  Split-operand ring kernel only:
      * precision != GT_PREC_F32, layout_a = layout_b = 0, cv_c % 16 == 0, no batching, no split-K, no A dropout,
