@@ -367,10 +367,16 @@ def roofline_leg(trainer, precision):
     # measurement for exactly this launch is on file under profiles/
     traffic, tsrc = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(f"{dom}|{','.join(str(v) for v in best[6])}")
-        if rec:
-            traffic, tsrc = int(rec["read_bytes"] + rec["write_bytes"]), rec["source"]
+        with open(os.path.join(ROOT, "profiles", "pmc_step.json")) as f:
+            pj = json.load(f)
+        # one launch geometry of the symbol: the split-operand kernels run 256 threads per 128 x 128 output tile
+        Ms, Ns = best[6][0], best[6][1]
+        grid = -(-Ms // 128) * -(-Ns // 128) * 256 * best[6][3]
+        rec = pj.get("_by_grid", {}).get(f"gt::{dom.replace('+splitk', '')}|{grid}") if x3_name(dom) else None
+        if rec and "read_bytes" in rec and "write_bytes" in rec:
+            traffic = int(rec["read_bytes"] + rec["write_bytes"])
+            tsrc = (pj.get("_source", "") + f"; the {rec['calls_seen']} launches of this symbol with grid size {grid} "
+                    "(every launch of this output shape in the step, averaged)")
     except (OSError, ValueError):
         pass
     roof = dict(bound=bound, kernel="gt::" + dom.replace("+splitk", ""), launch_shape_MNKb=list(best[6]),
@@ -398,14 +404,13 @@ def roofline_leg(trainer, precision):
     except (OSError, ValueError):
         pmc = {}
     legs = {}
-    for label, key, sym in (("qkv_proj+headnorm_fwd", "gemm_x3r_kernel<0, 0, 3, 3, 32, 0>", "gt::gemm_x3r_kernel<0, 0, 3, 3, 32, 0>"),
+    for label, key, sym in (("qkv_proj+headnorm_fwd", "gemm_x3p_kernel<0, 32, 0>", "gt::gemm_x3p_kernel<0, 32, 0>"),
                             ("headnorm_fwd", "gt_headnorm_fwd", "gt::headnorm_fwd_v2_kernel"),
                             ("headnorm_bwd", "gt_headnorm_bwd", "gt::headnorm_bwd_v2_kernel"),
                             ("galerkin_ktv", "gt_galerkin_ktv", "gt::galerkin_ktv_kernel<2>"),
                             ("galerkin_dkv", "gt_galerkin_dkv", "gt::galerkin_dkv_kernel<2>"),
-                            ("token_gemm_KN", "gemm_x3r_kernel<0, 1, 3, 3, 0, 0>", "gt::gemm_x3r_kernel<0, 1, 3, 3, 0, 0>"),
-                            ("token_gemm_NK(ffn)", "gemm_x3r_kernel<0, 0, 3, 3, 0, 0>", "gt::gemm_x3r_kernel<0, 0, 3, 3, 0, 0>"),
-                            ("conv3x3_implicit", "gemm_x3r_kernel<0, 0, 3, 3, 0, 1>", "gt::gemm_x3r_kernel<0, 0, 3, 3, 0, 1>"),
+                            ("token_gemms(packed B)", "gemm_x3p_kernel<0, 0, 0>", "gt::gemm_x3p_kernel<0, 0, 0>"),
+                            ("conv3x3_implicit", "gemm_x3p_kernel<0, 0, 1>", "gt::gemm_x3p_kernel<0, 0, 1>"),
                             ("conv3x3_wgrad", "gemm_x3r_kernel<1, 1, 3, 3, 0, 2>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 2>"),
                             ("weight_gradients", "gemm_x3r_kernel<1, 1, 3, 3, 0, 0>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 0>")):
         t = table.get(key) or table.get(key.replace("+splitk", ""))
@@ -425,6 +430,10 @@ def roofline_leg(trainer, precision):
         legs[label] = leg
     roof["legs"] = legs
     return roof, table
+
+
+def x3_name(key: str) -> bool:
+    return key.startswith("gemm_x3")
 
 
 def cpu_baseline_leg(model_cpu_sd, cfg, budget_s=20.0):

@@ -525,6 +525,189 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_kernel(const DkvP p) {
     }
 }
 
+// ---------------------------------------------------------------- galerkin dK', dV' with the LayerNorm backward behind them
+// The two products of galerkin_dkv_kernel, and on the same registers the per-head LayerNorm backward of
+// headnorm_bwd_v2_kernel for the K and V streams (layers.py:841-874 backwards): the head-tile gradients dK', dV'
+// ([T][h][DP], 2 x 136 MB at B = 128) are never written or read back.  A lane holds four consecutive tile columns
+// 16 mt + 4 kq .. + 3 of token row j, i.e. value columns v = col - p of the head: a row's dk values sit in the four kq
+// lanes of its j, so the two row means are a local sum and two cross-lane adds.  p is even (0 or 2): a float4 of tile
+// columns is two 8-byte aligned pairs of the raw projection / its gradient.  d(gamma), d(beta): per-lane running sums
+// over the block's tokens, folded over the 16 token lanes, then over the four waves in LDS in a fixed order; block
+// (b, head) owns the head's dk-slice of partial[b][dg K | dg V | db K | db V] (the layout gt_headnorm_bwd reduces).
+struct DkvLnP {
+    const float* Kp; const float* Vp; const float* dM;
+    const float* qkv; const float* gamma; const float* stats;
+    float* d_qkv; float* partial;
+    int n, h, dk, p, T;
+};
+template <int G>
+__global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p) {
+    constexpr int DP = 16 * G + 4, NS = 4 * G + 1, NMT = G + 1;
+    __shared__ float red[4][4][NMT][4][4];          // [wave][kq][mt][c][dgK, dbK, dgV, dbV]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int head = blockIdx.x % p.h, b = blockIdx.x / p.h;
+    const int64_t hD = (int64_t)p.h * DP;
+    const int64_t base = ((int64_t)b * p.n) * hD + (int64_t)head * DP;
+    const float* dm = p.dM + ((int64_t)b * p.h + head) * DP * DP;
+    const int hd = p.h * p.dk, d3 = 3 * hd;
+    const float inv = 1.f / (float)p.dk;
+    float a1[NMT][NS], a2[NMT][NS];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+        const int col = 16 * mt + j, cc = min(col, DP - 1);
+        const float live = col < DP ? 1.f : 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int k = (s < 4 * G) ? 4 * (kq + 4 * (s >> 2)) + (s & 3) : 16 * G + kq;
+            a1[mt][s] = live * dm[cc * DP + k];
+            a2[mt][s] = live * dm[k * DP + cc];
+        }
+    }
+    // this lane's value columns: pair A = (v0, v0 + 1), pair B = (v0 + 2, v0 + 3) of tile group mt
+    bool okA[NMT], okB[NMT];
+    f32x4 gmK[NMT], gmV[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+        const int v0 = 16 * mt + 4 * kq - p.p;
+        okA[mt] = v0 >= 0 && v0 + 1 < p.dk;
+        okB[mt] = v0 + 2 >= 0 && v0 + 3 < p.dk;
+        gmK[mt] = gmV[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* gk = p.gamma + (int64_t)head * p.dk + v0;
+        const float* gv = gk + hd;
+        if (okA[mt]) { gmK[mt][0] = gk[0]; gmK[mt][1] = gk[1]; gmV[mt][0] = gv[0]; gmV[mt][1] = gv[1]; }
+        if (okB[mt]) { gmK[mt][2] = gk[2]; gmK[mt][3] = gk[3]; gmV[mt][2] = gv[2]; gmV[mt][3] = gv[3]; }
+    }
+    f32x4 dgK[NMT], dbK[NMT], dgV[NMT], dbV[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) dgK[mt] = dbK[mt] = dgV[mt] = dbV[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntile = (p.n + 15) >> 4;
+    for (int tile = wave; tile < ntile; tile += 4) {
+        const int t = 16 * tile + j, tc = min(t, p.n - 1);
+        const int64_t tok = (int64_t)b * p.n + tc;
+        const float* kr = p.Kp + base + (int64_t)tc * hD;
+        const float* vr = p.Vp + base + (int64_t)tc * hD;
+        f32x4 kk[G + 1], vv[G + 1];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            kk[g] = *reinterpret_cast<const f32x4*>(kr + 4 * (kq + 4 * g));
+            vv[g] = *reinterpret_cast<const f32x4*>(vr + 4 * (kq + 4 * g));
+        }
+        kk[G] = *reinterpret_cast<const f32x4*>(kr + 16 * G);
+        vv[G] = *reinterpret_cast<const f32x4*>(vr + 16 * G);
+        // raw projection rows and statistics of this token (requested before the products, used after them)
+        const float* xk = p.qkv + tok * d3 + hd + head * p.dk - p.p + 4 * kq;        // + 16 mt : tile column -> value
+        const float* xv = xk + hd;
+        f32x4 xK[NMT], xV[NMT];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+            xK[mt] = xV[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (okA[mt]) {
+                const f32x2 a = *reinterpret_cast<const f32x2*>(xk + 16 * mt), c = *reinterpret_cast<const f32x2*>(xv + 16 * mt);
+                xK[mt][0] = a[0]; xK[mt][1] = a[1]; xV[mt][0] = c[0]; xV[mt][1] = c[1];
+            }
+            if (okB[mt]) {
+                const f32x2 a = *reinterpret_cast<const f32x2*>(xk + 16 * mt + 2), c = *reinterpret_cast<const f32x2*>(xv + 16 * mt + 2);
+                xK[mt][2] = a[0]; xK[mt][3] = a[1]; xV[mt][2] = c[0]; xV[mt][3] = c[1];
+            }
+        }
+        const f32x2 stK = *reinterpret_cast<const f32x2*>(p.stats + (tok * p.h + head) * 2);
+        const f32x2 stV = *reinterpret_cast<const f32x2*>(p.stats + (((int64_t)p.T + tok) * p.h + head) * 2);
+
+        f32x4 acc1[NMT], acc2[NMT];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) acc1[mt] = acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float bv, bk;
+            if (s < 4 * G) { bv = vv[s >> 2][s & 3]; bk = kk[s >> 2][s & 3]; }
+            else {
+                bv = kq == 0 ? vv[G][0] : (kq == 1 ? vv[G][1] : (kq == 2 ? vv[G][2] : vv[G][3]));
+                bk = kq == 0 ? kk[G][0] : (kq == 1 ? kk[G][1] : (kq == 2 ? kk[G][2] : kk[G][3]));
+            }
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt][s], bv, acc1[mt], 0, 0, 0);
+                acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mt][s], bk, acc2[mt], 0, 0, 0);
+            }
+        }
+        const bool live = t < p.n;
+        // LayerNorm backward of one stream on the lane's columns: gy = d(normalised head row), x = raw row
+        auto ln_bwd = [&](const f32x4 (&gy)[NMT], const f32x4 (&x)[NMT], const f32x4 (&gm)[NMT], f32x2 st,
+                          f32x4 (&dg)[NMT], f32x4 (&db)[NMT], float* __restrict__ dst) {
+            const float mu = st[0], rstd = st[1];
+            f32x4 xh[NMT], gg[NMT];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool ok = c < 2 ? okA[mt] : okB[mt];
+                    xh[mt][c] = ok ? (x[mt][c] - mu) * rstd : 0.f;
+                    gg[mt][c] = ok ? gy[mt][c] * gm[mt][c] : 0.f;
+                    s1 += gg[mt][c];
+                    s2 += gg[mt][c] * xh[mt][c];
+                }
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            const float m1 = s1 * inv, m2 = s2 * inv;
+            if (!live) return;
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                f32x4 dx;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool ok = c < 2 ? okA[mt] : okB[mt];
+                    dx[c] = rstd * (gg[mt][c] - m1 - xh[mt][c] * m2);
+                    if (ok) { dg[mt][c] += gy[mt][c] * xh[mt][c]; db[mt][c] += gy[mt][c]; }
+                }
+                if (okA[mt]) *reinterpret_cast<f32x2*>(dst + 16 * mt) = f32x2{dx[0], dx[1]};
+                if (okB[mt]) *reinterpret_cast<f32x2*>(dst + 16 * mt + 2) = f32x2{dx[2], dx[3]};
+            }
+        };
+        float* dk_row = p.d_qkv + tok * d3 + hd + head * p.dk - p.p + 4 * kq;
+        ln_bwd(acc1, xK, gmK, stK, dgK, dbK, dk_row);
+        ln_bwd(acc2, xV, gmV, stV, dgV, dbV, dk_row + hd);
+    }
+    // fold the 16 token lanes, then the four waves (fixed order)
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v[4] = {dgK[mt][c], dbK[mt][c], dgV[mt][c], dbV[mt][c]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) v[q] += __shfl_xor(v[q], m, 64);
+                if (j == 0) red[wave][kq][mt][c][q] = v[q];
+            }
+        }
+    __syncthreads();
+    float* pg = p.partial + (int64_t)b * 4 * hd + (int64_t)head * p.dk;
+    for (int e = threadIdx.x; e < 4 * NMT * 4 * 4; e += blockDim.x) {
+        const int q = e & 3, c = (e >> 2) & 3, mt = (e >> 4) % NMT, kq2 = e / (16 * NMT);
+        const int v = 16 * mt + 4 * kq2 + c - p.p;
+        if (v < 0 || v >= p.dk) continue;
+        const float sum = ((red[0][kq2][mt][c][q] + red[1][kq2][mt][c][q]) + red[2][kq2][mt][c][q]) + red[3][kq2][mt][c][q];
+        // q: 0 dg K, 1 db K, 2 dg V, 3 db V   ->  partial row [dg K | dg V | db K | db V], each h*dk wide
+        pg[((q & 1) * 2 + (q >> 1)) * hd + v] = sum;
+    }
+}
+
+// Q stream of the galerkin backward (not normalised): drop the coordinate / pad columns of dQ' [T][h][DP] into the Q block
+// of d_qkv [T][3 h dk]
+__global__ __launch_bounds__(256) void headtile_unpad_kernel(const float* __restrict__ src, float* __restrict__ d_qkv,
+                                                             int64_t total4, int h, int dk, int p, int DP) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total4) return;
+    const int Q4 = dk >> 2;
+    const int q = (int)(e % Q4), head = (int)((e / Q4) % h);
+    const int64_t t = e / ((int64_t)Q4 * h);
+    const f32x4 v = tile_load4(src + (t * h + head) * DP + p + 4 * q, p);
+    *reinterpret_cast<f32x4*>(d_qkv + t * 3 * h * dk + head * dk + 4 * q) = v;
+}
+
 static bool head_geom(int T, int h, int dk, int p, int norm_mask, int max_blocks, HeadGeom* g, int* threads,
                       int* blocks) {
     if (dk & 3) return false;
@@ -1106,6 +1289,40 @@ extern "C" int gt_galerkin_dkv(const float* Kp, const float* Vp, const float* dM
     else hipLaunchKernelGGL(galerkin_dkv_kernel<3>, grid, dim3(256), 0, st, p);
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int64_t gt_galerkin_dkv_ln_ws_bytes(int32_t B, int32_t h, int32_t dk) {
+    return (int64_t)B * 4 * h * dk * (int64_t)sizeof(float);
+}
+
+extern "C" int gt_galerkin_dkv_ln(const float* Kp, const float* Vp, const float* dM, const float* dQp, const float* qkv,
+                                  const float* gamma, const float* stats, int32_t B, int32_t n, int32_t h, int32_t dk,
+                                  int32_t p, float* d_qkv, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
+                                  void* stream) {
+    if (!Kp || !Vp || !dM || !dQp || !qkv || !gamma || !stats || !d_qkv || !dgamma || !dbeta) return GT_EINVAL;
+    if (B <= 0 || n <= 0 || h <= 0 || dk <= 0 || p < 0) return GT_EINVAL;
+    const int DP = round4(dk + p);
+    if ((DP != 20 && DP != 36 && DP != 52) || (p & 1) || (dk & 3)) return GT_ENOTSUP;
+    if ((reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vp) | reinterpret_cast<uintptr_t>(dQp) |
+         reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(d_qkv) | reinterpret_cast<uintptr_t>(stats)) & 15)
+        return GT_EALIGN;
+    if (!ws || ws_bytes < gt_galerkin_dkv_ln_ws_bytes(B, h, dk)) return GT_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    const int hd = h * dk;
+    float* partial = reinterpret_cast<float*>(ws);
+    DkvLnP q{Kp, Vp, dM, qkv, gamma, stats, d_qkv, partial, n, h, dk, p, B * n};
+    dim3 grid((unsigned)(B * h));
+    if (DP == 20) hipLaunchKernelGGL(galerkin_dkv_ln_kernel<1>, grid, dim3(256), 0, st, q);
+    else if (DP == 36) hipLaunchKernelGGL(galerkin_dkv_ln_kernel<2>, grid, dim3(256), 0, st, q);
+    else hipLaunchKernelGGL(galerkin_dkv_ln_kernel<3>, grid, dim3(256), 0, st, q);
+    GT_LAUNCH_CHECK();
+    const int64_t total4 = (int64_t)B * n * h * (dk >> 2);
+    hipLaunchKernelGGL(headtile_unpad_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, dQp, d_qkv, total4,
+                       h, dk, p, DP);
+    GT_LAUNCH_CHECK();
+    int rc = gt_slab_reduce(partial, 4 * hd, B, 2 * hd, 1.f, dgamma, stream);
+    if (rc) return rc;
+    return gt_slab_reduce(partial + 2 * hd, 4 * hd, B, 2 * hd, 1.f, dbeta, stream);
 }
 
 extern "C" int gt_galerkin_finalize_fwd(const float* slabs, int32_t n_slabs, int64_t slab_stride, int32_t B,

@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 10          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 11          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -91,6 +91,8 @@ _PROTOS = {
     "gt_galerkin_ktv_slabs": (C.c_int32, [C.c_int32, C.c_int32]),
     "gt_galerkin_ktv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
     "gt_galerkin_dkv": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
+    "gt_galerkin_dkv_ln_ws_bytes": (C.c_int64, [C.c_int32] * 3),
+    "gt_galerkin_dkv_ln": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p]),
     "gt_fourier_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.POINTER(GtDropout),
                                                                 C.c_int32, C.c_void_p]),
     "gt_dropact_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(GtDropout), C.c_int32, C.POINTER(GtDropout),
@@ -789,6 +791,30 @@ def galerkin_dkv(Kp, Vp, dM, dKp, dVp, B: int, n: int, h: int, DP: int):
     check(_timed("gt_galerkin_dkv", 4.0 * B * h * n * DP * DP, 16.0 * B * n * h * DP,
                  lambda: lib().gt_galerkin_dkv(Kp.data_ptr(), Vp.data_ptr(), dM.data_ptr(), dKp.data_ptr(), dVp.data_ptr(),
                                                B, n, h, DP, stream_ptr()), shape=(B, n, h, DP)), "gt_galerkin_dkv")
+
+
+def galerkin_dkv_ln_supported(dk: int, p: int, norm_mask: int) -> bool:
+    """Shapes of gt_galerkin_dkv_ln: K and V normalised, even coordinate count, head tile of 20 / 36 / 52 floats."""
+    return norm_mask == 0b110 and p % 2 == 0 and dk % 4 == 0 and round4(dk + p) in FOURIER_DP
+
+
+def galerkin_dkv_ln(Kp, Vp, dM, dQp, qkv, gamma, stats, B: int, n: int, h: int, dk: int, p: int):
+    """dK' = V' dM^T, dV' = K' dM with the per-head LayerNorm backward applied on the way out, plus the Q block: returns
+    (d_qkv [B*n, 3 h dk], dgamma, dbeta [2, h, dk]) -- what galerkin_dkv + headnorm_bwd return, in one streaming pass."""
+    need_f32_cuda(Kp, Vp, dM, dQp, qkv, gamma, stats)
+    dev = qkv.device
+    T = B * n
+    d_qkv = torch.empty(T, 3 * h * dk, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(2, h, dk, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(2, h, dk, dtype=torch.float32, device=dev)
+    ws = workspace(dev, lib().gt_galerkin_dkv_ln_ws_bytes(B, h, dk))
+    DP = round4(dk + p)
+    check(_timed("gt_galerkin_dkv_ln", 4.0 * B * h * n * DP * DP, 4.0 * T * h * (3 * DP + 5 * dk),
+                 lambda: lib().gt_galerkin_dkv_ln(Kp.data_ptr(), Vp.data_ptr(), dM.data_ptr(), dQp.data_ptr(), qkv.data_ptr(),
+                                                  gamma.data_ptr(), stats.data_ptr(), B, n, h, dk, p, d_qkv.data_ptr(),
+                                                  dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  stream_ptr()), shape=(B, n, h, DP)), "gt_galerkin_dkv_ln")
+    return d_qkv, dgamma, dbeta
 
 
 def mlp_head_supported(K: int, N: int, n_out: int) -> bool:

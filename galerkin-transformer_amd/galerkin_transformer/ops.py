@@ -257,6 +257,7 @@ def conv3x3_nhwc_ok(conv: torch.nn.Conv2d) -> bool:
             and _conv_implicit[0])
 
 
+_dkv_ln_fused = [os.environ.get("GT_DKV_LN", "1") != "0"]               # gt_galerkin_dkv_ln vs gt_galerkin_dkv + gt_headnorm_bwd
 _conv_implicit = [os.environ.get("GT_CONV_IMPLICIT", "1") != "0"]        # A/B switches (tools / tests)
 # weight gradient of the implicit convolution: "hip" (default) = the nine-tap pixel contraction on the ring kernel,
 # "miopen" = the library's channels-last wrw kernel on the same buffers.  Same box, back to back at B = 128 with the
@@ -703,7 +704,10 @@ class SimpleAttentionFn(Function):
             dwfc = torch.empty(d, h * Dr, dtype=torch.float32, device=dev)
             H.slab_reduce(dWs, B, d * h * Dr, d * h * Dr, dwfc)
             # dK' = V' dM^T ; dV' = K' dM          per (b, head)
-            if DP in H.FOURIER_DP:                             # one streaming pass (gt_galerkin_dkv)
+            fused_ln = _dkv_ln_fused[0] and H.galerkin_dkv_ln_supported(dk, p, norm_mask)
+            if fused_ln:       # ... with the head LayerNorm backward behind them: dK', dV' stay in registers
+                dqkv, dgamma, dbeta = H.galerkin_dkv_ln(Kp, Vp, dM, dO3[0], qkv, gamma, stats, B, n, h, dk, p)
+            elif DP in H.FOURIER_DP:                           # one streaming pass (gt_galerkin_dkv)
                 H.galerkin_dkv(Kp, Vp, dM, dO3[1], dO3[2], B, n, h, DP)
             else:
                 H.gemm(Vp, dM, dO3[1], n, DP, DP, lda=hD, ldb=DP, ldc=hD, batch=(B, h), a_bs=(n * hD, DP),
@@ -742,7 +746,8 @@ class SimpleAttentionFn(Function):
                        a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
                 H.gemm(dS, Qp, dO3[1], n, DP, n, layout_a=1, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
                        a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
-        dqkv, dgamma, dbeta = H.headnorm_bwd(dO3, qkv, gamma, stats, T, h, dk, p, norm_mask)
+        if not (kind == "galerkin" and fused_ln):
+            dqkv, dgamma, dbeta = H.headnorm_bwd(dO3, qkv, gamma, stats, T, h, dk, p, norm_mask)
         dwqkv = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
         dbqkv = torch.empty(3 * d, dtype=torch.float32, device=dev) if hbq else None
         dx = torch.empty(T, d, dtype=torch.float32, device=dev)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 10
+#define GT_ABI_VERSION 11
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -278,6 +278,17 @@ int gt_galerkin_finalize_bwd(const float* dPt, const float* Mt, const float* mas
  * DP in {20, 36, 52}, else GT_ENOTSUP (two batched gt_gemm launches do the same). */
 int gt_galerkin_dkv(const float* Kp, const float* Vp, const float* dM, float* dKp, float* dVp, int32_t B,
                     int32_t n, int32_t h, int32_t DP, void* stream);
+
+/* The same two products with the per-head LayerNorm backward of gt_headnorm_bwd (norm_mask = K and V, layers.py:841-874
+ * backwards) applied on the way out: dK', dV' are never written.  Writes all three blocks of d_qkv [B*n][3 h dk] (K, V:
+ * LayerNorm backward of the products; Q: dQp [B*n][h][DP] with its coordinate / pad columns dropped) and
+ * dgamma / dbeta [2][h][dk] (K then V).  qkv = the raw projection, gamma [2][h][dk], stats [2][B*n][h][2] as
+ * gt_headnorm_fwd left them.  DP = round4(dk + p) in {20, 36, 52} and p even, else GT_ENOTSUP (gt_galerkin_dkv +
+ * gt_headnorm_bwd do the same in two passes). */
+int64_t gt_galerkin_dkv_ln_ws_bytes(int32_t B, int32_t h, int32_t dk);
+int gt_galerkin_dkv_ln(const float* Kp, const float* Vp, const float* dM, const float* dQp, const float* qkv,
+                       const float* gamma, const float* stats, int32_t B, int32_t n, int32_t h, int32_t dk, int32_t p,
+                       float* d_qkv, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused Fourier-type attention (layers.py:672-705):  out = ((Q' K'^T) * scale .* mask) V'  on the head-tile

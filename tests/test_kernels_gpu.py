@@ -1052,3 +1052,34 @@ def test_gemm_x3_packed_b_epilogue_and_a_dropout(H, gpu_device):
         out[prec] = (Cc, pre)
     torch.cuda.synchronize()
     assert rel_l2(out["bf16x3"][0], out["f32"][0]) < 2e-6 and rel_l2(out["bf16x3"][1], out["f32"][1]) < 2e-6
+
+
+@pytest.mark.parametrize("B,n,h,dk,p", [(2, 100, 4, 32, 2), (1, 37, 2, 16, 2), (3, 1849, 4, 32, 2), (1, 64, 1, 48, 2),
+                                        (2, 50, 4, 36, 0)])
+def test_galerkin_dkv_ln_fused_equals_two_passes(H, gpu_device, B, n, h, dk, p):
+    """gt_galerkin_dkv_ln (dK', dV' products + head LayerNorm backward + Q un-padding in one pass) ==
+    gt_galerkin_dkv followed by gt_headnorm_bwd with norm_mask = K, V (layers.py:841-874 and :723 backwards)."""
+    dev = gpu_device
+    T, DP = B * n, H.round4(dk + p)
+    assert H.galerkin_dkv_ln_supported(dk, p, 0b110)
+    Kp, Vp = rnd(T, h, DP, dev=dev, seed=400), rnd(T, h, DP, dev=dev, seed=401)
+    dM = rnd(B, h, DP, DP, dev=dev, seed=402, scale=0.2)
+    dQp = rnd(T, h, DP, dev=dev, seed=403)
+    qkv = rnd(T, 3 * h * dk, dev=dev, seed=404)
+    gamma = 1 + 0.2 * rnd(2, h, dk, dev=dev, seed=405)
+    stats = torch.stack([0.3 * rnd(2, T, h, dev=dev, seed=406), 0.5 + rnd(2, T, h, dev=dev, seed=407).abs()], -1).contiguous()
+    dO3 = torch.empty(3, T, h, DP, device=dev)
+    dO3[0] = dQp
+    H.galerkin_dkv(Kp, Vp, dM, dO3[1], dO3[2], B, n, h, DP)
+    ref = H.headnorm_bwd(dO3, qkv, gamma, stats, T, h, dk, p, 0b110)
+    got = H.galerkin_dkv_ln(Kp, Vp, dM, dQp, qkv, gamma, stats, B, n, h, dk, p)
+    torch.cuda.synchronize()
+    for a, c, name in zip(got, ref, ("d_qkv", "dgamma", "dbeta")):
+        assert not torch.isnan(a).any(), name
+        assert rel_l2(a, c) < 2e-6, name
+
+
+def test_galerkin_dkv_ln_unsupported_shapes(H, gpu_device):
+    assert not H.galerkin_dkv_ln_supported(32, 1, 0b110)       # odd coordinate count: 4-byte aligned value columns
+    assert not H.galerkin_dkv_ln_supported(32, 2, 0b011)       # fourier-type norms (Q, K)
+    assert not H.galerkin_dkv_ln_supported(64, 2, 0b110)       # head tile of 68 floats

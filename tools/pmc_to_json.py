@@ -23,16 +23,21 @@ def short(n):
 
 
 res = defaultdict(dict)
+by_grid = defaultdict(dict)          # "symbol|grid size": one launch geometry of a symbol (a template instance serves many)
 for counter, key, scale in (("FETCH_SIZE", "read_bytes", 2048.0), ("WRITE_SIZE", "write_bytes", 1024.0)):
     agg = defaultdict(lambda: [0, 0.0])
+    aggg = defaultdict(lambda: [0, 0.0])
     for r in rows(counter, "*counter_collection.csv"):
         if r["Counter_Name"] == counter:
-            a = agg[short(r["Kernel_Name"])]
-            a[0] += 1
-            a[1] += float(r["Counter_Value"])
+            for a in (agg[short(r["Kernel_Name"])], aggg[short(r["Kernel_Name"]) + "|" + r.get("Grid_Size", "")]):
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
     for k, (n, v) in agg.items():
         res[k][key] = v / n * scale
         res[k]["calls_seen"] = n
+    for k, (n, v) in aggg.items():
+        by_grid[k][key] = v / n * scale
+        by_grid[k]["calls_seen"] = n
 agg = defaultdict(lambda: [0, 0.0])
 disp = {}
 for r in rows("SQ", "*counter_collection.csv"):
@@ -53,6 +58,7 @@ for k, (n, v) in agg.items():
         res[k]["mfma_util_at_2.4GHz"] = (v / n) / (1024.0 * ns * 2.4)
 meta = {"_source": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES, separate passes, --kernel-trace only, "
                    "over `bench.py --steps 2 --warmup 1 --no-graph` (tools/gpu_measure.sh); FETCH_SIZE doubled (gfx950)"}
+meta["_by_grid"] = {k: v for k, v in sorted(by_grid.items()) if v.get("read_bytes", 0) + v.get("write_bytes", 0) > 32e6}
 json.dump({**meta, **dict(sorted(res.items(), key=lambda kv: -(kv[1].get('read_bytes', 0) + kv[1].get('write_bytes', 0))))},
           open(out_path, "w"), indent=1)
 print(f"{len(res)} kernels -> {out_path}")
