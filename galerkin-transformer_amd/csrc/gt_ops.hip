@@ -1299,12 +1299,12 @@ extern "C" int gt_galerkin_dkv_ln(const float* Kp, const float* Vp, const float*
                                   const float* gamma, const float* stats, int32_t B, int32_t n, int32_t h, int32_t dk,
                                   int32_t p, float* d_qkv, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
                                   void* stream) {
-    if (!Kp || !Vp || !dM || !dQp || !qkv || !gamma || !stats || !d_qkv || !dgamma || !dbeta) return GT_EINVAL;
+    if (!Kp || !Vp || !dM || !qkv || !gamma || !stats || !d_qkv || !dgamma || !dbeta) return GT_EINVAL;
     if (B <= 0 || n <= 0 || h <= 0 || dk <= 0 || p < 0) return GT_EINVAL;
     const int DP = round4(dk + p);
     if ((DP != 20 && DP != 36 && DP != 52) || (p & 1) || (dk & 3)) return GT_ENOTSUP;
     if ((reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vp) | reinterpret_cast<uintptr_t>(dQp) |
-         reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(d_qkv) | reinterpret_cast<uintptr_t>(stats)) & 15)
+         reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(d_qkv) | reinterpret_cast<uintptr_t>(stats)) & 15)   // dQp may be 0
         return GT_EALIGN;
     if (!ws || ws_bytes < gt_galerkin_dkv_ln_ws_bytes(B, h, dk)) return GT_EWS;
     hipStream_t st = (hipStream_t)stream;
@@ -1316,10 +1316,12 @@ extern "C" int gt_galerkin_dkv_ln(const float* Kp, const float* Vp, const float*
     else if (DP == 36) hipLaunchKernelGGL(galerkin_dkv_ln_kernel<2>, grid, dim3(256), 0, st, q);
     else hipLaunchKernelGGL(galerkin_dkv_ln_kernel<3>, grid, dim3(256), 0, st, q);
     GT_LAUNCH_CHECK();
-    const int64_t total4 = (int64_t)B * n * h * (dk >> 2);
-    hipLaunchKernelGGL(headtile_unpad_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, dQp, d_qkv, total4,
-                       h, dk, p, DP);
-    GT_LAUNCH_CHECK();
+    if (dQp) {                                     // NULL: the caller's dQ product wrote the Q block itself
+        const int64_t total4 = (int64_t)B * n * h * (dk >> 2);
+        hipLaunchKernelGGL(headtile_unpad_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, dQp, d_qkv,
+                           total4, h, dk, p, DP);
+        GT_LAUNCH_CHECK();
+    }
     int rc = gt_slab_reduce(partial, 4 * hd, B, 2 * hd, 1.f, dgamma, stream);
     if (rc) return rc;
     return gt_slab_reduce(partial + 2 * hd, 4 * hd, B, 2 * hd, 1.f, dbeta, stream);

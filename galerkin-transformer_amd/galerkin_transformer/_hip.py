@@ -798,19 +798,21 @@ def galerkin_dkv_ln_supported(dk: int, p: int, norm_mask: int) -> bool:
     return norm_mask == 0b110 and p % 2 == 0 and dk % 4 == 0 and round4(dk + p) in FOURIER_DP
 
 
-def galerkin_dkv_ln(Kp, Vp, dM, dQp, qkv, gamma, stats, B: int, n: int, h: int, dk: int, p: int):
+def galerkin_dkv_ln(Kp, Vp, dM, dQp, qkv, gamma, stats, B: int, n: int, h: int, dk: int, p: int, d_qkv=None):
     """dK' = V' dM^T, dV' = K' dM with the per-head LayerNorm backward applied on the way out, plus the Q block: returns
-    (d_qkv [B*n, 3 h dk], dgamma, dbeta [2, h, dk]) -- what galerkin_dkv + headnorm_bwd return, in one streaming pass."""
-    need_f32_cuda(Kp, Vp, dM, dQp, qkv, gamma, stats)
+    (d_qkv [B*n, 3 h dk], dgamma, dbeta [2, h, dk]) -- what galerkin_dkv + headnorm_bwd return, in one streaming pass.
+    dQp=None with a caller-provided d_qkv: the Q block is already in place (written by the caller's dQ product)."""
+    need_f32_cuda(Kp, Vp, dM, dQp, qkv, gamma, stats, d_qkv)
     dev = qkv.device
     T = B * n
-    d_qkv = torch.empty(T, 3 * h * dk, dtype=torch.float32, device=dev)
+    if d_qkv is None:
+        d_qkv = torch.empty(T, 3 * h * dk, dtype=torch.float32, device=dev)
     dgamma = torch.empty(2, h, dk, dtype=torch.float32, device=dev)
     dbeta = torch.empty(2, h, dk, dtype=torch.float32, device=dev)
     ws = workspace(dev, lib().gt_galerkin_dkv_ln_ws_bytes(B, h, dk))
     DP = round4(dk + p)
     check(_timed("gt_galerkin_dkv_ln", 4.0 * B * h * n * DP * DP, 4.0 * T * h * (3 * DP + 5 * dk),
-                 lambda: lib().gt_galerkin_dkv_ln(Kp.data_ptr(), Vp.data_ptr(), dM.data_ptr(), dQp.data_ptr(), qkv.data_ptr(),
+                 lambda: lib().gt_galerkin_dkv_ln(Kp.data_ptr(), Vp.data_ptr(), dM.data_ptr(), ptr(dQp), qkv.data_ptr(),
                                                   gamma.data_ptr(), stats.data_ptr(), B, n, h, dk, p, d_qkv.data_ptr(),
                                                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   stream_ptr()), shape=(B, n, h, DP)), "gt_galerkin_dkv_ln")

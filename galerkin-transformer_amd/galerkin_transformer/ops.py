@@ -681,7 +681,8 @@ class SimpleAttentionFn(Function):
         if p_out > 0:                                        # mask once, not in every consumer's operand loader
             g = H.dropout_apply(g, H.dropout_desc(p_out, salt + 1, dev))
         d_out = None
-        dO3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
+        fused_ln = False
+        dO3 = None
         dbfc = None
         if kind == "galerkin":
             dbfc = torch.empty(d, dtype=torch.float32, device=dev) if hbf else None
@@ -696,17 +697,28 @@ class SimpleAttentionFn(Function):
                        a_drop_sign=sign, a_drop_ld=d, a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0),
                        a_colsum=dbfc)       # + d(fc bias) = column sums of the masked, signed g
             # dQ'[b] = (sign*g*mask1)[b] P[b]^T
-            H.gemm(g, P, dO3[0], n, hD, d, lda=d, ldb=d, ldc=hD, batch=(B, 1), a_bs=(n * d, 0),
-                   b_bs=(hD * d, 0), c_bs=(n * hD, 0), a_drop=d_out, a_drop_sign=sign, a_drop_ld=d,
-                   a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0))
+            fused_ln = _dkv_ln_fused[0] and H.galerkin_dkv_ln_supported(dk, p, norm_mask)
+            if fused_ln:
+                # only the value columns of dQ' reach d_qkv (the coordinates take no gradient): contract with those rows
+                # of P and write the Q block of d_qkv directly -- one 128-wide tile column instead of h*DP = 144, no
+                # dQ' round trip
+                dqkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
+                Pv = P.view(B, h, DP, d)[:, :, p:p + dk, :].reshape(B, d, d)
+                H.gemm(g, Pv, dqkv, n, d, d, lda=d, ldb=d, ldc=3 * d, batch=(B, 1), a_bs=(n * d, 0),
+                       b_bs=(d * d, 0), c_bs=(n * 3 * d, 0), a_drop=d_out, a_drop_sign=sign, a_drop_ld=d,
+                       a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0))
+            else:
+                dO3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
+                H.gemm(g, P, dO3[0], n, hD, d, lda=d, ldb=d, ldc=hD, batch=(B, 1), a_bs=(n * d, 0),
+                       b_bs=(hD * d, 0), c_bs=(n * hD, 0), a_drop=d_out, a_drop_sign=sign, a_drop_ld=d,
+                       a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0))
             H.join_side(dev)
             dM, dWs = H.galerkin_finalize_bwd(dPt, Mt, mask, d_attn, wf, B, h, DP, Dr, d, n)
             dwfc = torch.empty(d, h * Dr, dtype=torch.float32, device=dev)
             H.slab_reduce(dWs, B, d * h * Dr, d * h * Dr, dwfc)
             # dK' = V' dM^T ; dV' = K' dM          per (b, head)
-            fused_ln = _dkv_ln_fused[0] and H.galerkin_dkv_ln_supported(dk, p, norm_mask)
             if fused_ln:       # ... with the head LayerNorm backward behind them: dK', dV' stay in registers
-                dqkv, dgamma, dbeta = H.galerkin_dkv_ln(Kp, Vp, dM, dO3[0], qkv, gamma, stats, B, n, h, dk, p)
+                dqkv, dgamma, dbeta = H.galerkin_dkv_ln(Kp, Vp, dM, None, qkv, gamma, stats, B, n, h, dk, p, d_qkv=dqkv)
             elif DP in H.FOURIER_DP:                           # one streaming pass (gt_galerkin_dkv)
                 H.galerkin_dkv(Kp, Vp, dM, dO3[1], dO3[2], B, n, h, DP)
             else:
@@ -716,6 +728,7 @@ class SimpleAttentionFn(Function):
                        a_bs=(n * hD, DP), b_bs=(h * DP * DP, DP * DP), c_bs=(n * hD, DP))
         else:
             xc, wq, gamma, wpad, qkv, stats, out3, S, att, mask = ctx.saved_tensors
+            dO3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
             d_attn = H.dropout_desc(p_attn, salt, dev) if (p_attn > 0 and mask is None) else None
             Qp, Kp, Vp = out3[0], out3[1], out3[2]
             scale = 1.0 / math.sqrt(Dr) / n

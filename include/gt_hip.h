@@ -281,7 +281,8 @@ int gt_galerkin_dkv(const float* Kp, const float* Vp, const float* dM, float* dK
 
 /* The same two products with the per-head LayerNorm backward of gt_headnorm_bwd (norm_mask = K and V, layers.py:841-874
  * backwards) applied on the way out: dK', dV' are never written.  Writes all three blocks of d_qkv [B*n][3 h dk] (K, V:
- * LayerNorm backward of the products; Q: dQp [B*n][h][DP] with its coordinate / pad columns dropped) and
+ * LayerNorm backward of the products; Q: dQp [B*n][h][DP] with its coordinate / pad columns dropped -- or, with
+ * dQp = NULL, left to the caller, whose dQ product can write the value columns straight into the Q block) and
  * dgamma / dbeta [2][h][dk] (K then V).  qkv = the raw projection, gamma [2][h][dk], stats [2][B*n][h][2] as
  * gt_headnorm_fwd left them.  DP = round4(dk + p) in {20, 36, 52} and p even, else GT_ENOTSUP (gt_galerkin_dkv +
  * gt_headnorm_bwd do the same in two passes). */
