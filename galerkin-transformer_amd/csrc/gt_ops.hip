@@ -529,9 +529,8 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_kernel(const DkvP p) {
 // The two products of galerkin_dkv_kernel, and on the same registers the per-head LayerNorm backward of
 // headnorm_bwd_v2_kernel for the K and V streams (layers.py:841-874 backwards): the head-tile gradients dK', dV'
 // ([T][h][DP], 2 x 136 MB at B = 128) are never written or read back.  A lane holds four consecutive tile columns
-// 16 mt + 4 kq .. + 3 of token row j, i.e. value columns v = col - p of the head: a row's dk values sit in the four kq
-// lanes of its j, so the two row means are a local sum and two cross-lane adds.  p is even (0 or 2): a float4 of tile
-// columns is two 8-byte aligned pairs of the raw projection / its gradient.  d(gamma), d(beta): per-lane running sums
+// 16 mt + 4 kq .. + 3 of token row j (columns in value order, see the kernel): a row's dk values sit in the four kq
+// lanes of its j, so the two row means are a local sum and two cross-lane adds.  d(gamma), d(beta): per-lane running sums
 // over the block's tokens, folded over the 16 token lanes, then over the four waves in LDS in a fixed order; block
 // (b, head) owns the head's dk-slice of partial[b][dg K | dg V | db K | db V] (the layout gt_headnorm_bwd reduces).
 struct DkvLnP {
@@ -552,11 +551,15 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
     const float* dm = p.dM + ((int64_t)b * p.h + head) * DP * DP;
     const int hd = p.h * p.dk, d3 = 3 * hd;
     const float inv = 1.f / (float)p.dk;
+    // output columns in VALUE order: column c' < dk is value c' (tile column p + c'), the coordinate columns follow, then
+    // the pad -- a permutation of the rows of the dM fragments, so that the lane's four consecutive outputs are an
+    // aligned float4 of the raw projection row and of its gradient
     float a1[NMT][NS], a2[NMT][NS];
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) {
-        const int col = 16 * mt + j, cc = min(col, DP - 1);
-        const float live = col < DP ? 1.f : 0.f;
+        const int cp = 16 * mt + j;
+        const int col = cp < p.dk ? cp + p.p : (cp < p.dk + p.p ? cp - p.dk : cp), cc = min(col, DP - 1);
+        const float live = cp < DP ? 1.f : 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int k = (s < 4 * G) ? 4 * (kq + 4 * (s >> 2)) + (s & 3) : 16 * G + kq;
@@ -564,19 +567,17 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
             a2[mt][s] = live * dm[k * DP + cc];
         }
     }
-    // this lane's value columns: pair A = (v0, v0 + 1), pair B = (v0 + 2, v0 + 3) of tile group mt
-    bool okA[NMT], okB[NMT];
+    bool ok[NMT];                                   // the lane's float4 of group mt holds values (dk % 4 == 0: all or none)
     f32x4 gmK[NMT], gmV[NMT];
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) {
-        const int v0 = 16 * mt + 4 * kq - p.p;
-        okA[mt] = v0 >= 0 && v0 + 1 < p.dk;
-        okB[mt] = v0 + 2 >= 0 && v0 + 3 < p.dk;
+        const int v0 = 16 * mt + 4 * kq;
+        ok[mt] = v0 < p.dk;
         gmK[mt] = gmV[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* gk = p.gamma + (int64_t)head * p.dk + v0;
-        const float* gv = gk + hd;
-        if (okA[mt]) { gmK[mt][0] = gk[0]; gmK[mt][1] = gk[1]; gmV[mt][0] = gv[0]; gmV[mt][1] = gv[1]; }
-        if (okB[mt]) { gmK[mt][2] = gk[2]; gmK[mt][3] = gk[3]; gmV[mt][2] = gv[2]; gmV[mt][3] = gv[3]; }
+        if (ok[mt]) {
+            gmK[mt] = *reinterpret_cast<const f32x4*>(p.gamma + (int64_t)head * p.dk + v0);
+            gmV[mt] = *reinterpret_cast<const f32x4*>(p.gamma + hd + (int64_t)head * p.dk + v0);
+        }
     }
     f32x4 dgK[NMT], dbK[NMT], dgV[NMT], dbV[NMT];
 #pragma unroll
@@ -597,19 +598,15 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
         kk[G] = *reinterpret_cast<const f32x4*>(kr + 16 * G);
         vv[G] = *reinterpret_cast<const f32x4*>(vr + 16 * G);
         // raw projection rows and statistics of this token (requested before the products, used after them)
-        const float* xk = p.qkv + tok * d3 + hd + head * p.dk - p.p + 4 * kq;        // + 16 mt : tile column -> value
+        const float* xk = p.qkv + tok * d3 + hd + head * p.dk + 4 * kq;               // + 16 mt
         const float* xv = xk + hd;
         f32x4 xK[NMT], xV[NMT];
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
             xK[mt] = xV[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (okA[mt]) {
-                const f32x2 a = *reinterpret_cast<const f32x2*>(xk + 16 * mt), c = *reinterpret_cast<const f32x2*>(xv + 16 * mt);
-                xK[mt][0] = a[0]; xK[mt][1] = a[1]; xV[mt][0] = c[0]; xV[mt][1] = c[1];
-            }
-            if (okB[mt]) {
-                const f32x2 a = *reinterpret_cast<const f32x2*>(xk + 16 * mt + 2), c = *reinterpret_cast<const f32x2*>(xv + 16 * mt + 2);
-                xK[mt][2] = a[0]; xK[mt][3] = a[1]; xV[mt][2] = c[0]; xV[mt][3] = c[1];
+            if (ok[mt]) {
+                xK[mt] = *reinterpret_cast<const f32x4*>(xk + 16 * mt);
+                xV[mt] = *reinterpret_cast<const f32x4*>(xv + 16 * mt);
             }
         }
         const f32x2 stK = *reinterpret_cast<const f32x2*>(p.stats + (tok * p.h + head) * 2);
@@ -643,9 +640,8 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
             for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const bool ok = c < 2 ? okA[mt] : okB[mt];
-                    xh[mt][c] = ok ? (x[mt][c] - mu) * rstd : 0.f;
-                    gg[mt][c] = ok ? gy[mt][c] * gm[mt][c] : 0.f;
+                    xh[mt][c] = ok[mt] ? (x[mt][c] - mu) * rstd : 0.f;
+                    gg[mt][c] = ok[mt] ? gy[mt][c] * gm[mt][c] : 0.f;
                     s1 += gg[mt][c];
                     s2 += gg[mt][c] * xh[mt][c];
                 }
@@ -655,18 +651,18 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
             if (!live) return;
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) {
+                if (!ok[mt]) continue;
                 f32x4 dx;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const bool ok = c < 2 ? okA[mt] : okB[mt];
                     dx[c] = rstd * (gg[mt][c] - m1 - xh[mt][c] * m2);
-                    if (ok) { dg[mt][c] += gy[mt][c] * xh[mt][c]; db[mt][c] += gy[mt][c]; }
+                    dg[mt][c] += gy[mt][c] * xh[mt][c];
+                    db[mt][c] += gy[mt][c];
                 }
-                if (okA[mt]) *reinterpret_cast<f32x2*>(dst + 16 * mt) = f32x2{dx[0], dx[1]};
-                if (okB[mt]) *reinterpret_cast<f32x2*>(dst + 16 * mt + 2) = f32x2{dx[2], dx[3]};
+                *reinterpret_cast<f32x4*>(dst + 16 * mt) = dx;
             }
         };
-        float* dk_row = p.d_qkv + tok * d3 + hd + head * p.dk - p.p + 4 * kq;
+        float* dk_row = p.d_qkv + tok * d3 + hd + head * p.dk + 4 * kq;
         ln_bwd(acc1, xK, gmK, stK, dgK, dbK, dk_row);
         ln_bwd(acc2, xV, gmV, stV, dgV, dbV, dk_row + hd);
     }
@@ -687,8 +683,8 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
     float* pg = p.partial + (int64_t)b * 4 * hd + (int64_t)head * p.dk;
     for (int e = threadIdx.x; e < 4 * NMT * 4 * 4; e += blockDim.x) {
         const int q = e & 3, c = (e >> 2) & 3, mt = (e >> 4) % NMT, kq2 = e / (16 * NMT);
-        const int v = 16 * mt + 4 * kq2 + c - p.p;
-        if (v < 0 || v >= p.dk) continue;
+        const int v = 16 * mt + 4 * kq2 + c;
+        if (v >= p.dk) continue;
         const float sum = ((red[0][kq2][mt][c][q] + red[1][kq2][mt][c][q]) + red[2][kq2][mt][c][q]) + red[3][kq2][mt][c][q];
         // q: 0 dg K, 1 db K, 2 dg V, 3 db V   ->  partial row [dg K | dg V | db K | db V], each h*dk wide
         pg[((q & 1) * 2 + (q >> 1)) * hd + v] = sum;
@@ -1302,9 +1298,10 @@ extern "C" int gt_galerkin_dkv_ln(const float* Kp, const float* Vp, const float*
     if (!Kp || !Vp || !dM || !qkv || !gamma || !stats || !d_qkv || !dgamma || !dbeta) return GT_EINVAL;
     if (B <= 0 || n <= 0 || h <= 0 || dk <= 0 || p < 0) return GT_EINVAL;
     const int DP = round4(dk + p);
-    if ((DP != 20 && DP != 36 && DP != 52) || (p & 1) || (dk & 3)) return GT_ENOTSUP;
+    if ((DP != 20 && DP != 36 && DP != 52) || (dk & 3)) return GT_ENOTSUP;
     if ((reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vp) | reinterpret_cast<uintptr_t>(dQp) |
-         reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(d_qkv) | reinterpret_cast<uintptr_t>(stats)) & 15)   // dQp may be 0
+         reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(d_qkv) | reinterpret_cast<uintptr_t>(stats) |
+         reinterpret_cast<uintptr_t>(gamma)) & 15)                                      // dQp may be 0
         return GT_EALIGN;
     if (!ws || ws_bytes < gt_galerkin_dkv_ln_ws_bytes(B, h, dk)) return GT_EWS;
     hipStream_t st = (hipStream_t)stream;

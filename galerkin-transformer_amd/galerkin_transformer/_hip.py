@@ -794,8 +794,8 @@ def galerkin_dkv(Kp, Vp, dM, dKp, dVp, B: int, n: int, h: int, DP: int):
 
 
 def galerkin_dkv_ln_supported(dk: int, p: int, norm_mask: int) -> bool:
-    """Shapes of gt_galerkin_dkv_ln: K and V normalised, even coordinate count, head tile of 20 / 36 / 52 floats."""
-    return norm_mask == 0b110 and p % 2 == 0 and dk % 4 == 0 and round4(dk + p) in FOURIER_DP
+    """Shapes of gt_galerkin_dkv_ln: K and V normalised, head tile of 20 / 36 / 52 floats."""
+    return norm_mask == 0b110 and dk % 4 == 0 and round4(dk + p) in FOURIER_DP
 
 
 def galerkin_dkv_ln(Kp, Vp, dM, dQp, qkv, gamma, stats, B: int, n: int, h: int, dk: int, p: int, d_qkv=None):

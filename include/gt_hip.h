@@ -284,7 +284,7 @@ int gt_galerkin_dkv(const float* Kp, const float* Vp, const float* dM, float* dK
  * LayerNorm backward of the products; Q: dQp [B*n][h][DP] with its coordinate / pad columns dropped -- or, with
  * dQp = NULL, left to the caller, whose dQ product can write the value columns straight into the Q block) and
  * dgamma / dbeta [2][h][dk] (K then V).  qkv = the raw projection, gamma [2][h][dk], stats [2][B*n][h][2] as
- * gt_headnorm_fwd left them.  DP = round4(dk + p) in {20, 36, 52} and p even, else GT_ENOTSUP (gt_galerkin_dkv +
+ * gt_headnorm_fwd left them.  DP = round4(dk + p) in {20, 36, 52} and dk % 4 == 0, else GT_ENOTSUP (gt_galerkin_dkv +
  * gt_headnorm_bwd do the same in two passes). */
 int64_t gt_galerkin_dkv_ln_ws_bytes(int32_t B, int32_t h, int32_t dk);
 int gt_galerkin_dkv_ln(const float* Kp, const float* Vp, const float* dM, const float* dQp, const float* qkv,

@@ -1055,7 +1055,7 @@ def test_gemm_x3_packed_b_epilogue_and_a_dropout(H, gpu_device):
 
 
 @pytest.mark.parametrize("B,n,h,dk,p", [(2, 100, 4, 32, 2), (1, 37, 2, 16, 2), (3, 1849, 4, 32, 2), (1, 64, 1, 48, 2),
-                                        (2, 50, 4, 36, 0)])
+                                        (2, 50, 4, 36, 0), (2, 300, 2, 32, 1), (1, 90, 4, 16, 3)])
 def test_galerkin_dkv_ln_fused_equals_two_passes(H, gpu_device, B, n, h, dk, p):
     """gt_galerkin_dkv_ln (dK', dV' products + head LayerNorm backward + Q un-padding in one pass) ==
     gt_galerkin_dkv followed by gt_headnorm_bwd with norm_mask = K, V (layers.py:841-874 and :723 backwards)."""
@@ -1080,6 +1080,5 @@ def test_galerkin_dkv_ln_fused_equals_two_passes(H, gpu_device, B, n, h, dk, p):
 
 
 def test_galerkin_dkv_ln_unsupported_shapes(H, gpu_device):
-    assert not H.galerkin_dkv_ln_supported(32, 1, 0b110)       # odd coordinate count: 4-byte aligned value columns
     assert not H.galerkin_dkv_ln_supported(32, 2, 0b011)       # fourier-type norms (Q, K)
     assert not H.galerkin_dkv_ln_supported(64, 2, 0b110)       # head tile of 68 floats
