@@ -409,6 +409,7 @@ def roofline_leg(trainer, precision):
                             ("headnorm_bwd", "gt_headnorm_bwd", "gt::headnorm_bwd_v2_kernel"),
                             ("galerkin_ktv", "gt_galerkin_ktv", "gt::galerkin_ktv_kernel<2>"),
                             ("galerkin_dkv", "gt_galerkin_dkv", "gt::galerkin_dkv_kernel<2>"),
+                            ("galerkin_dkv+headnorm_bwd", "gt_galerkin_dkv_ln", "gt::galerkin_dkv_ln_kernel<2>"),
                             ("token_gemms(packed B)", "gemm_x3p_kernel<0, 0, 0>", "gt::gemm_x3p_kernel<0, 0, 0>"),
                             ("conv3x3_implicit", "gemm_x3p_kernel<0, 0, 1>", "gt::gemm_x3p_kernel<0, 0, 1>"),
                             ("conv3x3_wgrad", "gemm_x3r_kernel<1, 1, 3, 3, 0, 2>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 2>"),

@@ -11,13 +11,13 @@ export TMPDIR=/tmp
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 if has tests; then ( time timeout 900 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log; fi
 if has bench; then ( time timeout 900 python bench.py --table $O/table.json ) > $O/bench.log 2> $O/bench.err; tail -1 $O/bench.log | cut -c1-600; fi
-if has prof; then
+if has prof; then   # one stream (GT_DUAL_STREAM=0): per-kernel averages of kernels that do not overlap
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o trace --output-format csv -- \
+  GT_DUAL_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o trace --output-format csv -- \
       python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-f32-leg --no-accuracy > $O/prof.log 2>&1
   cd $R
   MS=$(grep '^{"metric' $O/prof.log | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step']*10)")
-  python tools/prof_csv_summary.py $O/prof 70 --last-ms $MS > $O/kernel_stats_steady.txt 2>&1
+  python tools/prof_csv_summary.py $O/prof 70 --last-ms $MS --by-grid > $O/kernel_stats_steady.txt 2>&1
   python tools/prof_csv_summary.py $O/prof 40 > $O/kernel_stats.txt 2>&1
   rm -rf $O/prof
   head -30 $O/kernel_stats_steady.txt | cut -c1-150
