@@ -982,13 +982,13 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
 }
 
 // ---- packed-B path: host side ---------------------------------------------------------------------------------------
-// B small next to A (a weight against >= 2048 token rows), three planes, one launch (no batching, split-K, second
+// B small next to A (a weight against >= 16384 token rows), three planes, one launch (no batching, split-K, second
 // product or row-sum by-product), operands the direct loads can take.  GT_X3_PACKED=0 switches it off (A/B runs).
 bool x3_packed_ok(const gt_gemm_desc* d, int planes, int split) {
     static const int on = [] { const char* e = getenv("GT_X3_PACKED"); return e ? atoi(e) : 1; }();
     if (!on || planes != 3 || split != 1 || d->batch0 * d->batch1 != 1 || d->K2 > 0 || d->a_colsum) return false;
     if (d->cv_c > 0 && d->cv_wgrad) return false;
-    if (d->M < 2048 || d->M < 8 * (int64_t)d->N) return false;
+    if (d->M < 16384 || d->M < 8 * (int64_t)d->N) return false;       // below that the extra (pack) launch is not paid back
     const bool a16 = (reinterpret_cast<uintptr_t>(d->A) & 15) == 0;
     if (d->cv_c > 0) return a16 && d->layout_a == 0 && (d->cv_c & 15) == 0;
     if (!a16 || (d->lda & 3)) return false;

@@ -310,7 +310,7 @@ class Conv3x3NhwcFn(Function):
             # dx[pix][ci] = sum_tap sum_co gy[pix - shift(tap)][co] W[co][ci][tap]: tap' = 8 - tap has the opposite shift
             wd = _conv_k_order(weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9, Cout))     # [Cin][tap'][Cout]
             dx = torch.empty(B, Hh, Ww, Cin, dtype=torch.float32, device=g.device)
-            with H.side_branch(dev):    # the data gradient next to the weight gradient below
+            with H.side_branch(dev, B * Hh * Ww):        # the data gradient next to the weight gradient below
                 H.gemm(g, wd, dx, B * Hh * Ww, Cin, 9 * Cout, lda=Cout, ldb=9 * Cout, ldc=Cin, conv=(Hh, Ww, Cout))
         if ctx.needs_input_grad[1]:
             # dw[co][ci][tap] = sum_pix gy[pix][co] x[pix + shift(tap)][ci]
@@ -396,7 +396,7 @@ class LinearFn(Function):
             dw = torch.empty(N, K + pe, dtype=torch.float32, device=dev)
             if want_db:         # the bias gradient rides on the weight-gradient GEMM (row sums of its A)
                 db = torch.empty(N, dtype=torch.float32, device=dev)
-            with H.side_branch(dev):
+            with H.side_branch(dev, T):
                 H.gemm(gp, x2, dw, N, K, T, layout_a=1, layout_b=1, lda=N, ldb=K, ldc=K + pe, split_k=0,
                        a_colsum=db)
                 if pe:
@@ -552,7 +552,7 @@ class FeedForwardFn(Function):
         # the side stream next to the data-gradient GEMMs (H.side_branch)
         dw2 = torch.empty(dout, f, dtype=torch.float32, device=dev)
         db2 = torch.empty(dout, dtype=torch.float32, device=dev) if hb2 else None
-        with H.side_branch(dev):
+        with H.side_branch(dev, T):
             H.gemm(gm, hid, dw2, dout, f, T, layout_a=1, layout_b=1, lda=dout, ldb=f, ldc=f, split_k=0,
                    a_colsum=db2)
         if act == H.ACT_RELU:
@@ -565,7 +565,7 @@ class FeedForwardFn(Function):
         dw1 = torch.empty(f, d, dtype=torch.float32, device=dev)
         db1 = torch.empty(f, dtype=torch.float32, device=dev) if hb1 else None
         dx = torch.empty(T, d, dtype=torch.float32, device=dev)
-        with H.side_branch(dev):
+        with H.side_branch(dev, T):
             H.gemm(gh, xc, dw1, f, d, T, layout_a=1, layout_b=1, lda=f, ldb=d, ldc=d, split_k=0, a_colsum=db1)
         same = has_res and dout == d
         H.gemm(gh, w1c, dx, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=g if same else None, ldr=d)
@@ -691,7 +691,7 @@ class SimpleAttentionFn(Function):
             Qp, Kp, Vp = out3[0], out3[1], out3[2]
             # dP^T[b] = (sign*g*mask1)^T[b] Q'[b]        [B, d, h*DP]
             dPt = torch.empty(B, d, hD, dtype=torch.float32, device=dev)
-            with H.side_branch(dev):    # the token-contracted product next to the token-row product below
+            with H.side_branch(dev, T): # the token-contracted product next to the token-row product below
                 H.gemm(g, Qp, dPt, d, hD, n, layout_a=1, layout_b=1, lda=d, ldb=hD, ldc=hD, batch=(B, 1),
                        a_bs=(n * d, 0), b_bs=(n * hD, 0), c_bs=(d * hD, 0), split_k=0, a_drop=d_out,
                        a_drop_sign=sign, a_drop_ld=d, a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0),
@@ -764,7 +764,7 @@ class SimpleAttentionFn(Function):
         dwqkv = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
         dbqkv = torch.empty(3 * d, dtype=torch.float32, device=dev) if hbq else None
         dx = torch.empty(T, d, dtype=torch.float32, device=dev)
-        with H.side_branch(dev):        # weight gradient next to the data gradient
+        with H.side_branch(dev, T):     # weight gradient next to the data gradient
             H.gemm(dqkv, xc, dwqkv, 3 * d, d, T, layout_a=1, layout_b=1, lda=3 * d, ldb=d, ldc=d, split_k=0,
                    a_colsum=dbqkv)
         H.gemm(dqkv, wq, dx, T, d, 3 * d, layout_b=1, lda=3 * d, ldb=d, ldc=d, res=g_in if has_res else None,

@@ -1016,19 +1016,20 @@ def test_upscaler_channels_last_path_equals_channels_first(H, gpu_device):
 
 
 @pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(4096 + 40, 128, 128), (2052, 200, 16), (5000, 96, 40), (3000, 256, 1152),
-                                   (2048, 136, 20), (2050, 128, 18)])
+@pytest.mark.parametrize("M,N,K", [(16384 + 40, 128, 128), (16400, 200, 16), (20000, 96, 40), (16384, 256, 1152),
+                                   (16384, 136, 20), (16386, 128, 18), (4096, 128, 128)])
 def test_gemm_x3_packed_b(H, gpu_device, la, lb, M, N, K):
     """gemm_x3p_kernel: B split once into fragment-ordered bf16 planes (x3_pack_b_kernel), read straight into the MFMA
-    operand registers; A through the ring.  Token-row shapes (M >= 2048, M >= 8 N) in every layout, ragged M / N / K
-    (partial pixel tiles, a partial last k-stage, N that does not fill its 128-column tile), 1, 2 and many k-stages."""
+    operand registers; A through the ring.  Token-row shapes (M >= 16384, M >= 8 N) in every layout, ragged M / N / K
+    (partial pixel tiles, a partial last k-stage, N that does not fill its 128-column tile), 1, 2 and many k-stages; below
+    16384 rows the pack launch is not paid back and the ring kernel splits B per block."""
     dev = gpu_device
     A = rnd(M, K, dev=dev, seed=301) if la == 0 else rnd(K, M, dev=dev, seed=301)
     B = rnd(N, K, dev=dev, seed=302) if lb == 0 else rnd(K, N, dev=dev, seed=302)
     name = H.gemm_kernel_name(A, B, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1], ldb=B.shape[1], ldc=N,
                               precision="bf16x3")
     aligned = (K % 4 == 0) if la == 0 else (M % 4 == 0)
-    assert ("gemm_x3p_kernel" in name) == aligned, name
+    assert ("gemm_x3p_kernel" in name) == (aligned and M >= 16384), name
     Cc = torch.full((M, N), float("nan"), device=dev)
     H.gemm(A, B, Cc, M, N, K, layout_a=la, layout_b=lb, lda=A.shape[1], ldb=B.shape[1], ldc=N, precision="bf16x3")
     torch.cuda.synchronize()
@@ -1039,7 +1040,7 @@ def test_gemm_x3_packed_b_epilogue_and_a_dropout(H, gpu_device):
     """The packed-B kernel with the fused epilogue (bias, SiLU, residual, pre-activation output) and the A-operand
     dropout prologue == the fp32 MFMA kernel on the same masks."""
     dev = gpu_device
-    M, N, K = 4100, 128, 256
+    M, N, K = 16500, 128, 256
     A, B = rnd(M, K, dev=dev, seed=310), rnd(N, K, dev=dev, seed=311, scale=0.1)
     bias, res = rnd(N, dev=dev, seed=312), rnd(M, N, dev=dev, seed=313)
     H.set_seed(99, dev)
