@@ -179,6 +179,7 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
     const int DP = p.hn_DP, W = NSEG * DP, sw = W + 4, W4 = W >> 2;
     const int stream = nwave / (p.hn_h * DK), head0 = (nwave / DK) % p.hn_h;
     const bool normed = (p.hn_mask >> stream) & 1;
+    const bool store_raw = !((p.hn_skip_raw >> stream) & 1);   // the raw projection of this stream goes to C
     const int ni = __popc(p.hn_mask & ((1 << stream) - 1));
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -196,7 +197,7 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
                 const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nwave + c + 4 * lh) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[q][t] = p.alpha * acc[i][j][4 * g + t] + bv[t];
-                if (row_ok)
+                if (row_ok && store_raw)
                     *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + nwave + c + 4 * lh) = f32x4{v[q][0], v[q][1], v[q][2], v[q][3]};
             }
             float mu = 0.f, rstd = 1.f;

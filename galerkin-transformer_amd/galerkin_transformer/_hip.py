@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 11          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 12          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -62,6 +62,7 @@ class GtGemmDesc(C.Structure):
         ("hn_norm_mask", C.c_int32), ("hn_eps", C.c_float),
         ("precision", C.c_int32),
         ("cv_h", C.c_int32), ("cv_w", C.c_int32), ("cv_c", C.c_int32), ("cv_wgrad", C.c_int32),
+        ("hn_skip_raw_mask", C.c_int32),
     ]
 
 
@@ -483,6 +484,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         d.hn_gamma, d.hn_beta, d.hn_pos = ptr(hn.get("gamma")), ptr(hn.get("beta")), ptr(hn.get("pos"))
         d.hn_out, d.hn_stats = hn["out"].data_ptr(), ptr(hn.get("stats"))
         d.hn_h, d.hn_dk, d.hn_p, d.hn_norm_mask, d.hn_eps = hn["h"], hn["dk"], hn["p"], hn["norm_mask"], hn["eps"]
+        d.hn_skip_raw_mask = hn.get("skip_raw", 0)
     if conv is not None:
         d.cv_h, d.cv_w, d.cv_c = conv
         d.cv_wgrad = int(conv_wgrad)

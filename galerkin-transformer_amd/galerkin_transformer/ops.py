@@ -613,9 +613,10 @@ class SimpleAttentionFn(Function):
             out3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
             stats = torch.empty(2, T, h, 2, dtype=torch.float32, device=dev)
             try:
+                # the raw projection is kept for the LayerNorm backward only: the normalised streams' blocks of qkv
                 H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv,
                        hn=dict(gamma=gamma, beta=beta, pos=posc, out=out3, stats=stats, h=h, dk=dk, p=p,
-                               norm_mask=norm_mask, eps=eps))
+                               norm_mask=norm_mask, eps=eps, skip_raw=(~norm_mask) & 7))
             except H.GtNotSupported:                          # shapes / alignment the fused kernel does not take
                 out3 = None
         if out3 is None:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 11
+#define GT_ABI_VERSION 12
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -195,6 +195,11 @@ typedef struct gt_gemm_desc {
      * (c_bs0 = the tap stride), split_k = 0 (the library cuts K into chunks; the nine taps of a chunk run next to each
      * other on one XCD and share its L2).  cv_w >= 16, no epilogue fields. */
     int32_t cv_h, cv_w, cv_c, cv_wgrad;
+
+    /* GT_EP_HEADNORM: streams (bit 0 Q, 1 K, 2 V) whose RAW projection is NOT written to C.  The backward needs the raw
+     * rows of the normalised streams only (LayerNorm backward); a training forward passes ~hn_norm_mask & 7 and saves
+     * a third of C's write traffic.  Zero (the default) writes all of C. */
+    int32_t hn_skip_raw_mask;
 } gt_gemm_desc;
 
 #define GT_PREC_F32    0

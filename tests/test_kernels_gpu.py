@@ -902,6 +902,19 @@ def test_qkv_headnorm_fused_epilogue(H, gpu_device, T, h, dk, p, mask):
     torch.cuda.synchronize()
     assert torch.equal(qkv2, qkv)
     assert not torch.isnan(out3).any()
+    # skip_raw: the raw projection of the un-normalised streams is not written (it has no reader in training)
+    qkv3 = torch.full_like(qkv, float("nan"))
+    out3b = torch.empty_like(out3)
+    H.gemm(x, w, qkv3, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, hn=dict(hn, out=out3b, skip_raw=(~mask) & 7),
+           precision="bf16x3")
+    torch.cuda.synchronize()
+    for st in range(3):
+        blk = qkv3[:, st * d:(st + 1) * d]
+        if (mask >> st) & 1:
+            assert torch.equal(blk, qkv[:, st * d:(st + 1) * d])
+        else:
+            assert torch.isnan(blk).all()
+    assert torch.equal(out3b, out3)
     assert rel_l2(out3, out_ref) < 1e-6
     nn = bin(mask).count("1")
     if nn:
