@@ -219,3 +219,48 @@ def test_device_resident_loader_cpu():
     full = torch.stack([ds[i]["target"] for i in range(10)])
     for row in e1:
         assert (full == row).flatten(1).all(1).sum() == 1
+
+
+@pytest.mark.parametrize("Cin,Cout", [(32, 8), (48, 16), (64, 5)])
+def test_implicit_conv_contraction_order_cpu(Cin, Cout):
+    """The k order the implicit-GEMM convolution kernel walks (include/gt_hip.h, cv_*: channel block -> tap -> channel,
+    CB = 32 when C % 32 == 0 else 16) and ops._conv_k_order's filter arrangement describe the same contraction: an
+    im2col matrix built in that order times the arranged filter is F.conv2d(padding=1); the data-gradient arrangement
+    (taps reversed, channel roles swapped) gives conv2d's input gradient."""
+    import torch
+    import torch.nn.functional as F
+    from galerkin_transformer import ops
+    torch.manual_seed(0)
+    B, Hh, Ww = 2, 5, 7
+    x = torch.randn(B, Hh, Ww, Cin, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 3, 3, dtype=torch.float64)
+
+    def im2col(img):                                   # [B,H,W,C] -> [B*H*W, 9*C] in the kernel's k order
+        C_ = img.shape[-1]
+        cb = 32 if C_ % 32 == 0 else 16
+        pad = F.pad(img, (0, 0, 1, 1, 1, 1))
+        cols = []
+        for blk in range(C_ // cb):
+            for tap in range(9):
+                dy, dx = tap // 3, tap % 3             # pixel + (dy - 1, dx - 1) in the unpadded image
+                cols.append(pad[:, dy:dy + Hh, dx:dx + Ww, blk * cb:(blk + 1) * cb])
+        return torch.cat(cols, -1).reshape(B * Hh * Ww, 9 * C_)
+
+    wf = ops._conv_k_order(w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin))
+    y = (im2col(x) @ wf.t()).reshape(B, Hh, Ww, Cout)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = F.conv2d(xr, w, padding=1)
+    assert torch.allclose(y.permute(0, 3, 1, 2), ref, atol=1e-12)
+    if Cout % 16 == 0:                                 # the data gradient contracts over (tap, Cout): cv_c = Cout
+        gy = torch.randn(B, Hh, Ww, Cout, dtype=torch.float64)
+        (gx,) = torch.autograd.grad(ref, xr, gy.permute(0, 3, 1, 2))
+        wd = ops._conv_k_order(w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9, Cout))
+        dx = (im2col(gy) @ wd.t()).reshape(B, Hh, Ww, Cin)
+        assert torch.allclose(dx.permute(0, 3, 1, 2), gx, atol=1e-12)
+
+
+def test_fused_backward_and_packing_eligibility_cpu():
+    from galerkin_transformer import _hip
+    assert _hip.galerkin_dkv_ln_supported(32, 2, 0b110) and _hip.galerkin_dkv_ln_supported(16, 1, 0b110)
+    assert not _hip.galerkin_dkv_ln_supported(32, 2, 0b011) and not _hip.galerkin_dkv_ln_supported(64, 2, 0b110)
+    assert not _hip.galerkin_dkv_ln_supported(30, 2, 0b110)
