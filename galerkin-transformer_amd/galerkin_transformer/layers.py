@@ -11,7 +11,6 @@ import copy
 import math
 
 import numpy as np
-import os
 
 import torch
 import torch.nn.functional as F
