@@ -646,7 +646,16 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
     return 0;
 }
 
+static bool width_split(const gt_gemm_desc* d, gt_gemm_desc* a, gt_gemm_desc* b);
+static int64_t ws_bytes_one(const gt_gemm_desc* d);
+
 extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
+    gt_gemm_desc a, b;
+    if (d && width_split(d, &a, &b)) return std::max(ws_bytes_one(&a), ws_bytes_one(&b));
+    return ws_bytes_one(d);
+}
+
+static int64_t ws_bytes_one(const gt_gemm_desc* d) {
     Plan pl;
     if (d && !getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return tsmm_ws_bytes(d);
     if (make_plan(d, &pl)) return 0;
@@ -871,36 +880,47 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     return 0;
 }
 
+// Splits d into the 128-aligned column range `a` and the remainder `b` when that pays (see gt_gemm); false otherwise.
+static bool width_split(const gt_gemm_desc* d, gt_gemm_desc* a, gt_gemm_desc* b) {
+    const int rem = d->N % 128;
+    Plan pl;
+    if (!(d->N > 128 && rem != 0 && rem <= 64 && d->ep_mode == GT_EP_NORMAL && d->cv_c == 0 && make_plan(d, &pl) == 0 &&
+          pl.bn == 128))
+        return false;
+    // only when the aligned part alone fills the chip: two half-empty launches would serialise instead.  One launch
+    // per tile (split == 1): >= 512 tiles (measured);  K-split products (token-contracted, no epilogue): the K
+    // slices of the aligned part fill it
+    const int64_t main_tiles = (int64_t)pl.tiles_m * (d->N / 128) * d->batch0 * d->batch1;
+    if (pl.split == 1 ? main_tiles < 512 : (main_tiles * pl.split < 256 || d->K2 > 0)) return false;
+    const int n_main = d->N - rem;
+    *a = *d;
+    *b = *d;
+    a->N = n_main;
+    b->N = rem;
+    b->B = d->B + (d->layout_b == 0 ? (int64_t)n_main * d->ldb : (int64_t)n_main);
+    b->C = d->C + n_main;
+    if (d->K2 > 0) b->B2 = d->B2 + (d->layout_b == 0 ? (int64_t)n_main * d->ldb2 : (int64_t)n_main);
+    if (d->bias) b->bias = d->bias + n_main;
+    if (d->rp) b->rp_b = d->rp_b + (int64_t)n_main * d->rp_ldb;
+    if (d->add) b->add = d->add + n_main;
+    if (d->pre) b->pre = d->pre + n_main;
+    if (d->aux) b->aux = d->aux + n_main;
+    if (d->res) b->res = d->res + n_main;
+    if (pl.split == 1) a->split_k = b->split_k = 1;      // else: each part plans its own K slices (split_k as given)
+    b->a_colsum = nullptr;                               // the row sums of A ride on the first launch only
+    return true;
+}
+
 // Widths just above a multiple of 128 (the merged-head width h*(d_k+p) = 144 of the Darcy model) would
 // waste most of a second 128-wide tile column: run the aligned part and the remainder as two launches,
 // the remainder on a narrow-tile configuration.
 extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream) {
     if (!d) return GT_EINVAL;
-    const int rem = d->N % 128;
-    Plan pl;
-    // only when the aligned part alone fills the chip: two half-empty launches would serialise instead
-    if (d->N > 128 && rem != 0 && rem <= 64 && d->ep_mode == GT_EP_NORMAL && d->cv_c == 0 && make_plan(d, &pl) == 0 &&
-        pl.split == 1 &&
-        pl.bn == 128 &&
-        (int64_t)pl.tiles_m * (d->N / 128) * d->batch0 * d->batch1 >= 512) {
-        const int n_main = d->N - rem;
-        gt_gemm_desc a = *d, b = *d;
-        a.N = n_main;
-        b.N = rem;
-        b.B = d->B + (d->layout_b == 0 ? (int64_t)n_main * d->ldb : (int64_t)n_main);
-        b.C = d->C + n_main;
-        if (d->K2 > 0) b.B2 = d->B2 + (d->layout_b == 0 ? (int64_t)n_main * d->ldb2 : (int64_t)n_main);
-        if (d->bias) b.bias = d->bias + n_main;
-        if (d->rp) b.rp_b = d->rp_b + (int64_t)n_main * d->rp_ldb;
-        if (d->add) b.add = d->add + n_main;
-        if (d->pre) b.pre = d->pre + n_main;
-        if (d->aux) b.aux = d->aux + n_main;
-        if (d->res) b.res = d->res + n_main;
-        a.split_k = b.split_k = 1;
-        b.a_colsum = nullptr;
+    gt_gemm_desc a, b;
+    if (width_split(d, &a, &b)) {
         int rc = gemm_one(&a, d->N, 0, ws, ws_bytes, stream);
         if (rc) return rc;
-        return gemm_one(&b, d->N, n_main, ws, ws_bytes, stream);
+        return gemm_one(&b, d->N, a.N, ws, ws_bytes, stream);      // same stream: the scratch is free again
     }
     return gemm_one(d, d->N, 0, ws, ws_bytes, stream);
 }

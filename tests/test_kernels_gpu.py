@@ -1096,3 +1096,22 @@ def test_galerkin_dkv_ln_fused_equals_two_passes(H, gpu_device, B, n, h, dk, p):
 def test_galerkin_dkv_ln_unsupported_shapes(H, gpu_device):
     assert not H.galerkin_dkv_ln_supported(32, 2, 0b011)       # fourier-type norms (Q, K)
     assert not H.galerkin_dkv_ln_supported(64, 2, 0b110)       # head tile of 68 floats
+
+
+@pytest.mark.parametrize("batch", [16, 3])
+def test_gemm_x3_split_k_width_split(H, gpu_device, batch):
+    """Token-contracted product with N = 144 (the merged-head width of the Darcy model), K slices, batched, with the
+    row-sum by-product: with enough K slices to fill the chip the library runs the aligned 128 columns on the
+    split-operand kernel and the 16-column remainder on a narrow fp32 tile (two launches, gt_gemm: width_split);
+    batch 3 stays one launch.  Both against fp64."""
+    dev = gpu_device
+    M, N, K = 128, 144, 1849
+    A = rnd(batch, K, M, dev=dev, seed=500)
+    B = rnd(batch, K, N, dev=dev, seed=501)
+    Cc = torch.full((batch, M, N), float("nan"), device=dev)
+    cs = torch.full((M,), float("nan"), device=dev)
+    H.gemm(A, B, Cc, M, N, K, layout_a=1, layout_b=1, lda=M, ldb=N, ldc=N, batch=(batch, 1), a_bs=(K * M, 0),
+           b_bs=(K * N, 0), c_bs=(M * N, 0), split_k=0, a_colsum=cs, precision="bf16x3")
+    torch.cuda.synchronize()
+    assert rel_l2(Cc, A.double().transpose(1, 2) @ B.double()) < KTOL
+    assert rel_l2(cs, A.double().sum((0, 1))) < KTOL
