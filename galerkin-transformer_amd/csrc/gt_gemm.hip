@@ -670,7 +670,8 @@ static int64_t ws_bytes_one(const gt_gemm_desc* d) {
 // full width is drop_ld (d already points at that column range).
 static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int64_t ws_bytes, void* stream) {
     if (!d || !d->A || !d->B) return GT_EINVAL;
-    if (!d->C && d->ep_mode != GT_EP_ROWDOT) return GT_EINVAL;
+    if (!d->C && d->ep_mode != GT_EP_ROWDOT && !(d->ep_mode == GT_EP_HEADNORM && (d->hn_skip_raw_mask & 7) == 7))
+        return GT_EINVAL;
     if (d->ep_mode == GT_EP_HEADNORM) {
         if (d->layout_a || d->layout_b || d->batch0 * d->batch1 != 1 || d->K2 > 0 || d->split_k > 1) return GT_ENOTSUP;
         if (d->hn_h <= 0 || d->hn_p < 0 || d->N != 3 * d->hn_h * d->hn_dk || (d->hn_norm_mask & ~7)) return GT_EINVAL;
@@ -754,7 +755,7 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
         p.hn_gamma = d->hn_gamma; p.hn_beta = d->hn_beta; p.hn_pos = d->hn_pos; p.hn_out = d->hn_out;
         p.hn_stats = d->hn_stats; p.hn_h = d->hn_h; p.hn_dk = d->hn_dk; p.hn_p = d->hn_p;
         p.hn_DP = (d->hn_dk + d->hn_p + 3) & ~3; p.hn_mask = d->hn_norm_mask; p.hn_eps = d->hn_eps;
-        p.hn_skip_raw = d->hn_skip_raw_mask & 7;
+        p.hn_skip_raw = d->hn_skip_raw_mask & 7; p.hn_plain = d->hn_plain != 0;
     } else if (d->ep_mode != GT_EP_NORMAL) {
         if (pl.tiles_n != 1 || pl.split != 1) return GT_ENOTSUP;
         p.ep_mode = d->ep_mode; p.n_out = d->n_out; p.w2 = d->w2; p.ldw2 = d->ldw2; p.b2 = d->b2;

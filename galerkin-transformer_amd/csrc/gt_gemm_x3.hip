@@ -224,7 +224,7 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
                     const f32x4 gm = *reinterpret_cast<const f32x4*>(p.hn_gamma + (ni * p.hn_h + head) * DK + dim);
                     const f32x4 bt = *reinterpret_cast<const f32x4*>(p.hn_beta + (ni * p.hn_h + head) * DK + dim);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) y[t] = (y[t] - mu) * rstd * gm[t] + bt[t];
+                    for (int t = 0; t < 4; ++t) y[t] = p.hn_plain ? (y[t] - mu) * rstd : (y[t] - mu) * rstd * gm[t] + bt[t];
                 }
                 float* dst = seg + p.hn_p + dim;
 #pragma unroll

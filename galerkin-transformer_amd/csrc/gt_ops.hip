@@ -538,11 +538,17 @@ struct DkvLnP {
     const float* qkv; const float* gamma; const float* stats;
     float* d_qkv; float* partial;
     int n, h, dk, p, T;
+    const float* beta;                              // PLAIN only
 };
-template <int G>
+// PLAIN: the head tiles hold the normalised values WITHOUT the LayerNorm affine (gt_hip.h: hn_plain): K' = gamma_K xh + beta_K
+// is never formed -- gamma scales the rows of the dM fragments (the contraction index is the tile column), beta dM is a
+// per-output-column constant added to the products, and xh for the LayerNorm backward is the tile itself: the raw
+// projection is neither stored by the forward nor read here.
+template <int G, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p) {
     constexpr int DP = 16 * G + 4, NS = 4 * G + 1, NMT = G + 1;
     __shared__ float red[4][4][NMT][4][4];          // [wave][kq][mt][c][dgK, dbK, dgV, dbV]
+    __shared__ __attribute__((aligned(16))) float cst[2][4][NMT][4];    // PLAIN: [dK' | dV'][kq][mt][c] = (beta dM) of the lane's columns
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
     const int head = blockIdx.x % p.h, b = blockIdx.x / p.h;
@@ -563,9 +569,30 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int k = (s < 4 * G) ? 4 * (kq + 4 * (s >> 2)) + (s & 3) : 16 * G + kq;
-            a1[mt][s] = live * dm[cc * DP + k];
-            a2[mt][s] = live * dm[k * DP + cc];
+            float sv = 1.f, sk = 1.f;               // PLAIN: the operand rows carry xh; its gamma moves onto dM
+            if (PLAIN && k >= p.p && k < p.p + p.dk) {
+                sv = p.gamma[hd + (int64_t)head * p.dk + k - p.p];
+                sk = p.gamma[(int64_t)head * p.dk + k - p.p];
+            }
+            a1[mt][s] = live * sv * dm[cc * DP + k];
+            a2[mt][s] = live * sk * dm[k * DP + cc];
         }
+    }
+    if (PLAIN) {                                     // beta dM of every output column, once per block
+        for (int e = threadIdx.x; e < 2 * 4 * NMT * 4; e += blockDim.x) {
+            const int c = e & 3, mt = (e >> 2) % NMT, kq2 = (e / (4 * NMT)) & 3, which = e / (16 * NMT);
+            const int cp = 16 * mt + 4 * kq2 + c;
+            const int col = cp < p.dk ? cp + p.p : (cp < p.dk + p.p ? cp - p.dk : cp);
+            float acc = 0.f;
+            if (cp < DP)
+                for (int v = 0; v < p.dk; ++v) {
+                    const int k = p.p + v;
+                    acc += which == 0 ? p.beta[hd + (int64_t)head * p.dk + v] * dm[col * DP + k]      // dK' = V' dM^T
+                                      : p.beta[(int64_t)head * p.dk + v] * dm[k * DP + col];           // dV' = K' dM
+                }
+            cst[which][kq2][mt][c] = acc;
+        }
+        __syncthreads();
     }
     bool ok[NMT];                                   // the lane's float4 of group mt holds values (dk % 4 == 0: all or none)
     f32x4 gmK[NMT], gmV[NMT];
@@ -597,16 +624,17 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
         }
         kk[G] = *reinterpret_cast<const f32x4*>(kr + 16 * G);
         vv[G] = *reinterpret_cast<const f32x4*>(vr + 16 * G);
-        // raw projection rows and statistics of this token (requested before the products, used after them)
-        const float* xk = p.qkv + tok * d3 + hd + head * p.dk + 4 * kq;               // + 16 mt
-        const float* xv = xk + hd;
+        // raw projection rows (PLAIN: the normalised values themselves, in value order, out of the tile rows just
+        // requested -- cache-hot) and statistics of this token: requested before the products, used after them
+        const float* xk = PLAIN ? kr + p.p + 4 * kq : p.qkv + tok * d3 + hd + head * p.dk + 4 * kq;       // + 16 mt
+        const float* xv = PLAIN ? vr + p.p + 4 * kq : xk + hd;
         f32x4 xK[NMT], xV[NMT];
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
             xK[mt] = xV[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ok[mt]) {
-                xK[mt] = *reinterpret_cast<const f32x4*>(xk + 16 * mt);
-                xV[mt] = *reinterpret_cast<const f32x4*>(xv + 16 * mt);
+                xK[mt] = PLAIN ? tile_load4(xk + 16 * mt, p.p) : *reinterpret_cast<const f32x4*>(xk + 16 * mt);
+                xV[mt] = PLAIN ? tile_load4(xv + 16 * mt, p.p) : *reinterpret_cast<const f32x4*>(xv + 16 * mt);
             }
         }
         const f32x2 stK = *reinterpret_cast<const f32x2*>(p.stats + (tok * p.h + head) * 2);
@@ -614,7 +642,13 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
 
         f32x4 acc1[NMT], acc2[NMT];
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) acc1[mt] = acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < NMT; ++mt) {
+            acc1[mt] = acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (PLAIN) {
+                acc1[mt] = *reinterpret_cast<const f32x4*>(&cst[0][kq][mt][0]);
+                acc2[mt] = *reinterpret_cast<const f32x4*>(&cst[1][kq][mt][0]);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             float bv, bk;
@@ -630,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
             }
         }
         const bool live = t < p.n;
-        // LayerNorm backward of one stream on the lane's columns: gy = d(normalised head row), x = raw row
+        // LayerNorm backward of one stream on the lane's columns: gy = d(normalised head row), x = raw row (PLAIN: xh)
         auto ln_bwd = [&](const f32x4 (&gy)[NMT], const f32x4 (&x)[NMT], const f32x4 (&gm)[NMT], f32x2 st,
                           f32x4 (&dg)[NMT], f32x4 (&db)[NMT], float* __restrict__ dst) {
             const float mu = st[0], rstd = st[1];
@@ -640,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p)
             for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    xh[mt][c] = ok[mt] ? (x[mt][c] - mu) * rstd : 0.f;
+                    xh[mt][c] = ok[mt] ? (PLAIN ? x[mt][c] : (x[mt][c] - mu) * rstd) : 0.f;
                     gg[mt][c] = ok[mt] ? gy[mt][c] * gm[mt][c] : 0.f;
                     s1 += gg[mt][c];
                     s2 += gg[mt][c] * xh[mt][c];
@@ -739,7 +773,8 @@ static bool head_geom(int T, int h, int dk, int p, int norm_mask, int max_blocks
 template <int NB>
 __global__ __launch_bounds__(256) void galerkin_ktv_kernel(const float* __restrict__ Kp, const float* __restrict__ Vp,
                                                            int n, int h, int DP, int p, int chunk,
-                                                           float* __restrict__ slabs, int B) {
+                                                           float* __restrict__ slabs, int B,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int b = blockIdx.y, ch = blockIdx.x;
@@ -757,6 +792,18 @@ __global__ __launch_bounds__(256) void galerkin_ktv_kernel(const float* __restri
         pp[0][0] = pp[0][1] = pp[1][0] = pp[1][1] = 0.f;
         const float* kb = Kp + ((int64_t)b * n) * hD + (int64_t)head * DP;
         const float* vb = Vp + ((int64_t)b * n) * hD + (int64_t)head * DP;
+        // "plain" head tiles (gt_hip.h: hn_plain) hold the normalised values without the LayerNorm affine: K' = gamma_K xh +
+        // beta_K is formed as the operand is loaded (gamma, beta [2][h][16 NB]: K then V); NULL = tiles hold K', V'
+        float gk[NB], bk[NB], gv[NB], bv[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            gk[c] = gv[c] = 1.f;
+            bk[c] = bv[c] = 0.f;
+            if (gamma) {
+                const int o = head * 16 * NB + 16 * c + i, hd = h * 16 * NB;
+                gk[c] = gamma[o]; bk[c] = beta[o]; gv[c] = gamma[hd + o]; bv[c] = beta[hd + o];
+            }
+        }
         for (int tb = t_lo; tb < t_hi; tb += 16) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {                       // 4 independent 4-token steps in flight
@@ -768,8 +815,8 @@ __global__ __launch_bounds__(256) void galerkin_ktv_kernel(const float* __restri
             float a[NB], v[NB], pk[2] = {0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                a[c] = ok ? kr[p + 16 * c + i] : 0.f;
-                v[c] = ok ? vr[p + 16 * c + i] : 0.f;
+                a[c] = ok ? fmaf(kr[p + 16 * c + i], gk[c], bk[c]) : 0.f;
+                v[c] = ok ? fmaf(vr[p + 16 * c + i], gv[c], bv[c]) : 0.f;
             }
             if (p > 0) pk[0] = ok ? kr[0] : 0.f;
             if (p > 1) pk[1] = ok ? kr[1] : 0.f;
@@ -1295,7 +1342,17 @@ extern "C" int gt_galerkin_dkv_ln(const float* Kp, const float* Vp, const float*
                                   const float* gamma, const float* stats, int32_t B, int32_t n, int32_t h, int32_t dk,
                                   int32_t p, float* d_qkv, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
                                   void* stream) {
-    if (!Kp || !Vp || !dM || !qkv || !gamma || !stats || !d_qkv || !dgamma || !dbeta) return GT_EINVAL;
+    if (!qkv) return GT_EINVAL;
+    return gt_galerkin_dkv_ln_plain(Kp, Vp, dM, dQp, qkv, gamma, nullptr, stats, B, n, h, dk, p, d_qkv, dgamma, dbeta, ws,
+                                    ws_bytes, stream);
+}
+
+// beta != NULL: "plain" head tiles (gt_hip.h: hn_plain), qkv unused (may be NULL)
+extern "C" int gt_galerkin_dkv_ln_plain(const float* Kp, const float* Vp, const float* dM, const float* dQp,
+                                        const float* qkv, const float* gamma, const float* beta, const float* stats,
+                                        int32_t B, int32_t n, int32_t h, int32_t dk, int32_t p, float* d_qkv,
+                                        float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, void* stream) {
+    if (!Kp || !Vp || !dM || (!qkv && !beta) || !gamma || !stats || !d_qkv || !dgamma || !dbeta) return GT_EINVAL;
     if (B <= 0 || n <= 0 || h <= 0 || dk <= 0 || p < 0) return GT_EINVAL;
     const int DP = round4(dk + p);
     if ((DP != 20 && DP != 36 && DP != 52) || (dk & 3)) return GT_ENOTSUP;
@@ -1307,11 +1364,17 @@ extern "C" int gt_galerkin_dkv_ln(const float* Kp, const float* Vp, const float*
     hipStream_t st = (hipStream_t)stream;
     const int hd = h * dk;
     float* partial = reinterpret_cast<float*>(ws);
-    DkvLnP q{Kp, Vp, dM, qkv, gamma, stats, d_qkv, partial, n, h, dk, p, B * n};
+    DkvLnP q{Kp, Vp, dM, qkv, gamma, stats, d_qkv, partial, n, h, dk, p, B * n, beta};
     dim3 grid((unsigned)(B * h));
-    if (DP == 20) hipLaunchKernelGGL(galerkin_dkv_ln_kernel<1>, grid, dim3(256), 0, st, q);
-    else if (DP == 36) hipLaunchKernelGGL(galerkin_dkv_ln_kernel<2>, grid, dim3(256), 0, st, q);
-    else hipLaunchKernelGGL(galerkin_dkv_ln_kernel<3>, grid, dim3(256), 0, st, q);
+    if (beta) {
+        if (DP == 20) hipLaunchKernelGGL((galerkin_dkv_ln_kernel<1, true>), grid, dim3(256), 0, st, q);
+        else if (DP == 36) hipLaunchKernelGGL((galerkin_dkv_ln_kernel<2, true>), grid, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((galerkin_dkv_ln_kernel<3, true>), grid, dim3(256), 0, st, q);
+    } else {
+        if (DP == 20) hipLaunchKernelGGL((galerkin_dkv_ln_kernel<1, false>), grid, dim3(256), 0, st, q);
+        else if (DP == 36) hipLaunchKernelGGL((galerkin_dkv_ln_kernel<2, false>), grid, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((galerkin_dkv_ln_kernel<3, false>), grid, dim3(256), 0, st, q);
+    }
     GT_LAUNCH_CHECK();
     if (dQp) {                                     // NULL: the caller's dQ product wrote the Q block itself
         const int64_t total4 = (int64_t)B * n * h * (dk >> 2);
@@ -1452,7 +1515,14 @@ extern "C" int32_t gt_galerkin_ktv_slabs(int32_t B, int32_t n) {
 
 extern "C" int gt_galerkin_ktv(const float* Kp, const float* Vp, int32_t B, int32_t n, int32_t h, int32_t dk,
                                int32_t p, float* slabs, int32_t n_slabs, void* stream) {
+    return gt_galerkin_ktv_affine(Kp, Vp, nullptr, nullptr, B, n, h, dk, p, slabs, n_slabs, stream);
+}
+
+extern "C" int gt_galerkin_ktv_affine(const float* Kp, const float* Vp, const float* gamma, const float* beta, int32_t B,
+                                      int32_t n, int32_t h, int32_t dk, int32_t p, float* slabs, int32_t n_slabs,
+                                      void* stream) {
     if (!Kp || !Vp || !slabs || B <= 0 || n <= 0 || h <= 0 || dk <= 0 || p < 0 || n_slabs <= 0) return GT_EINVAL;
+    if ((gamma == nullptr) != (beta == nullptr)) return GT_EINVAL;
     if ((dk & 15) || dk > 96 || p > 2) return GT_ENOTSUP;
     if (B > 65535) return GT_EINVAL;
     const int DP = round4(dk + p);
@@ -1461,11 +1531,11 @@ extern "C" int gt_galerkin_ktv(const float* Kp, const float* Vp, int32_t B, int3
     dim3 grid((unsigned)n_slabs, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     switch (dk / 16) {
-        case 1: hipLaunchKernelGGL(galerkin_ktv_kernel<1>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B); break;
-        case 2: hipLaunchKernelGGL(galerkin_ktv_kernel<2>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B); break;
-        case 3: hipLaunchKernelGGL(galerkin_ktv_kernel<3>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B); break;
-        case 4: hipLaunchKernelGGL(galerkin_ktv_kernel<4>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B); break;
-        case 6: hipLaunchKernelGGL(galerkin_ktv_kernel<6>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B); break;
+        case 1: hipLaunchKernelGGL(galerkin_ktv_kernel<1>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B, gamma, beta); break;
+        case 2: hipLaunchKernelGGL(galerkin_ktv_kernel<2>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B, gamma, beta); break;
+        case 3: hipLaunchKernelGGL(galerkin_ktv_kernel<3>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B, gamma, beta); break;
+        case 4: hipLaunchKernelGGL(galerkin_ktv_kernel<4>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B, gamma, beta); break;
+        case 6: hipLaunchKernelGGL(galerkin_ktv_kernel<6>, grid, dim3(256), 0, st, Kp, Vp, n, h, DP, p, chunk, slabs, B, gamma, beta); break;
         default: return GT_ENOTSUP;
     }
     GT_LAUNCH_CHECK();

@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 12          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 13          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -62,7 +62,7 @@ class GtGemmDesc(C.Structure):
         ("hn_norm_mask", C.c_int32), ("hn_eps", C.c_float),
         ("precision", C.c_int32),
         ("cv_h", C.c_int32), ("cv_w", C.c_int32), ("cv_c", C.c_int32), ("cv_wgrad", C.c_int32),
-        ("hn_skip_raw_mask", C.c_int32),
+        ("hn_skip_raw_mask", C.c_int32), ("hn_plain", C.c_int32),
     ]
 
 
@@ -91,8 +91,10 @@ _PROTOS = {
     "gt_headnorm_bwd_ws_bytes": (C.c_int64, [C.c_int32] * 3),
     "gt_galerkin_ktv_slabs": (C.c_int32, [C.c_int32, C.c_int32]),
     "gt_galerkin_ktv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
+    "gt_galerkin_ktv_affine": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
     "gt_galerkin_dkv": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
     "gt_galerkin_dkv_ln_ws_bytes": (C.c_int64, [C.c_int32] * 3),
+    "gt_galerkin_dkv_ln_plain": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 5 + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p]),
     "gt_galerkin_dkv_ln": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p]),
     "gt_fourier_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.POINTER(GtDropout),
                                                                 C.c_int32, C.c_void_p]),
@@ -434,7 +436,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics).  precision=None uses the module mode
     (set_precision).  conv=(H, W, C): A is a channels-last [B, H, W, C] image and the product is the implicit 3x3
     convolution (K = 9*C; gt_hip.h: cv_*); with conv_wgrad, B is that image and the nine batch entries are the taps of the
-    weight gradient."""
+    weight gradient.  Cout may be None for a GT_EP_HEADNORM launch that stores no raw projection (hn["skip_raw"] == 7)."""
     need_f32_cuda(A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, a_colsum)
     L = lib()
     d = GtGemmDesc()
@@ -485,6 +487,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         d.hn_out, d.hn_stats = hn["out"].data_ptr(), ptr(hn.get("stats"))
         d.hn_h, d.hn_dk, d.hn_p, d.hn_norm_mask, d.hn_eps = hn["h"], hn["dk"], hn["p"], hn["norm_mask"], hn["eps"]
         d.hn_skip_raw_mask = hn.get("skip_raw", 0)
+        d.hn_plain = int(bool(hn.get("plain", False)))
     if conv is not None:
         d.cv_h, d.cv_w, d.cv_c = conv
         d.cv_wgrad = int(conv_wgrad)
@@ -775,18 +778,24 @@ def conv3x3_resize_bwd(g: torch.Tensor, y: torch.Tensor, x: torch.Tensor, w: tor
     return dw
 
 
-def galerkin_ktv(Kp: torch.Tensor, Vp: torch.Tensor, B: int, n: int, h: int, dk: int, p: int):
+def galerkin_ktv_supported(dk: int, p: int) -> bool:
+    return not (dk % 16 or dk > 96 or dk // 16 == 5 or p > 2)
+
+
+def galerkin_ktv(Kp: torch.Tensor, Vp: torch.Tensor, B: int, n: int, h: int, dk: int, p: int, gamma=None, beta=None):
     """K'^T V' partial slabs [n_slabs, B, h, DP, DP] from head tiles [B*n, h, DP]; None if the streaming kernel
-    does not cover this head size (caller falls back to the batched GEMM)."""
-    need_f32_cuda(Kp, Vp)
-    if dk % 16 or dk > 96 or dk // 16 == 5 or p > 2:
+    does not cover this head size (caller falls back to the batched GEMM).  gamma, beta [2, h, dk]: the tiles are
+    "plain" (normalised values without the LayerNorm affine, gt_hip.h: hn_plain) and the affine is applied on load."""
+    need_f32_cuda(Kp, Vp, gamma, beta)
+    if not galerkin_ktv_supported(dk, p):
         return None
     DP = round4(dk + p)
     ns = lib().gt_galerkin_ktv_slabs(B, n)
     slabs = torch.empty(ns, B, h, DP, DP, dtype=torch.float32, device=Kp.device)
     check(_timed("gt_galerkin_ktv", 2.0 * B * h * n * DP * DP, 8.0 * B * n * h * DP,
-                 lambda: lib().gt_galerkin_ktv(Kp.data_ptr(), Vp.data_ptr(), B, n, h, dk, p, slabs.data_ptr(), ns,
-                                               stream_ptr()), shape=(B, n, h, dk, p)), "gt_galerkin_ktv")
+                 lambda: lib().gt_galerkin_ktv_affine(Kp.data_ptr(), Vp.data_ptr(), ptr(gamma), ptr(beta), B, n, h, dk, p,
+                                                      slabs.data_ptr(), ns, stream_ptr()),
+                 shape=(B, n, h, dk, p)), "gt_galerkin_ktv")
     return slabs
 
 
@@ -806,12 +815,13 @@ def galerkin_dkv_ln_supported(dk: int, p: int, norm_mask: int) -> bool:
     return norm_mask == 0b110 and dk % 4 == 0 and round4(dk + p) in FOURIER_DP
 
 
-def galerkin_dkv_ln(Kp, Vp, dM, dQp, qkv, gamma, stats, B: int, n: int, h: int, dk: int, p: int, d_qkv=None):
+def galerkin_dkv_ln(Kp, Vp, dM, dQp, qkv, gamma, stats, B: int, n: int, h: int, dk: int, p: int, d_qkv=None, beta=None):
     """dK' = V' dM^T, dV' = K' dM with the per-head LayerNorm backward applied on the way out, plus the Q block: returns
     (d_qkv [B*n, 3 h dk], dgamma, dbeta [2, h, dk]) -- what galerkin_dkv + headnorm_bwd return, in one streaming pass.
-    dQp=None with a caller-provided d_qkv: the Q block is already in place (written by the caller's dQ product)."""
-    need_f32_cuda(Kp, Vp, dM, dQp, qkv, gamma, stats, d_qkv)
-    dev = qkv.device
+    dQp=None with a caller-provided d_qkv: the Q block is already in place (written by the caller's dQ product).
+    beta given: "plain" head tiles (the normalised values without the affine); qkv is then unused and may be None."""
+    need_f32_cuda(Kp, Vp, dM, dQp, qkv, gamma, stats, d_qkv, beta)
+    dev = Kp.device
     T = B * n
     if d_qkv is None:
         d_qkv = torch.empty(T, 3 * h * dk, dtype=torch.float32, device=dev)
@@ -820,8 +830,8 @@ def galerkin_dkv_ln(Kp, Vp, dM, dQp, qkv, gamma, stats, B: int, n: int, h: int, 
     ws = workspace(dev, lib().gt_galerkin_dkv_ln_ws_bytes(B, h, dk))
     DP = round4(dk + p)
     check(_timed("gt_galerkin_dkv_ln", 4.0 * B * h * n * DP * DP, 4.0 * T * h * (3 * DP + 5 * dk),
-                 lambda: lib().gt_galerkin_dkv_ln(Kp.data_ptr(), Vp.data_ptr(), dM.data_ptr(), ptr(dQp), qkv.data_ptr(),
-                                                  gamma.data_ptr(), stats.data_ptr(), B, n, h, dk, p, d_qkv.data_ptr(),
+                 lambda: lib().gt_galerkin_dkv_ln_plain(Kp.data_ptr(), Vp.data_ptr(), dM.data_ptr(), ptr(dQp), ptr(qkv),
+                                                  gamma.data_ptr(), ptr(beta), stats.data_ptr(), B, n, h, dk, p, d_qkv.data_ptr(),
                                                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   stream_ptr()), shape=(B, n, h, DP)), "gt_galerkin_dkv_ln")
     return d_qkv, dgamma, dbeta

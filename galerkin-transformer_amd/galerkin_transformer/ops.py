@@ -257,6 +257,7 @@ def conv3x3_nhwc_ok(conv: torch.nn.Conv2d) -> bool:
             and _conv_implicit[0])
 
 
+_plain_tiles = [os.environ.get("GT_PLAIN_TILES", "1") != "0"]          # K', V' head tiles without the LayerNorm affine
 _dkv_ln_fused = [os.environ.get("GT_DKV_LN", "1") != "0"]               # gt_galerkin_dkv_ln vs gt_galerkin_dkv + gt_headnorm_bwd
 _conv_implicit = [os.environ.get("GT_CONV_IMPLICIT", "1") != "0"]        # A/B switches (tools / tests)
 # weight gradient of the implicit convolution: "hip" (default) = the nine-tap pixel contraction on the ring kernel,
@@ -606,20 +607,28 @@ class SimpleAttentionFn(Function):
         posc = None if pos is None else _c(pos).reshape(T, p)
         wq, wf = _c(wqkv), _c(wfc)
         salt = _next_salt(4)
-        qkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
-        out3 = stats = None
+        qkv = out3 = stats = None
+        # "plain" head tiles: when every consumer of K', V' is one of the fused Galerkin kernels, the tiles keep the
+        # normalised values WITHOUT the LayerNorm affine (the consumers apply gamma / beta), the backward takes xh from the
+        # tiles, and the raw projection has no reader left: it is neither written nor allocated (gt_hip.h: hn_plain)
+        plain = (_plain_tiles[0] and kind == "galerkin" and _dkv_ln_fused[0] and H.galerkin_dkv_ln_supported(dk, p, norm_mask)
+                 and H.galerkin_ktv_supported(dk, p))
         if _qkvnorm_fused[0] and dk in (16, 32, 64) and bqkv is not None and H.get_precision() == "bf16x3":
             # head norm on the projection's epilogue (GT_EP_HEADNORM): one pass less over [T, 3d], one launch less
             out3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
             stats = torch.empty(2, T, h, 2, dtype=torch.float32, device=dev)
+            if not plain:
+                qkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
             try:
                 # the raw projection is kept for the LayerNorm backward only: the normalised streams' blocks of qkv
                 H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv,
                        hn=dict(gamma=gamma, beta=beta, pos=posc, out=out3, stats=stats, h=h, dk=dk, p=p,
-                               norm_mask=norm_mask, eps=eps, skip_raw=(~norm_mask) & 7))
+                               norm_mask=norm_mask, eps=eps, skip_raw=7 if plain else (~norm_mask) & 7, plain=plain))
             except H.GtNotSupported:                          # shapes / alignment the fused kernel does not take
                 out3 = None
         if out3 is None:
+            plain = False
+            qkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
             H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
             out3, stats = H.headnorm_fwd(qkv, posc, gamma, beta, T, h, dk, p, norm_mask, eps)
         Qp, Kp, Vp = out3[0], out3[1], out3[2]
@@ -629,7 +638,8 @@ class SimpleAttentionFn(Function):
         d_attn = H.dropout_desc(p_attn, salt, dev) if (p_attn > 0 and mask is None) else None
         d_out = H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None
         if kind == "galerkin":
-            slabs = H.galerkin_ktv(Kp, Vp, B, n, h, dk, p)          # streaming MFMA kernel, token chunks
+            slabs = H.galerkin_ktv(Kp, Vp, B, n, h, dk, p, gamma=gamma if plain else None,
+                                   beta=beta if plain else None)   # streaming MFMA kernel, token chunks
             if slabs is None:                                       # head sizes it does not cover
                 slabs = torch.empty(1, B, h, DP, DP, dtype=torch.float32, device=dev)
                 H.gemm(Kp, Vp, slabs, DP, DP, n, layout_a=1, layout_b=1, lda=hD, ldb=hD, ldc=DP, batch=(B, h),
@@ -639,7 +649,8 @@ class SimpleAttentionFn(Function):
             H.gemm(Qp, P, out, n, d, hD, layout_b=1, lda=hD, ldb=d, ldc=d, batch=(B, 1), a_bs=(n * hD, 0),
                    b_bs=(hD * d, 0), c_bs=(n * d, 0), bias=bfc, drop=d_out, res=rc, ldr=d, r_bs=(n * d, 0),
                    out_scale=sign)
-            ctx.save_for_backward(xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask)
+            ctx.save_for_backward(xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask, beta if plain else None)
+            ctx.plain = plain
             attn_w = Mt[:, :, :Dr, :Dr]
         else:
             scale = 1.0 / math.sqrt(Dr) / n
@@ -687,7 +698,7 @@ class SimpleAttentionFn(Function):
         dbfc = None
         if kind == "galerkin":
             dbfc = torch.empty(d, dtype=torch.float32, device=dev) if hbf else None
-            xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask = ctx.saved_tensors
+            xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask, beta_plain = ctx.saved_tensors
             d_attn = H.dropout_desc(p_attn, salt, dev) if (p_attn > 0 and mask is None) else None
             Qp, Kp, Vp = out3[0], out3[1], out3[2]
             # dP^T[b] = (sign*g*mask1)^T[b] Q'[b]        [B, d, h*DP]
@@ -698,7 +709,7 @@ class SimpleAttentionFn(Function):
                        a_drop_sign=sign, a_drop_ld=d, a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0),
                        a_colsum=dbfc)       # + d(fc bias) = column sums of the masked, signed g
             # dQ'[b] = (sign*g*mask1)[b] P[b]^T
-            fused_ln = _dkv_ln_fused[0] and H.galerkin_dkv_ln_supported(dk, p, norm_mask)
+            fused_ln = ctx.plain or (_dkv_ln_fused[0] and H.galerkin_dkv_ln_supported(dk, p, norm_mask))
             if fused_ln:
                 # only the value columns of dQ' reach d_qkv (the coordinates take no gradient): contract with those rows
                 # of P and write the Q block of d_qkv directly -- one 128-wide tile column instead of h*DP = 144, no
@@ -719,7 +730,8 @@ class SimpleAttentionFn(Function):
             H.slab_reduce(dWs, B, d * h * Dr, d * h * Dr, dwfc)
             # dK' = V' dM^T ; dV' = K' dM          per (b, head)
             if fused_ln:       # ... with the head LayerNorm backward behind them: dK', dV' stay in registers
-                dqkv, dgamma, dbeta = H.galerkin_dkv_ln(Kp, Vp, dM, None, qkv, gamma, stats, B, n, h, dk, p, d_qkv=dqkv)
+                dqkv, dgamma, dbeta = H.galerkin_dkv_ln(Kp, Vp, dM, None, qkv, gamma, stats, B, n, h, dk, p, d_qkv=dqkv,
+                                                        beta=beta_plain)
             elif DP in H.FOURIER_DP:                           # one streaming pass (gt_galerkin_dkv)
                 H.galerkin_dkv(Kp, Vp, dM, dO3[1], dO3[2], B, n, h, DP)
             else:

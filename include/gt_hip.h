@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 12
+#define GT_ABI_VERSION 13
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -200,6 +200,12 @@ typedef struct gt_gemm_desc {
      * rows of the normalised streams only (LayerNorm backward); a training forward passes ~hn_norm_mask & 7 and saves
      * a third of C's write traffic.  Zero (the default) writes all of C. */
     int32_t hn_skip_raw_mask;
+
+    /* GT_EP_HEADNORM, hn_plain != 0: the head tiles of the normalised streams hold the normalised values WITHOUT the
+     * LayerNorm affine (xh = (x - mean) * rstd); gamma and beta are applied by the consumers (gt_galerkin_ktv_affine
+     * on load, gt_galerkin_dkv_ln_plain folded into dM), whose LayerNorm backward then needs no raw projection at all:
+     * with hn_skip_raw_mask = 7 the launch writes nothing to C and C may be NULL. */
+    int32_t hn_plain;
 } gt_gemm_desc;
 
 #define GT_PREC_F32    0
@@ -269,6 +275,10 @@ int64_t gt_headnorm_bwd_ws_bytes(int32_t T, int32_t h, int32_t dk);
 int32_t gt_galerkin_ktv_slabs(int32_t B, int32_t n);
 int gt_galerkin_ktv(const float* Kp, const float* Vp, int32_t B, int32_t n, int32_t h, int32_t dk, int32_t p,
                     float* slabs, int32_t n_slabs, void* stream);
+/* The same for "plain" head tiles (gt_gemm_desc.hn_plain): K' = gamma_K xh + beta_K, V' likewise, formed while the
+ * operands are loaded; gamma, beta [2][h][dk] (K then V).  NULL gamma / beta = gt_galerkin_ktv. */
+int gt_galerkin_ktv_affine(const float* Kp, const float* Vp, const float* gamma, const float* beta, int32_t B, int32_t n,
+                           int32_t h, int32_t dk, int32_t p, float* slabs, int32_t n_slabs, void* stream);
 int gt_galerkin_finalize_fwd(const float* slabs, int32_t n_slabs, int64_t slab_stride,
                              int32_t B, int32_t h, int32_t DP, int32_t Dr, int32_t d, int32_t n_tokens,
                              const float* mask, const gt_dropout* drop, const float* Wfc,
@@ -295,6 +305,12 @@ int64_t gt_galerkin_dkv_ln_ws_bytes(int32_t B, int32_t h, int32_t dk);
 int gt_galerkin_dkv_ln(const float* Kp, const float* Vp, const float* dM, const float* dQp, const float* qkv,
                        const float* gamma, const float* stats, int32_t B, int32_t n, int32_t h, int32_t dk, int32_t p,
                        float* d_qkv, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, void* stream);
+/* The same on "plain" head tiles: beta [2][h][dk] given, qkv unused (may be NULL); gamma moves onto the rows of dM, beta dM
+ * is added to the products, the tiles themselves are the xh of the LayerNorm backward. */
+int gt_galerkin_dkv_ln_plain(const float* Kp, const float* Vp, const float* dM, const float* dQp, const float* qkv,
+                             const float* gamma, const float* beta, const float* stats, int32_t B, int32_t n, int32_t h,
+                             int32_t dk, int32_t p, float* d_qkv, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused Fourier-type attention (layers.py:672-705):  out = ((Q' K'^T) * scale .* mask) V'  on the head-tile

@@ -1115,3 +1115,80 @@ def test_gemm_x3_split_k_width_split(H, gpu_device, batch):
     torch.cuda.synchronize()
     assert rel_l2(Cc, A.double().transpose(1, 2) @ B.double()) < KTOL
     assert rel_l2(cs, A.double().sum((0, 1))) < KTOL
+
+
+def _plain_case(H, dev, B, n, h, dk, p, seed):
+    """Raw K / V projections with their LayerNorm statistics, the affine head tiles K', V' and the "plain" tiles (xh)."""
+    T, DP = B * n, H.round4(dk + p)
+    d = h * dk
+    qkv = rnd(T, 3 * d, dev=dev, seed=seed)
+    gamma = 1 + 0.3 * rnd(2, h, dk, dev=dev, seed=seed + 1)
+    beta = 0.2 * rnd(2, h, dk, dev=dev, seed=seed + 2)
+    pos = rnd(T, p, dev=dev, seed=seed + 3) if p else None
+    eps = 1e-6
+    tiles, plains, stats = [], [], []
+    for st in (1, 2):
+        x = qkv[:, st * d:(st + 1) * d].reshape(T, h, dk).double()
+        mu = x.mean(-1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + eps)
+        xh = (x - mu) * rstd
+        y = xh * gamma[st - 1].double() + beta[st - 1].double()
+        for src, dst in ((y, tiles), (xh, plains)):
+            tile = torch.zeros(T, h, DP, dtype=torch.float64, device=dev)
+            if p:
+                tile[:, :, :p] = pos.double()[:, None, :]
+            tile[:, :, p:p + dk] = src
+            dst.append(tile.float().contiguous())
+        stats.append(torch.cat([mu, rstd], -1))
+    return qkv, gamma, beta, torch.stack(stats).float().contiguous(), tiles, plains
+
+
+@pytest.mark.parametrize("B,n,h,dk,p", [(2, 100, 4, 32, 2), (1, 37, 2, 16, 2), (2, 700, 4, 32, 1), (1, 64, 1, 48, 2)])
+def test_plain_head_tiles_ktv_and_dkv_ln(H, gpu_device, B, n, h, dk, p):
+    """ "Plain" head tiles (normalised values without the LayerNorm affine, gt_hip.h: hn_plain): gt_galerkin_ktv_affine on
+    them == gt_galerkin_ktv on the affine tiles, and gt_galerkin_dkv_ln_plain (gamma folded into dM, beta dM added, xh taken
+    from the tiles, no raw projection) == gt_galerkin_dkv_ln on the affine tiles + raw projection."""
+    dev = gpu_device
+    T, DP = B * n, H.round4(dk + p)
+    qkv, gamma, beta, stats, (Kp, Vp), (Kx, Vx) = _plain_case(H, dev, B, n, h, dk, p, 600)
+    ref = H.galerkin_ktv(Kp, Vp, B, n, h, dk, p)
+    got = H.galerkin_ktv(Kx, Vx, B, n, h, dk, p, gamma=gamma, beta=beta)
+    torch.cuda.synchronize()
+    assert rel_l2(got.sum(0), ref.sum(0)) < 2e-6
+    dM = rnd(B, h, DP, DP, dev=dev, seed=610, scale=0.2)
+    dQp = rnd(T, h, DP, dev=dev, seed=611)
+    ref = H.galerkin_dkv_ln(Kp, Vp, dM, dQp, qkv, gamma, stats, B, n, h, dk, p)
+    got = H.galerkin_dkv_ln(Kx, Vx, dM, dQp, None, gamma, stats, B, n, h, dk, p, beta=beta)
+    torch.cuda.synchronize()
+    for a, c, name in zip(got, ref, ("d_qkv", "dgamma", "dbeta")):
+        assert not torch.isnan(a).any(), name
+        assert rel_l2(a, c) < 3e-6, name
+
+
+def test_qkv_headnorm_plain_tiles(H, gpu_device):
+    """GT_EP_HEADNORM with hn_plain: K / V tiles hold (x - mean) * rstd, no raw projection is written (C = None)."""
+    dev = gpu_device
+    T, h, dk, p, mask = 1500, 4, 32, 2, 0b110
+    d = h * dk
+    x = rnd(T, d, dev=dev, seed=620)
+    w = rnd(3 * d, d, dev=dev, seed=621, scale=0.2)
+    b = rnd(3 * d, dev=dev, seed=622)
+    gamma = 1 + 0.1 * rnd(2, h, dk, dev=dev, seed=623)
+    beta = 0.1 * rnd(2, h, dk, dev=dev, seed=624)
+    pos = rnd(T, p, dev=dev, seed=625)
+    DP = H.round4(dk + p)
+    out_ref = torch.empty(3, T, h, DP, device=dev)
+    st_ref = torch.zeros(2, T, h, 2, device=dev)
+    qkv = torch.empty(T, 3 * d, device=dev)
+    hn = dict(gamma=gamma, beta=beta, pos=pos, out=out_ref, stats=st_ref, h=h, dk=dk, p=p, norm_mask=mask, eps=1e-7)
+    H.gemm(x, w, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, hn=hn, precision="bf16x3")
+    out = torch.full_like(out_ref, float("nan"))
+    st = torch.zeros_like(st_ref)
+    H.gemm(x, w, None, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, precision="bf16x3",
+           hn=dict(hn, out=out, stats=st, skip_raw=7, plain=True))
+    torch.cuda.synchronize()
+    assert torch.equal(st, st_ref) and torch.equal(out[0], out_ref[0])
+    for s_ in (1, 2):                                  # affine tile = gamma * plain + beta on the value columns
+        val = out[s_][:, :, p:p + dk] * gamma[s_ - 1] + beta[s_ - 1]
+        assert rel_l2(val, out_ref[s_][:, :, p:p + dk]) < 1e-6
+        assert torch.equal(out[s_][:, :, :p], out_ref[s_][:, :, :p]) and torch.equal(out[s_][:, :, p + dk:], out_ref[s_][:, :, p + dk:])
