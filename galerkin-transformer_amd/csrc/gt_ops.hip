@@ -805,32 +805,45 @@ __global__ __launch_bounds__(256) void galerkin_ktv_kernel(const float* __restri
             }
         }
         for (int tb = t_lo; tb < t_hi; tb += 16) {
+          // 4 independent 4-token steps in flight: every load of the 16 tokens is requested before the first is used
+          float a[4][NB], v[4][NB], pk[4][2];
+          bool okk[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {                       // 4 independent 4-token steps in flight
-            const int t0 = tb + 4 * u;
-            const int t = t0 + kq;
-            const bool ok = t < t_hi;
+          for (int u = 0; u < 4; ++u) {
+            const int t = tb + 4 * u + kq;
+            okk[u] = t < t_hi;
             const float* kr = kb + (int64_t)t * hD;
             const float* vr = vb + (int64_t)t * hD;
-            float a[NB], v[NB], pk[2] = {0.f, 0.f};
+            pk[u][0] = pk[u][1] = 0.f;
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                a[c] = ok ? fmaf(kr[p + 16 * c + i], gk[c], bk[c]) : 0.f;
-                v[c] = ok ? fmaf(vr[p + 16 * c + i], gv[c], bv[c]) : 0.f;
+                a[u][c] = okk[u] ? kr[p + 16 * c + i] : 0.f;
+                v[u][c] = okk[u] ? vr[p + 16 * c + i] : 0.f;
             }
-            if (p > 0) pk[0] = ok ? kr[0] : 0.f;
-            if (p > 1) pk[1] = ok ? kr[1] : 0.f;
+            if (p > 0) pk[u][0] = okk[u] ? kr[0] : 0.f;
+            if (p > 1) pk[u][1] = okk[u] ? kr[1] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (gamma) {                                       // plain tiles: the LayerNorm affine on the way in
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    a[u][c] = okk[u] ? fmaf(a[u][c], gk[c], bk[c]) : 0.f;
+                    v[u][c] = okk[u] ? fmaf(v[u][c], gv[c], bv[c]) : 0.f;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < NB; ++c)
 #pragma unroll
-                for (int e = 0; e < NB; ++e) acc[c][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], v[e], acc[c][e], 0, 0, 0);
+                for (int e = 0; e < NB; ++e)
+                    acc[c][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c], v[u][e], acc[c][e], 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                kp[c][0] = fmaf(a[c], pk[0], kp[c][0]); kp[c][1] = fmaf(a[c], pk[1], kp[c][1]);
-                pv[c][0] = fmaf(pk[0], v[c], pv[c][0]); pv[c][1] = fmaf(pk[1], v[c], pv[c][1]);
+                kp[c][0] = fmaf(a[u][c], pk[u][0], kp[c][0]); kp[c][1] = fmaf(a[u][c], pk[u][1], kp[c][1]);
+                pv[c][0] = fmaf(pk[u][0], v[u][c], pv[c][0]); pv[c][1] = fmaf(pk[u][1], v[u][c], pv[c][1]);
             }
-            pp[0][0] = fmaf(pk[0], pk[0], pp[0][0]); pp[0][1] = fmaf(pk[0], pk[1], pp[0][1]);
-            pp[1][0] = fmaf(pk[1], pk[0], pp[1][0]); pp[1][1] = fmaf(pk[1], pk[1], pp[1][1]);
+            pp[0][0] = fmaf(pk[u][0], pk[u][0], pp[0][0]); pp[0][1] = fmaf(pk[u][0], pk[u][1], pp[0][1]);
+            pp[1][0] = fmaf(pk[u][1], pk[u][0], pp[1][0]); pp[1][1] = fmaf(pk[u][1], pk[u][1], pp[1][1]);
           }
         }
         // borders: combine the 4 token lanes
