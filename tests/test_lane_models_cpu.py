@@ -248,3 +248,116 @@ def test_dft_analysis_lane_map(n, P):
                 prr = min(16 * mt + 4 * kq[l] + r, P - 1)
                 Y[prr, 16 * nt + j[l]] = acc[0][l, r] + acc[1][l, r]
     assert np.allclose(Y, F.T @ X, atol=1e-9)
+
+
+@pytest.mark.parametrize("G,n,p", [(2, 37, 2), (1, 21, 2), (2, 40, 1), (3, 18, 2)])
+def test_galerkin_dkv_ln_plain_lane_map(G, n, p):
+    """galerkin_dkv_ln_kernel<G, PLAIN = true> (gt_ops.hip) for one (batch, head): output columns in value order (a row
+    permutation of the dM fragments), gamma folded into the fragment rows, beta dM as the accumulators' start value, the
+    LayerNorm backward on the lanes that hold the products (row means over the four kq lanes of a token), d(gamma) /
+    d(beta) folded over the token lanes -- against the plain numpy statement of the same backward."""
+    DP, NS, NMT = 16 * G + 4, 4 * G + 1, G + 1
+    dk = DP - 4 if p else DP                         # round4(dk + p) == DP with dk % 4 == 0
+    rng = np.random.default_rng(10 * G + p)
+    xh = [rng.standard_normal((n, dk)) for _ in range(2)]            # normalised K and V values
+    pos = rng.standard_normal((n, p))
+    tile = [np.zeros((n, DP)) for _ in range(2)]                     # plain head tiles [pos | xh | pad]
+    for s_ in range(2):
+        tile[s_][:, :p] = pos
+        tile[s_][:, p:p + dk] = xh[s_]
+    gam, bet = 1 + 0.3 * rng.standard_normal((2, dk)), 0.2 * rng.standard_normal((2, dk))
+    rstd = 0.5 + rng.random((2, n))
+    dM = rng.standard_normal((DP, DP))
+
+    # ---- reference
+    aff = [t.copy() for t in tile]
+    for s_ in range(2):
+        aff[s_][:, p:p + dk] = xh[s_] * gam[s_] + bet[s_]
+    gyK, gyV = (aff[1] @ dM.T)[:, p:p + dk], (aff[0] @ dM)[:, p:p + dk]
+    ref_dx, ref_dg, ref_db = [], [], []
+    for s_, gy in enumerate((gyK, gyV)):
+        gg = gy * gam[s_]
+        m1, m2 = gg.mean(1, keepdims=True), (gg * xh[s_]).mean(1, keepdims=True)
+        ref_dx.append(rstd[s_][:, None] * (gg - m1 - xh[s_] * m2))
+        ref_dg.append((gy * xh[s_]).sum(0))
+        ref_db.append(gy.sum(0))
+
+    # ---- lane model
+    def kidx(s):
+        return 4 * (KQ + 4 * (s >> 2)) + (s & 3) if s < 4 * G else 16 * G + KQ
+
+    a1 = np.zeros((NMT, NS, 64)); a2 = np.zeros((NMT, NS, 64))
+    for mt in range(NMT):
+        cp = 16 * mt + J
+        col = np.where(cp < dk, cp + p, np.where(cp < dk + p, cp - dk, cp))
+        cc = np.minimum(col, DP - 1)
+        live = (cp < DP).astype(float)
+        for s in range(NS):
+            k = kidx(s)
+            isval = (k >= p) & (k < p + dk)
+            sv = np.where(isval, gam[1][np.clip(k - p, 0, dk - 1)], 1.0)
+            sk = np.where(isval, gam[0][np.clip(k - p, 0, dk - 1)], 1.0)
+            a1[mt, s] = live * sv * dM[cc, k]
+            a2[mt, s] = live * sk * dM[k, cc]
+    cst = np.zeros((2, 4, NMT, 4))
+    for kq2 in range(4):
+        for mt in range(NMT):
+            for c in range(4):
+                cp = 16 * mt + 4 * kq2 + c
+                if cp >= DP:
+                    continue
+                col = cp + p if cp < dk else (cp - dk if cp < dk + p else cp)
+                cst[0, kq2, mt, c] = sum(bet[1][v] * dM[col, p + v] for v in range(dk))
+                cst[1, kq2, mt, c] = sum(bet[0][v] * dM[p + v, col] for v in range(dk))
+    ok = [(16 * mt + 4 * KQ) < dk for mt in range(NMT)]
+    dx = [np.full((n, dk), np.nan) for _ in range(2)]
+    dg = [[np.zeros((64, 4)) for _ in range(NMT)] for _ in range(2)]
+    db = [[np.zeros((64, 4)) for _ in range(NMT)] for _ in range(2)]
+    for tl in range((n + 15) // 16):
+        t = 16 * tl + J
+        tc = np.minimum(t, n - 1)
+        kk = [tile[0][tc[:, None], (4 * (KQ + 4 * g))[:, None] + np.arange(4)] for g in range(G)] + [tile[0][tc, 16 * G:16 * G + 4]]
+        vv = [tile[1][tc[:, None], (4 * (KQ + 4 * g))[:, None] + np.arange(4)] for g in range(G)] + [tile[1][tc, 16 * G:16 * G + 4]]
+        acc = [[cst[w][KQ, mt].copy() for mt in range(NMT)] for w in range(2)]
+        for s in range(NS):
+            if s < 4 * G:
+                bv, bk = vv[s >> 2][:, s & 3], kk[s >> 2][:, s & 3]
+            else:
+                bv, bk = vv[G][S.LANES, KQ], kk[G][S.LANES, KQ]
+            for mt in range(NMT):
+                acc[0][mt] = S.mfma(a1[mt, s], bv, acc[0][mt])
+                acc[1][mt] = S.mfma(a2[mt, s], bk, acc[1][mt])
+        live_t = t < n
+        for s_ in range(2):
+            x = [None] * NMT
+            for mt in range(NMT):                  # tile_load4(row + p + 4 kq + 16 mt): the value-ordered float4 of the tile row
+                cols = np.minimum(p + 16 * mt + 4 * KQ[:, None] + np.arange(4), DP - 1)
+                x[mt] = np.where(ok[mt][:, None], tile[s_][tc[:, None], cols], 0.0)
+            gm = [np.where(ok[mt][:, None], gam[s_][np.minimum(16 * mt + 4 * KQ[:, None] + np.arange(4), dk - 1)], 0.0) for mt in range(NMT)]
+            gg = [np.where(ok[mt][:, None], acc[s_][mt] * gm[mt], 0.0) for mt in range(NMT)]
+            s1 = sum(g_.sum(1) for g_ in gg)
+            s2 = sum((g_ * x_).sum(1) for g_, x_ in zip(gg, x))
+            for sh in (16, 32):                     # the two cross-lane adds over the kq lanes of a token
+                s1 = s1 + s1[S.LANES ^ sh]
+                s2 = s2 + s2[S.LANES ^ sh]
+            m1, m2 = s1 / dk, s2 / dk
+            for l in range(64):
+                if not live_t[l]:
+                    continue
+                for mt in range(NMT):
+                    if not ok[mt][l]:
+                        continue
+                    v0 = 16 * mt + 4 * KQ[l]
+                    dx[s_][t[l], v0:v0 + 4] = rstd[s_][t[l]] * (gg[mt][l] - m1[l] - x[mt][l] * m2[l])
+                    dg[s_][mt][l] += acc[s_][mt][l] * x[mt][l]
+                    db[s_][mt][l] += acc[s_][mt][l]
+    for s_ in range(2):
+        assert np.allclose(dx[s_], ref_dx[s_], atol=1e-9)
+        got_dg, got_db = np.zeros(dk), np.zeros(dk)
+        for mt in range(NMT):
+            for l in range(64):
+                v0 = 16 * mt + 4 * KQ[l]
+                if v0 < dk:
+                    got_dg[v0:v0 + 4] += dg[s_][mt][l]
+                    got_db[v0:v0 + 4] += db[s_][mt][l]
+        assert np.allclose(got_dg, ref_dg[s_], atol=1e-9) and np.allclose(got_db, ref_db[s_], atol=1e-9)
