@@ -361,3 +361,108 @@ def test_galerkin_dkv_ln_plain_lane_map(G, n, p):
                     got_dg[v0:v0 + 4] += dg[s_][mt][l]
                     got_db[v0:v0 + 4] += db[s_][mt][l]
         assert np.allclose(got_dg, ref_dg[s_], atol=1e-9) and np.allclose(got_db, ref_db[s_], atol=1e-9)
+
+
+def _mfma32(first, second, acc):
+    """Lane model of v_mfma_f32_32x32x16_bf16 (values kept in float64): D[32][32] += X[32][16] Y[16][32] with
+    lane l supplying row l & 31 of X / column l & 31 of Y for k = 8 (l >> 5) .. + 7, and holding
+    D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31] in accumulator register r."""
+    lanes = np.arange(64)
+    lr, lh = lanes & 31, lanes >> 5
+    X = np.zeros((32, 16)); Y = np.zeros((16, 32))
+    for e in range(8):
+        X[lr, 8 * lh + e] = first[:, e]
+        Y[8 * lh + e, lr] = second[:, e]
+    D = X @ Y
+    out = acc.copy()
+    for r in range(16):
+        out[:, r] += D[(r & 3) + 8 * (r >> 2) + 4 * lh, lr]
+    return out
+
+
+@pytest.mark.parametrize("conv", [False, True])
+def test_packed_b_kernel_lane_map(conv):
+    """gemm_x3p_kernel (gt_gemm_x3.hip), one 128 x 128 block tile: x3_pack_b_kernel's fragment order, the wave's B
+    fragment addresses, the A rows of a stage (plain, or the implicit 3x3 convolution: channel block -> tap -> channel
+    stage order, tap-valid bits, neighbour-row offsets) and the accumulator -> (row, column) map of the epilogue,
+    against A B^T / conv2d restated in numpy.  Values stay float64: the bf16 split is exact and tested on the GPU."""
+    rng = np.random.default_rng(int(conv))
+    if conv:
+        Bn, Hh, Ww, Cc, N = 1, 9, 13, 32, 128           # 117 pixels: one partial tile; 32 channels: CB = 32, two stages per tap
+        M, K = Bn * Hh * Ww, 9 * Cc
+        img = rng.standard_normal((Bn, Hh, Ww, Cc))
+        A = img.reshape(M, Cc)
+        cb = 32 if Cc % 32 == 0 else 16
+        w = rng.standard_normal((N, Cc, 3, 3))
+        Bmat = w.transpose(0, 2, 3, 1).reshape(N, 9, Cc // cb, cb).transpose(0, 2, 1, 3).reshape(N, K)    # ops._conv_k_order
+    else:
+        M, N, K = 100, 72, 40                            # partial M tile, N that does not fill the tile, partial last stage
+        A = rng.standard_normal((M, K))
+        Bmat = rng.standard_normal((N, K))
+    NT, KS = ((N + 127) // 128) * 4, (K + 15) // 16
+    lanes = np.arange(64)
+    lr, lh = lanes & 31, lanes >> 5
+    # x3_pack_b_kernel (one plane)
+    packed = np.zeros((NT, KS, 64, 8))
+    for nt in range(NT):
+        for ks in range(KS):
+            n = nt * 32 + lr
+            for e in range(8):
+                k = ks * 16 + 8 * lh + e
+                okb = (n < N) & (k < K)
+                packed[nt, ks, :, e] = np.where(okb, Bmat[np.minimum(n, N - 1), np.minimum(k, K - 1)], 0.0)
+    C = np.full((M, N), np.nan)
+    m0 = n0 = 0
+    for wave in range(4):
+        wm, wn = wave >> 1, wave & 1
+        acc = [[np.zeros((64, 16)) for _ in range(2)] for _ in range(2)]
+        tap, c0 = 0, 0
+        for ks in range(KS):
+            am = []
+            for i in range(2):
+                row = wm * 64 + 32 * i + lr
+                m = m0 + row
+                v = np.zeros((64, 8))
+                if conv:
+                    pix = np.minimum(m, M - 1) % (Hh * Ww)
+                    y, x = pix // Ww, pix % Ww
+                    dy, dx = tap // 3 - 1, tap % 3 - 1
+                    valid = (m < M) & (y + dy >= 0) & (y + dy < Hh) & (x + dx >= 0) & (x + dx < Ww)
+                    src = np.clip(m + dy * Ww + dx, 0, M - 1)
+                    for e in range(8):
+                        v[:, e] = np.where(valid, A[src, c0 + 8 * lh + e], 0.0)
+                else:
+                    for e in range(8):
+                        k = ks * 16 + 8 * lh + e
+                        v[:, e] = np.where((m < M) & (k < K), A[np.minimum(m, M - 1), np.minimum(k, K - 1)], 0.0)
+                am.append(v)
+            if conv:                                   # the issue state machine: channel block first, taps second
+                c0 += 16
+                if c0 % cb == 0:
+                    c0 -= cb
+                    tap += 1
+                    if tap == 9:
+                        tap, c0 = 0, c0 + cb
+            nt0 = (n0 + wn * 64) >> 5
+            for j in range(2):
+                bn = packed[nt0 + j, ks]
+                for i in range(2):
+                    acc[i][j] = _mfma32(bn, am[i], acc[i][j])
+        for i in range(2):                             # x3_epilogue: register 4 g + t of accumulator (i, j)
+            for j in range(2):
+                for g in range(4):
+                    for t in range(4):
+                        mrow = m0 + wm * 64 + 32 * i + lr
+                        ncol = n0 + wn * 64 + 32 * j + 8 * g + 4 * lh + t
+                        okc = (mrow < M) & (ncol < N)
+                        C[mrow[okc], ncol[okc]] = acc[i][j][okc, 4 * g + t]
+    if conv:
+        pad = np.pad(img, ((0, 0), (1, 1), (1, 1), (0, 0)))
+        ref = np.zeros((Bn, Hh, Ww, N))
+        for ky in range(3):
+            for kx in range(3):
+                ref += pad[:, ky:ky + Hh, kx:kx + Ww, :] @ w[:, :, ky, kx].T
+        ref = ref.reshape(M, N)
+    else:
+        ref = A @ Bmat.T
+    assert not np.isnan(C).any() and np.allclose(C, ref, atol=1e-9)
