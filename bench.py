@@ -266,14 +266,17 @@ class Trainer:
         try:
             for p in self.params:
                 p.grad = None
+            # with a process group alive its watchdog thread touches the runtime (event queries) while this thread
+            # captures: "thread_local" keeps those calls from invalidating the capture
+            mode = dict(capture_error_mode="thread_local") if self.world > 1 else {}
             self.g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, **mode):
                 self.fwd_bwd()
                 if self.world == 1:
                     self.opt_step()
             if self.world > 1:
                 self.g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
+                with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), **mode):
                     self.opt_step()
             torch.cuda.synchronize()
             return True
