@@ -389,14 +389,19 @@ def grads_of(fn: Callable[..., Tensor], sd: Mapping[str, Tensor], inputs: Sequen
 
 
 def model_train_step_cpu(sd: Dict[str, Tensor], cfg: Mapping, node, pos, grid, target,
-                         adam_state: dict, lr: float = 1e-3, clip: float = 0.99):
-    """One fwd + MSE + bwd + clip_grad_norm_ + Adam step in plain torch (cpu_baseline leg).
-    sd tensors must be leaf tensors with requires_grad=True; updated in place."""
+                         adam_state: dict, lr: float = 1e-3, clip: float = 0.99, attn_drops="random"):
+    """One fwd + MSE + bwd + clip_grad_norm_ + Adam step in plain torch (cpu_baseline leg; the reference's step is
+    utils_ft.py:676-681 around model.py:953-1017).  sd tensors must be leaf tensors with requires_grad=True; updated in
+    place.  attn_drops: "random" (the reference's always-on attention dropout, fresh masks), None (identity), or one
+    multiplicative mask per encoder layer (mask replay) -- the two deterministic forms serve the trajectory test."""
     params = [v for v in sd.values() if v.requires_grad]
     for p in params:
         p.grad = None
-    pred = fourier_transformer_2d(sd, cfg, node, pos, grid, attn_drops=["random"] * cfg["num_encoder_layers"])
-    loss = ((pred - target) ** 2).mean()
+    if isinstance(attn_drops, str):
+        attn_drops = [attn_drops] * cfg["num_encoder_layers"]
+    dt = params[0].dtype
+    pred = fourier_transformer_2d(sd, cfg, node.to(dt), pos.to(dt), grid.to(dt), attn_drops=attn_drops)
+    loss = ((pred - target.to(dt)) ** 2).mean()
     loss.backward()
     torch.nn.utils.clip_grad_norm_(params, clip)
     if "opt" not in adam_state:

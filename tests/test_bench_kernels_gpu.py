@@ -1,0 +1,267 @@
+"""Oracle parity on the kernel instances the headline bench runs (-m gpu).
+
+bench.py's Darcy 141^2 step runs at B = 128 per GPU: T = 236 672 token rows, where gt_gemm selects the packed-B
+split-operand kernel (`gemm_x3p_kernel`, T >= 16 384), the QKV launch carries the head-norm epilogue on plain tiles
+(`gemm_x3p_kernel<0, 32, 0>`), the backward is the fused dK'/dV'/LayerNorm pass on plain tiles
+(`galerkin_dkv_ln_kernel<2, true>`) and the weight gradients fork to the side stream (T >= _hip.SIDE_MIN_ROWS).
+The cases below sit just above those switches (C2 at B = 18: T = 33 282; C4 at B = 26: T = 33 696), are compared with
+the CPU oracle at the 1e-5 bar, and assert that the launches really were those kernels:
+
+  (a) one encoder layer, attention dropout off and mask-replay                  -- reference model.py:104-140
+  (b) the whole FourierTransformer2D of bench.darcy_config() at 141^2 / 43^2    -- reference model.py:953-1017
+  (c) a 5-step training trajectory (FlatClipAdam, HIP graph) against the oracle's
+      clip_grad_norm_ + Adam step                                                -- reference utils_ft.py:656-681
+"""
+import json
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+from _util import rel_l2, TOL
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Spy:
+    """Records what the operators handed to the library (plain tiles? side stream?) while active."""
+
+    def __init__(self, H):
+        self.H, self.dkv_plain, self.ktv_affine, self.forks = H, [], [], 0
+
+    def __enter__(self):
+        H = self.H
+        self._dkv, self._ktv, self._side = H.galerkin_dkv_ln, H.galerkin_ktv, H._side_stream
+
+        def dkv(*a, **k):
+            self.dkv_plain.append(k.get("beta") is not None)
+            return self._dkv(*a, **k)
+
+        def ktv(*a, **k):
+            self.ktv_affine.append(k.get("gamma") is not None)
+            return self._ktv(*a, **k)
+
+        def side(dev):
+            self.forks += 1
+            return self._side(dev)
+
+        H.galerkin_dkv_ln, H.galerkin_ktv, H._side_stream = dkv, ktv, side
+        return self
+
+    def __exit__(self, *exc):
+        self.H.galerkin_dkv_ln, self.H.galerkin_ktv, self.H._side_stream = self._dkv, self._ktv, self._side
+
+
+def _kernels_of(fn):
+    """Kernel keys (gt_gemm_kernel_name / entry-point names) of every C-ABI launch fn() makes."""
+    from galerkin_transformer import _hip
+    with _hip.Profile() as prof:
+        fn()
+    torch.cuda.synchronize()
+    return [r[0] for r in prof.records]
+
+
+LAYER_CASES = {
+    # T = B n >= _hip.SIDE_MIN_ROWS (32 768) > the packed-B threshold (16 384)
+    "C2_B18": dict(B=18, n=1849, d=128, h=4, p=2, ff=256, eps=1e-7,
+                   expect=("gemm_x3p_kernel<0, 32, 0>", "gemm_x3p_kernel<0, 0, 0>", "gt_galerkin_ktv", "gt_galerkin_dkv_ln"),
+                   plain=True),
+    # d_k = 48: no fused head-norm epilogue (widths 16 / 32 / 64), affine tiles, the fused backward in its non-plain form
+    "C4_B26": dict(B=26, n=1296, d=192, h=4, p=2, ff=384, eps=1e-7,
+                   expect=("gemm_x3p_kernel<0, 0, 0>", "gt_headnorm_fwd", "gt_galerkin_ktv", "gt_galerkin_dkv_ln"),
+                   plain=False),
+}
+
+
+@pytest.mark.parametrize("mode", ["off", "replay"])
+@pytest.mark.parametrize("name", list(LAYER_CASES))
+def test_encoder_layer_bench_kernel_instances(gpu_device, name, mode):
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip
+    from oracle import galerkin_oracle as O
+    c = LAYER_CASES[name]
+    B, n, d, h, p, ff, eps = (c[k] for k in ("B", "n", "d", "h", "p", "ff", "eps"))
+    assert B * n >= _hip.SIDE_MIN_ROWS
+    torch.manual_seed(31)
+    layer = gt.SimpleTransformerEncoderLayer(d_model=d, pos_dim=p, n_head=h, dim_feedforward=ff,
+                                             attention_type="galerkin", layer_norm=False, attn_norm=True,
+                                             norm_eps=eps, dropout=0.0, ffn_dropout=0.0)
+    with torch.no_grad():
+        for prm in layer.parameters():
+            prm.add_(0.02 * torch.randn_like(prm))
+    x, pos, cot = torch.randn(B, n, d), torch.rand(B, n, p), torch.randn(B, n, d)
+    Dr = d // h + p
+    mask = (torch.rand(B, h, Dr, Dr) >= 0.5).float() * 2.0 if mode == "replay" else None
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    ref_y, (ref_dx,), ref_dp = O.grads_of(
+        lambda s, xx: O.encoder_layer(s, xx, pos, n_head=h, attention_type="galerkin", layer_norm=False,
+                                      attn_norm=True, norm_eps=eps, attn_drop=mask), sd, [x], cot)
+    dev = gpu_device
+    layer = layer.to(dev)
+    posd, cotd = pos.to(dev), cot.to(dev)
+
+    def run():
+        if mask is not None:
+            gt.push_attention_masks([mask.to(dev)])
+        xg = x.to(dev).requires_grad_(True)
+        layer.zero_grad(set_to_none=True)
+        y = layer(xg, posd)
+        y.backward(cotd)
+        return xg, y
+
+    gt.set_attention_dropout(mode)
+    try:
+        with _Spy(_hip) as spy:
+            xg, y = run()                                  # the path as it runs: two streams
+        torch.cuda.synchronize()
+        errs = {"out": rel_l2(y, ref_y), "dx": rel_l2(xg.grad, ref_dx)}
+        for k, v in dict(layer.named_parameters()).items():
+            errs[k] = rel_l2(v.grad, ref_dp[k])
+        kernels = _kernels_of(run)                         # same shapes again, one stream, launches named
+    finally:
+        gt.set_attention_dropout("reference")
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+    if gt.get_precision() == "bf16x3":                     # the kernel selection of the default arithmetic
+        for k in c["expect"]:
+            assert k in kernels, (k, sorted(set(kernels)))
+        assert spy.dkv_plain == [c["plain"]] and spy.ktv_affine == [c["plain"]]
+        if _hip._dual_stream[0]:
+            assert spy.forks >= 4                          # dP^T, dW_qkv, dW_1, dW_2 left for the side stream
+
+
+def _zero_dropout_cfg(bench):
+    cfg = bench.darcy_config()
+    for k in ("dropout", "downscaler_dropout", "upscaler_dropout", "ffn_dropout", "encoder_dropout", "decoder_dropout"):
+        cfg[k] = 0.0
+    return cfg
+
+
+@pytest.mark.parametrize("mode", ["off", "replay"])
+def test_whole_model_darcy141_vs_oracle(gpu_device, mode):
+    """FourierTransformer2D of the bench configuration (down-scaler -> 6 layers -> implicit-conv up-scaler -> upsample_fc
+    -> 2 x SpectralConv2d -> head) at its own size, B = 18: prediction and every parameter gradient vs the oracle."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip
+    from oracle import galerkin_oracle as O
+    B = 18
+    cfg = _zero_dropout_cfg(bench)
+    torch.manual_seed(41)
+    model = gt.FourierTransformer2D(**cfg)
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.add_(0.02 * torch.randn_like(prm))
+    b = bench.synthetic_batch(B, torch.device("cpu"), seed=77)
+    cot = torch.randn(B, bench.N_FINE, bench.N_FINE, 1)
+    L, h, Dr = cfg["num_encoder_layers"], cfg["n_head"], cfg["n_hidden"] // cfg["n_head"] + 2
+    masks = [(torch.rand(B, h, Dr, Dr) >= 0.5).float() * 2.0 for _ in range(L)] if mode == "replay" else None
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ref, _, ref_dp = O.grads_of(
+        lambda s: O.fourier_transformer_2d(s, cfg, b["node"], b["pos"], b["grid"], attn_drops=masks), sd, [], cot)
+    dev = gpu_device
+    model = model.to(dev).train()
+    bd = {k: v.to(dev) for k, v in b.items()}
+
+    def run():
+        if masks is not None:
+            gt.push_attention_masks([m.to(dev) for m in masks])
+        model.zero_grad(set_to_none=True)
+        out = model(bd["node"], None, bd["pos"], bd["grid"])["preds"]
+        out.backward(cot.to(dev))
+        return out
+
+    gt.set_attention_dropout(mode)
+    try:
+        out = run()
+        torch.cuda.synchronize()
+        errs = {"out": rel_l2(out, ref)}
+        for k, v in dict(model.named_parameters()).items():
+            errs[k] = rel_l2(v.grad, ref_dp[k])
+        kernels = set(_kernels_of(run))
+    finally:
+        gt.set_attention_dropout("reference")
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+    assert len(errs) == 1 + len(ref_dp) == 1 + sum(1 for _ in model.parameters())
+    if gt.get_precision() == "bf16x3":
+        for k in ("gemm_x3p_kernel<0, 32, 0>", "gemm_x3p_kernel<0, 0, 0>", "gemm_x3p_kernel<0, 0, 1>", "gt_galerkin_dkv_ln"):
+            assert k in kernels, (k, sorted(kernels))
+
+
+def test_training_trajectory_vs_oracle(gpu_device):
+    """Five optimizer steps of the bench's training step (fwd + MSE + bwd + clip 0.99 + Adam, lr 1e-3; FlatClipAdam,
+    step 1 eager, steps 2-5 replays of the captured HIP graph; every nn.Dropout 0, the attention masks replayed) against
+    the oracle's step in float64.
+
+    Adam's first steps move every parameter by ~lr * sign(g): an element whose gradient is below the fp32 noise of the
+    backward pass can take the opposite sign in ANY two fp32-class implementations, so parameters do not agree to 1e-5
+    after several steps -- the oracle's own float32 run deviates from its float64 run by ~1e-4 of the parameter norm.
+    The gate is therefore: the loss of every step within 1e-5, and the parameter deviation from the float64 trajectory
+    no larger than 3x what the float32 ORACLE shows against the same float64 trajectory (+ 2e-5)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip
+    from oracle import galerkin_oracle as O
+    B, STEPS = 4, 5
+    cfg = _zero_dropout_cfg(bench)
+    torch.manual_seed(43)
+    model = gt.FourierTransformer2D(**cfg)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    b = bench.synthetic_batch(B, torch.device("cpu"), seed=79)
+    L, h, Dr = cfg["num_encoder_layers"], cfg["n_head"], cfg["n_hidden"] // cfg["n_head"] + 2
+    masks = [(torch.rand(B, h, Dr, Dr) >= 0.5).float() * 2.0 for _ in range(L)]
+
+    def oracle_run(dtype):
+        sd = {k: v.detach().clone().to(dtype).requires_grad_(v.is_floating_point()) for k, v in sd0.items()}
+        state, losses = {}, []
+        for _ in range(STEPS):
+            losses.append(O.model_train_step_cpu(sd, cfg, b["node"], b["pos"], b["grid"], b["target"], state,
+                                                 lr=1e-3, clip=0.99, attn_drops=masks))
+        return {k: v.detach().double() for k, v in sd.items()}, losses
+
+    p64, l64 = oracle_run(torch.float64)
+    p32, l32 = oracle_run(torch.float32)
+
+    dev = gpu_device
+    model = model.to(dev).train()
+    gt.set_attention_dropout("replay")
+    try:
+        gt.push_attention_masks([m.to(dev) for m in masks] * 2)       # the eager step + the capture trace
+        tr = bench.Trainer(model, bench.synthetic_batch(B, dev, seed=79), 1, lr=1e-3, clip=0.99, use_graph=True)
+        losses = []
+        assert tr.capture(warm=1)                                      # step 1 (eager), then the capture
+        losses.append(float(tr.loss.item()))
+        for _ in range(STEPS - 1):
+            tr.step()
+            losses.append(float(tr.loss.item()))
+        torch.cuda.synchronize()
+    finally:
+        gt.set_attention_dropout("reference")
+    phip = {k: v.detach().double().cpu() for k, v in model.state_dict().items()}
+
+    def dev_of(a):
+        num = sum(float(((a[k] - p64[k]) ** 2).sum()) for k in p64)
+        return math.sqrt(num / sum(float((p64[k] ** 2).sum()) for k in p64))
+
+    moved = math.sqrt(sum(float(((p64[k] - sd0[k].double()) ** 2).sum()) for k in p64) /
+                      sum(float((p64[k] ** 2).sum()) for k in p64))
+    e_hip, e_f32 = dev_of(phip), dev_of(p32)
+    loss_err = max(abs(a - c) / abs(c) for a, c in zip(losses, l64))
+    rec = dict(steps=STEPS, batch=B, loss_hip=losses, loss_oracle_f64=l64, loss_rel_err_max=loss_err,
+               param_rel_l2_hip_vs_f64=e_hip, param_rel_l2_oracle_f32_vs_f64=e_f32, param_rel_movement=moved,
+               precision=gt.get_precision())
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_trajectory.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print(json.dumps(rec))
+    assert loss_err < 1e-5, rec
+    assert e_hip <= 3.0 * e_f32 + 2e-5, rec
+    assert e_hip < 0.02 * moved, rec                       # and a small fraction of what the five steps moved
