@@ -504,7 +504,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         L.gt_gemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(sp))
         nm = C.create_string_buffer(160)
         L.gt_gemm_kernel_name(C.byref(d), nm, 160)
-        key = nm.value.decode().replace("void gt::", "").replace("(gt::GemmP)", "").replace("(gt::TsmmP)", "")
+        key = (nm.value.decode().replace("(gt::GemmP)", "").replace("(gt::TsmmP)", "").replace("void ", "")
+               .replace("gt::", ""))
         key += "+splitk" if (sp.value > 1 and "tsmm" not in key) else ""
         flops = 2.0 * M * N * (K + K2) * nb
         if conv_wgrad:

@@ -41,6 +41,18 @@ def push_attention_masks(masks):
     _attn_masks.extend(masks)
 
 
+# ReLU mask capture for parity runs: with a list installed, every FeedForward forward (ReLU, no hidden dropout) appends
+# the boolean mask hidden > 0 it will differentiate with.  At bench sizes (~1e7 pre-activations per layer) some lie within
+# fp32 rounding of the kink, where the derivative is decided by the last bit of the accumulation; the checker replays
+# these decisions in its float64 model instead of comparing coin flips (oracle feed_forward(relu_mask=...)).
+_relu_mask_sink = [None]
+
+
+def set_relu_mask_sink(sink):
+    """sink: a list to append the FeedForward ReLU masks to (in call order), or None to switch the capture off."""
+    _relu_mask_sink[0] = sink
+
+
 _qkvnorm_fused = [True]         # QKV projection + head norm in one launch when the library supports the shape
 _next_salt = H.next_salt        # call-site salt counter (rewound by _hip.set_seed / utils.get_seed)
 
@@ -528,6 +540,8 @@ class FeedForwardFn(Function):
         pre = torch.empty(T, f, dtype=torch.float32, device=dev) if act == H.ACT_SILU else None
         H.gemm(xc, w1c, hid, T, f, d, lda=d, ldb=d, ldc=f, bias=b1, act=act, pre=pre, ldpre=f,
                drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None)
+        if _relu_mask_sink[0] is not None and act == H.ACT_RELU and p_h == 0:
+            _relu_mask_sink[0].append(hid > 0)
         out = torch.empty(T, dout, dtype=torch.float32, device=dev)
         rc = None if res is None else _c(res).reshape(T, dout)
         H.gemm(hid, w2c, out, T, dout, f, lda=f, ldb=f, ldc=dout, bias=b2,

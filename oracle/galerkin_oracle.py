@@ -131,8 +131,15 @@ def simple_attention(sd: Mapping[str, Tensor], x: Tensor, pos: Optional[Tensor],
     return o, m
 
 
-def feed_forward(sd: Mapping[str, Tensor], x: Tensor, activation: str = "relu") -> Tensor:
-    h = _act(activation, "relu")(F.linear(x, sd["lr1.weight"], sd["lr1.bias"]))
+def feed_forward(sd: Mapping[str, Tensor], x: Tensor, activation: str = "relu",
+                 relu_mask: Optional[Tensor] = None) -> Tensor:
+    """layers.py:979-987.  relu_mask (0/1, shape of the hidden activation): the ReLU decisions are taken from the mask
+    instead of the sign of the pre-activation -- ReLU mask replay for parity runs at sizes where some pre-activation of
+    the ~1e7 lies within fp32 rounding of the kink, so that its derivative is undefined at fp32 resolution (any two
+    fp32 implementations, the reference on two machines included, may disagree there; each such element moves the
+    parameter gradients by ~1e-4 relative)."""
+    pre = F.linear(x, sd["lr1.weight"], sd["lr1.bias"])
+    h = pre * relu_mask.to(pre.dtype) if relu_mask is not None else _act(activation, "relu")(pre)
     return F.linear(h, sd["lr2.weight"], sd["lr2.bias"])
 
 
@@ -140,7 +147,7 @@ def encoder_layer(sd: Mapping[str, Tensor], x: Tensor, pos: Optional[Tensor], *,
                   n_head: int, attention_type: str = "galerkin", layer_norm: bool = False,
                   attn_norm: Optional[bool] = None, norm_eps: float = 1e-5,
                   residual_type: Optional[str] = "add", activation_type: str = "relu",
-                  attn_drop: AttnDrop = None, return_attn: bool = False):
+                  attn_drop: AttnDrop = None, return_attn: bool = False, relu_mask: Optional[Tensor] = None):
     """One encoder layer (model.py:104-140) with all nn.Dropout = identity."""
     if attn_norm is None:
         attn_norm = not layer_norm
@@ -156,7 +163,8 @@ def encoder_layer(sd: Mapping[str, Tensor], x: Tensor, pos: Optional[Tensor], *,
     d = x.shape[-1]
     if layer_norm:
         x = F.layer_norm(x, (d,), sd["layer_norm1.weight"], sd["layer_norm1.bias"], norm_eps)
-    x = x + feed_forward(_sub(sd, "ff."), x, activation_type)
+    x = x + feed_forward(_sub(sd, "ff."), x, activation_type,
+                         relu_mask=None if relu_mask is None else relu_mask.reshape(x.shape[0], x.shape[1], -1))
     if layer_norm:
         x = F.layer_norm(x, (d,), sd["layer_norm2.weight"], sd["layer_norm2.bias"], norm_eps)
     return (x, m) if return_attn else x
@@ -289,7 +297,7 @@ def _enc_kwargs(cfg: Mapping) -> dict:
 
 def fourier_transformer_2d(sd: Mapping[str, Tensor], cfg: Mapping, node: Tensor, pos: Tensor,
                            grid: Tensor, *, attn_drops: Optional[Sequence[AttnDrop]] = None,
-                           normalizer=None) -> Tensor:
+                           normalizer=None, relu_masks: Optional[Sequence[Tensor]] = None) -> Tensor:
     """FourierTransformer2D.forward (model.py:953-1017) -> preds (B,n,n,n_targets)."""
     B = node.shape[0]
     ns = int(round(math.sqrt(pos.shape[1])))
@@ -304,7 +312,8 @@ def fourier_transformer_2d(sd: Mapping[str, Tensor], cfg: Mapping, node: Tensor,
     ek = _enc_kwargs(cfg)
     for li in range(cfg["num_encoder_layers"]):
         ad = None if attn_drops is None else attn_drops[li]
-        x = encoder_layer(_sub(sd, f"encoder_layers.{li}."), x, pos, attn_drop=ad, **ek)
+        x = encoder_layer(_sub(sd, f"encoder_layers.{li}."), x, pos, attn_drop=ad,
+                          relu_mask=None if relu_masks is None else relu_masks[li], **ek)
     x = x.reshape(B, ns, ns, nh)
     if cfg.get("upscaler_size"):
         x = interp_upscaler(_sub(sd, "upscaler."), x, interp_size=cfg["upscaler_size"],
