@@ -253,8 +253,12 @@ class Trainer:
         self.comm()
         self.opt_step()
 
+    _warm_stream = None                                  # one warm-up stream per process (scratch is kept per stream)
+
     def capture(self, warm=3):
-        s = torch.cuda.Stream()
+        if Trainer._warm_stream is None:
+            Trainer._warm_stream = torch.cuda.Stream()
+        s = Trainer._warm_stream
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warm):
@@ -397,6 +401,7 @@ def roofline_leg(trainer, precision):
                       "useful_vs_f32_mfma_peak": round(useful / PEAK_F32_MFMA_TFLOPS, 4)},
                 hbm={"algorithmic_gbs": round(hbm, 1), "peak_gbs": PEAK_HBM_GBS, "frac": round(hbm / PEAK_HBM_GBS, 4)},
                 traffic=traffic, traffic_source=tsrc,
+                traffic_ratio=(round(traffic / best[2], 3) if traffic else None),
                 algorithmic_flops_per_launch=best[1], algorithmic_bytes_per_launch=best[2])
     # legs the north star names: live per-launch HIP-event time of this step + the HBM bytes / matrix-pipe busy cycles
     # of the same kernel symbol from the rocprofv3 --pmc passes on file (profiles/pmc_step.json: FETCH_SIZE doubled
@@ -412,7 +417,8 @@ def roofline_leg(trainer, precision):
                             ("headnorm_bwd", "gt_headnorm_bwd", "gt::headnorm_bwd_v2_kernel"),
                             ("galerkin_ktv", "gt_galerkin_ktv", "gt::galerkin_ktv_kernel<2>"),
                             ("galerkin_dkv", "gt_galerkin_dkv", "gt::galerkin_dkv_kernel<2>"),
-                            ("galerkin_dkv+headnorm_bwd", "gt_galerkin_dkv_ln", "gt::galerkin_dkv_ln_kernel<2>"),
+                            ("galerkin_dkv+headnorm_bwd", "gt_galerkin_dkv_ln", "gt::galerkin_dkv_ln_kernel<2, true>"),
+                            ("galerkin_qp(Q'.P with fc folded)", "gemm_x3r_kernel<0, 1, 3, 3, 0, 0>", "gt::gemm_x3r_kernel<0, 1, 3, 3, 0, 0>"),
                             ("token_gemms(packed B)", "gemm_x3p_kernel<0, 0, 0>", "gt::gemm_x3p_kernel<0, 0, 0>"),
                             ("conv3x3_implicit", "gemm_x3p_kernel<0, 0, 1>", "gt::gemm_x3p_kernel<0, 0, 1>"),
                             ("conv3x3_wgrad", "gemm_x3r_kernel<1, 1, 3, 3, 0, 2>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 2>"),
@@ -643,6 +649,8 @@ def main():
                        "dropout": "config.yml (train mode) + reference attention dropout p=0.5",
                        "final_loss": round(loss, 6)},
             "f32_mfma_exact": f32_leg,
+            # algorithmic work of the whole step (19.3 GFLOP per sample fwd + bwd) over the step time
+            "useful_tflops": (round(19.3e9 * gb / (elapsed / a.steps) / 1e12, 2) if a.workload == "ex2_darcy141" else None),
             "roofline": roof, "cpu_baseline": cpu, "accuracy": acc,
         }
         if a.table and table:

@@ -288,26 +288,38 @@ def get_precision() -> str:
 
 
 # ----------------------------------------------------------------------------------- scratch / rng state
-_ws_cache = {}
-_ws_retired = []          # outgrown buffers stay alive: a captured HIP graph may have their pointer baked in
+_ws_cache = {}            # (device, stream) -> [buffer, pinned]; insertion order = recency (re-inserted on use)
+_ws_retired = []          # outgrown / evicted PINNED buffers stay alive: a captured HIP graph has their pointer baked in
 _WS_MIN = 64 << 20
+_WS_MAX_UNPINNED = 6      # scratch of at most this many non-capture streams is kept (least recently used go first)
 
 
 def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     """Scratch buffer per (device, stream): consumers of one stream are stream-ordered, so reuse is safe; two
     streams never share a buffer (a graph capture runs on its own stream, so captured work gets its own buffer
-    from the capture's memory pool).  A buffer that has to grow is retired, not freed -- graphs captured earlier
-    keep replaying into memory nobody else owns."""
+    from the capture's memory pool).  A buffer handed out during a capture is pinned for the life of the process (the
+    graph replays into it); a pinned buffer that has to grow is retired, not freed.  Buffers of ordinary streams are
+    kept for the _WS_MAX_UNPINNED most recently used streams only, so short-lived streams do not pin 64 MB each and a
+    recycled stream handle cannot inherit a buffer that a live graph owns."""
     dev = device.index if device.index is not None else torch.cuda.current_device()
     key = (device.type, dev, torch.cuda.current_stream(dev).cuda_stream)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
+    capturing = torch.cuda.is_current_stream_capturing()
+    ent = _ws_cache.pop(key, None)
+    if ent is not None and ent[1] and not capturing:
+        # the handle of a capture stream came back as an ordinary stream: its buffer belongs to the graph
+        _ws_retired.append(ent[0])
+        ent = None
+    if ent is None or ent[0].numel() < nbytes:
         size = max(_WS_MIN, int(nbytes * 1.25))
-        if buf is not None:
-            _ws_retired.append(buf)
-        buf = torch.empty(size, dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
-    return buf
+        if ent is not None and ent[1]:
+            _ws_retired.append(ent[0])
+        ent = [torch.empty(size, dtype=torch.uint8, device=device), capturing]
+    ent[1] = ent[1] or capturing
+    _ws_cache[key] = ent                                   # most recently used last
+    unpinned = [k for k, v in _ws_cache.items() if not v[1]]
+    for k in unpinned[:max(0, len(unpinned) - _WS_MAX_UNPINNED)]:
+        del _ws_cache[k]
+    return ent[0]
 
 
 # ----------------------------------------------------------------------------------- second stream

@@ -55,15 +55,16 @@ class NavierStokesDatasetLite(Dataset):
     # ---- data -----------------------------------------------------------------------------------------
     def _load(self):
         path = self.data_path
-        if path is not None and os.path.exists(path):
-            try:
-                import h5py
-            except ImportError:
-                h5py = None
-            if h5py is not None:
-                with timer(f"Loading {os.path.basename(path)}"):
-                    with h5py.File(path, mode='r') as data:
-                        return np.transpose(data['u'])                    # (N, n, n, T)
+        if path is not None and self.synthetic_len is None:
+            # a data file was asked for: fail loudly like the reference (ns_lite.py:60-75) instead of training on
+            # synthetic fields under the file's name
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"NavierStokesDatasetLite: {path} does not exist (pass synthetic_len=... for "
+                                        "the synthetic advection-diffusion set)")
+            import h5py                                                   # ImportError if the reader is missing
+            with timer(f"Loading {os.path.basename(path)}"):
+                with h5py.File(path, mode='r') as data:
+                    return np.transpose(data['u'])                        # (N, n, n, T)
         n = self.synthetic_len if self.synthetic_len is not None else (self.train_len + self.valid_len)
         return self.synthetic_trajectories(n, self.n_grid, self.time_steps_input + self.time_steps_output,
                                            self.random_state)

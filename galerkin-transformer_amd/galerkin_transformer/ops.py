@@ -44,7 +44,7 @@ def push_attention_masks(masks):
 # ReLU mask capture for parity runs: with a list installed, every FeedForward forward (ReLU, no hidden dropout) appends
 # the boolean mask hidden > 0 it will differentiate with.  At bench sizes (~1e7 pre-activations per layer) some lie within
 # fp32 rounding of the kink, where the derivative is decided by the last bit of the accumulation; the checker replays
-# these decisions in its float64 model instead of comparing coin flips (oracle feed_forward(relu_mask=...)).
+# these decisions in its float64 model instead of comparing coin flips.
 _relu_mask_sink = [None]
 
 
@@ -307,7 +307,9 @@ class Conv3x3NhwcFn(Function):
         xc = _c(x)
         wf = _conv_k_order(weight.permute(0, 2, 3, 1).reshape(Cout, 9, Cin))       # [Cout][tap][Cin] -> k order
         y = torch.empty(B, Hh, Ww, Cout, dtype=torch.float32, device=x.device)
-        H.gemm(xc, wf, y, B * Hh * Ww, Cout, 9 * Cin, lda=Cin, ldb=9 * Cin, ldc=Cout, conv=(Hh, Ww, Cin))
+        ctx.prec = H.get_precision()             # the backward products run in the arithmetic of the forward
+        H.gemm(xc, wf, y, B * Hh * Ww, Cout, 9 * Cin, lda=Cin, ldb=9 * Cin, ldc=Cout, conv=(Hh, Ww, Cin),
+               precision=ctx.prec)
         ctx.save_for_backward(xc, weight)
         return y
 
@@ -324,16 +326,27 @@ class Conv3x3NhwcFn(Function):
             wd = _conv_k_order(weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9, Cout))     # [Cin][tap'][Cout]
             dx = torch.empty(B, Hh, Ww, Cin, dtype=torch.float32, device=g.device)
             with H.side_branch(dev, B * Hh * Ww):        # the data gradient next to the weight gradient below
-                H.gemm(g, wd, dx, B * Hh * Ww, Cin, 9 * Cout, lda=Cout, ldb=9 * Cout, ldc=Cin, conv=(Hh, Ww, Cout))
+                try:
+                    H.gemm(g, wd, dx, B * Hh * Ww, Cin, 9 * Cout, lda=Cout, ldb=9 * Cout, ldc=Cin, conv=(Hh, Ww, Cout),
+                           precision=ctx.prec)
+                except H.GtNotSupported:         # gt_hip.h: on GT_ENOTSUP the caller takes the library convolution
+                    dx = torch.ops.aten.convolution_backward(
+                        g.permute(0, 3, 1, 2), xc.permute(0, 3, 1, 2), weight, None, [1, 1], [1, 1], [1, 1], False,
+                        [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).contiguous()
         if ctx.needs_input_grad[1]:
             # dw[co][ci][tap] = sum_pix gy[pix][co] x[pix + shift(tap)][ci]
-            if Ww >= 16 and _conv_wgrad[0]:   # nine [Cout, Cin] products over the pixels, K chunks x taps on one launch
-                                              # + a fixed-order reduce (gt_hip.h: cv_wgrad)
+            hip_wgrad = Ww >= 16 and _conv_wgrad[0]
+            if hip_wgrad:       # nine [Cout, Cin] products over the pixels, K chunks x taps on one launch
+                                # + a fixed-order reduce (gt_hip.h: cv_wgrad)
                 dw9 = torch.empty(9, Cout, Cin, dtype=torch.float32, device=g.device)
-                H.gemm(g, xc, dw9, Cout, Cin, B * Hh * Ww, layout_a=1, layout_b=1, lda=Cout, ldb=Cin, ldc=Cin,
-                       batch=(9, 1), c_bs=(Cout * Cin, 0), split_k=0, conv=(Hh, Ww, Cin), conv_wgrad=True)
-                dw = dw9.view(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
-            else:                   # the library's channels-last wrw kernel on the same buffers
+                try:
+                    H.gemm(g, xc, dw9, Cout, Cin, B * Hh * Ww, layout_a=1, layout_b=1, lda=Cout, ldb=Cin, ldc=Cin,
+                           batch=(9, 1), c_bs=(Cout * Cin, 0), split_k=0, conv=(Hh, Ww, Cin), conv_wgrad=True,
+                           precision=ctx.prec)
+                    dw = dw9.view(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
+                except H.GtNotSupported:
+                    hip_wgrad = False
+            if not hip_wgrad:   # the library's channels-last wrw kernel on the same buffers
                 dw = torch.ops.aten.convolution_backward(
                     g.permute(0, 3, 1, 2), xc.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last),
                     None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].contiguous()

@@ -58,10 +58,53 @@ class FlatClipAdam(torch.optim.Optimizer):
         self.sched_dev = torch.tensor([float(lr), float(betas[0])], **f32)    # what schedulers move: lr, beta1
         self.sqnorm = torch.zeros(1, **f32)
         self._sched_host = (float(lr), float(betas[0]))
+        self._built = True
+        self._bind_state()
+
+    # ---- optimizer state: the moments are exposed per parameter (views of the flat buffers) in torch.optim.Adam's
+    # layout, so state_dict() / load_state_dict() -- what run_train pickles as `optimizer_state` -- round-trip them
+    def _bind_state(self):
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.state[p] = {"step": self.step_count, "exp_avg": self.exp_avg[o:o + n].view_as(p),
+                             "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p)}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)              # fills self.state[p] with (copies of) the saved tensors
+        steps = []
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                st, n = self.state.get(p), p.numel()
+                if not st:
+                    continue
+                self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.append(int(torch.as_tensor(st["step"]).reshape(-1)[0].item()))
+            self.step_count.fill_(max(steps) if steps else 0)
+        self._bind_state()
+        self._sched_host = None                           # param_groups may carry another lr / beta1
+        self.sync_schedule()
+
+    def add_param_group(self, param_group):
+        if getattr(self, "_built", False) or len(self.param_groups) >= 1:
+            raise NotImplementedError("FlatClipAdam keeps ONE flat bucket with one set of hyper-parameters: "
+                                      "per-group options / add_param_group are not supported")
+        super().add_param_group(param_group)
+
+    def _check_views(self):
+        """Every p.data must still be the view of the flat parameter bucket made at construction: model.to() / .float()
+        / a manual `p.data = ...` rebinds it, and the optimizer would then update a bucket nobody reads."""
+        base, end = self.flat_param.data_ptr(), self.flat_param.data_ptr() + 4 * self.numel
+        for p, o in zip(self.params, self.offsets):
+            if p.data_ptr() != base + 4 * o or not (base <= p.data_ptr() < end):
+                raise RuntimeError("FlatClipAdam: a parameter no longer lives in the optimizer's flat bucket (the model was "
+                                   "moved / cast / re-bound after the optimizer was built); rebuild the optimizer")
 
     # ---- pieces (bench.py / a DDP loop call them separately to put the all-reduce in between) -----------------
     def gather_grads(self):
-        """flat_grad <- the parameters' .grad (missing gradients count as zero): one multi-tensor copy."""
+        """flat_grad <- the parameters' .grad: one multi-tensor copy.  A parameter without a gradient counts as a zero
+        gradient (its moments decay and weight decay applies), where torch.optim.Adam would skip it: every parameter of
+        the models here takes a gradient in every step."""
         srcs, dsts = [], []
         for p, v in zip(self.params, self.grad_views):
             if p.grad is None:
@@ -82,6 +125,8 @@ class FlatClipAdam(torch.optim.Optimizer):
         from param_groups[0] to their device scalars.  Call it outside a captured graph; the graph reads the scalars."""
         g = self.param_groups[0]
         cur = (float(g["lr"]), float(g["betas"][0]))
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("FlatClipAdam: one parameter group")
         if cur != self._sched_host:
             self.sched_dev.copy_(torch.tensor(cur, dtype=torch.float32), non_blocking=True)
             self._sched_host = cur
@@ -111,6 +156,7 @@ class FlatClipAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._check_views()
         self.sync_schedule()                                  # schedulers write param_groups[0]
         self.gather_grads()
         self.all_reduce()

@@ -112,8 +112,10 @@ def _forward(model, data, device):
 
 def _finish_step(model, loss, optimizer, lr_scheduler, grad_clip):
     loss.backward()
-    if getattr(optimizer, "max_norm", 0):       # optim.FlatClipAdam: the clip is part of its fused step
-        optimizer.max_norm = float(grad_clip)
+    if hasattr(optimizer, "flat_grad") and hasattr(optimizer, "max_norm"):
+        # optim.FlatClipAdam: the clip is part of its fused step, applied to the all-reduced (averaged) gradient -- also
+        # when the optimizer was built with max_norm=None (a local clip here would see the pre-average norm)
+        optimizer.max_norm = float(grad_clip) if grad_clip else 0.0
     else:
         nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
     optimizer.step()

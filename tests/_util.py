@@ -40,3 +40,25 @@ def rel_l2(a, b):
     b = b.detach().double().cpu()
     den = float(b.norm())
     return float((a - b).norm()) / (den if den > 0 else 1.0)
+
+
+def spectral_conv2d_dft_math(x, wlin, blin, w0, w1, modes, act=torch.nn.functional.silu):
+    """The S1..S4 truncated-DFT pipeline of galerkin_transformer/spectral.py restated in plain torch einsums (any
+    device / dtype) on the product's own bases (spectral.dft_bases): pins the formulation against torch.fft on the CPU."""
+    from galerkin_transformer.spectral import dft_bases
+
+    B, n, _, C = x.shape
+    m = modes
+    F1, G2, G3, F4 = (t.to(x.dtype).to(x.device) for t in dft_bases(n, m))
+    X1 = torch.einsum("yk,bxyc->bxkc", F1, x)                                   # [B,n,2m,C]
+    X2 = torch.einsum("rq,brkc->bqkc", G2, X1.reshape(B, 2 * n, m, C))          # [B,4m,m,C]
+    X2 = X2.reshape(B, 2, 2 * m * m, C)
+    xc = torch.complex(X2[:, 0], X2[:, 1])
+    W = torch.cat([w0, w1], dim=2).reshape(w0.shape[0], w0.shape[1], 2 * m * m, 2)
+    yc = torch.einsum("bqi,ioq->bqo", xc, torch.complex(W[..., 0], W[..., 1]))
+    Y = torch.stack([yc.real, yc.imag], 1)                                      # [B,2,2m*m,Co]
+    Co = Y.shape[-1]
+    Z = torch.einsum("rq,bqkc->brkc", G3, Y.reshape(B, 4 * m, m, Co))           # [B,2n,m,Co]
+    Z = Z.reshape(B, n, 2 * m, Co)
+    out = torch.einsum("yk,bxko->bxyo", F4, Z)
+    return act(out + torch.nn.functional.linear(x, wlin, blin))

@@ -158,7 +158,7 @@ def _zero_dropout_cfg(bench):
 @pytest.mark.parametrize("mode,scaler_act", [("replay", "relu"), ("off", "silu")])
 def test_whole_model_darcy141_vs_oracle(gpu_device, mode, scaler_act):
     """FourierTransformer2D of the bench configuration (down-scaler -> 6 layers -> implicit-conv up-scaler -> upsample_fc
-    -> 2 x SpectralConv2d -> head) at its own size, B = 18: prediction and every parameter gradient vs the float64 oracle
+    -> 2 x SpectralConv2d -> head) at its own size, B = 18 / 9: prediction and every parameter gradient vs the float64 oracle
     (FeedForward ReLU masks replayed).  The prediction is held to 1e-5 (the north-star bar) in both runs.
 
     ("replay", "relu") is the bench configuration with the attention masks replayed (the reference applies that dropout
@@ -179,7 +179,7 @@ def test_whole_model_darcy141_vs_oracle(gpu_device, mode, scaler_act):
     import galerkin_transformer as gt
     from galerkin_transformer import _hip, ops
     from oracle import galerkin_oracle as O
-    B = 18
+    B = 18 if mode == "replay" else 9            # T = 33 282 / 16 641: both on the packed-B kernels (T >= 16 384)
     cfg = _zero_dropout_cfg(bench)
     cfg["downscaler_activation"] = scaler_act
     torch.manual_seed(41)

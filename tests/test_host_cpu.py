@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("name", ["sconv2d_odd", "sconv2d_even_flat", "sconv2d_relu"])
 def test_truncated_dft_equals_fft(name):
     """S1..S4 GEMM pipeline (galerkin_transformer/spectral.py) == rfft2/irfft2 oracle, in fp64."""
-    from galerkin_transformer.spectral import spectral_conv2d_reference_math
+    from _util import spectral_conv2d_dft_math as spectral_conv2d_reference_math
     g = Golden(name)
     m = g.meta
     sd = {k: v.double() for k, v in g.sd.items()}

@@ -117,7 +117,9 @@ def test_ns_lite_surface_and_rollout_plumbing():
     for name in ("NavierStokesDatasetLite", "FourierTransformer2DLite", "train_batch_ns", "validate_epoch_ns",
                  "WeightedL2Loss2d", "run_train", "get_seed", "OneCycleLR", "DataLoader", "defaultdict"):
         assert hasattr(NS, name), name
-    ds = NS.NavierStokesDatasetLite(data_path="/nonexistent/ns_V1000_N5000_T50.mat", train_len=6, valid_len=2)
+    with pytest.raises(FileNotFoundError):            # a named data file that is not there fails loudly (as the reference)
+        NS.NavierStokesDatasetLite(data_path="/nonexistent/ns_V1000_N5000_T50.mat", train_len=6, valid_len=2)
+    ds = NS.NavierStokesDatasetLite(train_len=6, valid_len=2, synthetic_len=8)
     it = ds[0]
     assert len(ds) == 6 and it["node"].shape == (64, 64, 10) and it["target"].shape == (64, 64, 10)
     assert it["target_grad"].shape == (64, 64, 2, 10) and it["pos"].shape == (4096, 2) and it["grid"].shape == (64, 64, 2)

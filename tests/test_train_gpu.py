@@ -197,3 +197,79 @@ def test_flat_clip_adam_matches_torch(gpu_device):
         if max_norm:
             ref = torch.sqrt(sum((gr ** 2).sum() for gr in grads)).item()
             assert abs(opt_a.grad_norm() - ref) < 1e-5 * ref
+
+
+def test_ddp_step_equals_single_process(gpu_device, tmp_path):
+    """SURVEY section 4(iv) / reference libs/utils_ft.py:656-681 under DDP: two ranks (gloo, sharing cuda:0) with B samples
+    each, FlatClipAdam's in-place flat all-reduce with the 1/world average folded into gt_grad_sqnorm / gt_adam_clip_step,
+    dropout off == ONE process on the concatenated 2B batch: the averaged gradient and its clip norm to 1e-5, the
+    parameters after the step to 1e-4 (Adam's first step is ~lr * sign(g): an element whose gradient sits in the fp32
+    noise of the two summation orders may move the other way)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "_ddp_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    f2, f1 = str(tmp_path / "ddp.pt"), str(tmp_path / "single.pt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", worker, f2, "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    out = subprocess.run([sys.executable, worker, f1, "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    a, b = torch.load(f2), torch.load(f1)
+    assert a["world"] == 2 and b["world"] == 1
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    assert rel(a["grad"], b["grad"]) < 1e-5, rel(a["grad"], b["grad"])
+    assert abs(a["norm"] - b["norm"]) < 1e-5 * b["norm"]
+    assert rel(a["param"], b["param"]) < 1e-4, rel(a["param"], b["param"])
+
+
+def test_flat_clip_adam_state_dict_roundtrip(gpu_device):
+    """optimizer.state_dict() (what run_train pickles as `optimizer_state`) carries the moments and the step count: a
+    fresh FlatClipAdam that loads it continues exactly like the original; a torch.optim.Adam state loads too; and a
+    parameter re-bound after construction (model.to / .float) is refused instead of silently updating a stale bucket."""
+    import copy
+    import galerkin_transformer as gt
+    dev = gpu_device
+    g = torch.Generator().manual_seed(9)
+    shapes = [(5, 7), (33,), (2, 3, 4)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(5)]
+
+    def mk(vals):
+        ps = [torch.nn.Parameter(v.clone().to(dev)) for v in vals]
+        return ps, gt.FlatClipAdam(ps, lr=2e-3, max_norm=0.9)
+
+    pa, oa = mk(init)
+    for it in range(3):
+        for p, gr in zip(pa, grads[it]):
+            p.grad = gr.to(dev).clone()
+        oa.step()
+    sd = copy.deepcopy(oa.state_dict())
+    assert int(sd["state"][0]["step"].item()) == 3 and sd["state"][1]["exp_avg"].abs().sum() > 0
+    pb, ob = mk([p.detach().cpu() for p in pa])
+    ob.load_state_dict(sd)
+    for it in range(3, 5):
+        for p, q, gr in zip(pa, pb, grads[it]):
+            p.grad, q.grad = gr.to(dev).clone(), gr.to(dev).clone()
+        oa.step(); ob.step()
+    torch.cuda.synchronize()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p, q)
+    # torch.optim.Adam's state has the same layout
+    pt = [torch.nn.Parameter(v.clone().to(dev)) for v in init]
+    ot = torch.optim.Adam(pt, lr=2e-3)
+    for p, gr in zip(pt, grads[0]):
+        p.grad = gr.to(dev).clone()
+    ot.step()
+    pc, oc = mk([p.detach().cpu() for p in pt])
+    oc.load_state_dict(ot.state_dict())
+    assert int(oc.step_count.item()) == 1 and torch.allclose(oc.state[pc[0]]["exp_avg"], ot.state[pt[0]]["exp_avg"])
+    # re-bound parameter
+    pa[0].data = pa[0].data.clone()
+    pa[0].grad = grads[0][0].to(dev)
+    with pytest.raises(RuntimeError):
+        oa.step()
+    with pytest.raises(NotImplementedError):
+        oa.add_param_group({"params": [torch.nn.Parameter(torch.zeros(3, device=dev))]})

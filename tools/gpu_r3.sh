@@ -19,7 +19,7 @@ for step in "$@"; do
   case $name in
     newtests) ( time timeout 1500 python -m pytest tests/test_bench_kernels_gpu.py -q -s ) > $O/newtests.log 2>&1; tail -5 $O/newtests.log;;
     suite) ( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/suite.log 2>&1; grep -E "passed|failed|FAILED|Error" $O/suite.log | tail -15;;
-    pytest) ( time timeout 1200 python -m pytest $arg -q -x ) > $O/pytest_$(echo $arg | tr '/:. ' '____' | cut -c1-60).log 2>&1; tail -5 $O/pytest_*.log | tail -8;;
+    pytest) L=$O/pytest_$(echo $arg | tr '/:. ' '____' | cut -c1-60).log; ( time timeout 1200 python -m pytest $arg -q -x ) > $L 2>&1; grep -E "passed|failed|^E  " $L | cut -c1-300 | tail -n 8;;
     micro) ( env $(echo $arg | tr ',' ' ') timeout 300 python tools/x3_micro.py 2>>$O/micro.err | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); r['env']='$arg'; print(json.dumps(r))" ) >> $O/micro.jsonl
            python -c "import sys,json; r=json.loads(open('$O/micro.jsonl').read().strip().splitlines()[-1]); print('$arg', ' | '.join('%s %.0f' % (k[:18], v['us']) for k, v in r.items() if isinstance(v, dict)))";;
     bench) ( env $(echo $arg | tr ',' ' ') timeout 400 python bench.py $BENCH_FAST 2>$O/bench.err | tail -1 ) > $O/bench_$(echo "$arg" | tr '=,/ ' '____').json
