@@ -730,12 +730,14 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
     if (d->cv_c > 0) {
         if (!pl.x3 || (!d->cv_wgrad && pl.split != 1)) return GT_ENOTSUP;
         p.cv_H = d->cv_h; p.cv_W = d->cv_w; p.cv_C = d->cv_c; p.cv_wgrad = d->cv_wgrad != 0;
+        // lda (forward / data gradient) / ldb (weight gradient) = the pixel pitch of the image: >= cv_c, so a convolution can
+        // read a channel slice of a wider channels-last buffer in place (values below cv_c mean "dense")
         if (d->cv_wgrad) {
-            p.ldb = d->cv_c; p.b_bs0 = p.b_bs1 = 0;
-            p.b_vec = al16(d->B) && m4(d->cv_c);
+            p.ldb = d->ldb > d->cv_c ? d->ldb : d->cv_c; p.b_bs0 = p.b_bs1 = 0;
+            p.b_vec = al16(d->B) && m4(p.ldb);
         } else {
-            p.lda = d->cv_c;
-            p.a_vec = al16(d->A);
+            p.lda = d->lda > d->cv_c ? d->lda : d->cv_c;
+            p.a_vec = al16(d->A) && m4(p.lda);
         }
     }
 

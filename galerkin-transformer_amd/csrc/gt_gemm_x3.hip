@@ -458,8 +458,8 @@ __device__ __forceinline__ void x3r_split(const float (&v)[8], bf16x8 (&out)[PLA
 // line is then read by its nine taps within 18 consecutive stages and stays in L2; taps-outermost measured 3.07 GB of
 // fabric reads per launch for 0.39 GB of activations (rocprofv3 FETCH_SIZE x 2, profiles/r02q_pmc_step.json).
 __device__ __forceinline__ void x3r_issue_conv(const float* const (&rowp)[2], const int (&ok)[2], int tap, int c0, int W,
-                                               int C, char* img, int wave, int lane) {
-    const int shift = ((tap / 3 - 1) * W + (tap % 3 - 1)) * C + c0;
+                                               int64_t ld, char* img, int wave, int lane) {
+    const int64_t shift = (int64_t)((tap / 3 - 1) * W + (tap % 3 - 1)) * ld + c0;      // ld = pixel pitch (>= channels)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q = wave * 2 + i;
@@ -472,7 +472,7 @@ __device__ __forceinline__ void x3r_issue_conv(const float* const (&rowp)[2], co
 // Weight-gradient flavour (cv_wgrad): the x-contiguous B image of a stage is 16 consecutive pixels p of the tap-shifted
 // activations, B(p, n) = X[p + (dy, dx)][n]; rows whose neighbour falls outside the picture (or p >= kend) read zero.
 // (y, x) = the lane's two pixels of the current stage; W >= 16, so one stage wraps at most one image row.
-__device__ __forceinline__ void x3r_issue_convw(const float* __restrict__ X, int C, int n0, int N, int k0, int kend,
+__device__ __forceinline__ void x3r_issue_convw(const float* __restrict__ X, int64_t C, int n0, int N, int k0, int kend,
                                                 const int (&py)[2], const int (&px)[2], int dy, int dx, int H, int W,
                                                 char* img, int wave, int lane) {
 #pragma unroll
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
                 for (int t = 0; t < 9; ++t)
                     ok |= (((unsigned)(y + t / 3 - 1) < (unsigned)p.cv_H) && ((unsigned)(x + t % 3 - 1) < (unsigned)p.cv_W)) << t;
                 cv_ok[i] = ok;
-                cv_row[i] = A + (int64_t)m * p.cv_C;
+                cv_row[i] = A + (int64_t)m * p.lda;
             }
         }
     }
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
         char* st = smem + (s % R) * X3R_STAGE;
         const int k0 = kbeg + s * X3_BK;
         if (CV == 1) {
-            x3r_issue_conv(cv_row, cv_ok, cv_tap, cv_c0, p.cv_W, p.cv_C, st, wave, lane);
+            x3r_issue_conv(cv_row, cv_ok, cv_tap, cv_c0, p.cv_W, p.lda, st, wave, lane);
             cv_c0 += X3_BK;                        // channel block first, taps second, channel blocks last (gt_hip.h)
             if ((cv_c0 & (cv_cb - 1)) == 0) {
                 cv_c0 -= cv_cb;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
             x3r_issue<LA>(A, p.lda, m0, p.M, k0, kend, st, wave, lane);
         }
         if (CV == 2) {
-            x3r_issue_convw(p.B, p.cv_C, n0, p.N, k0, kend, cw_y, cw_x, z / 3 - 1, z % 3 - 1, p.cv_H, p.cv_W,
+            x3r_issue_convw(p.B, p.ldb, n0, p.N, k0, kend, cw_y, cw_x, z / 3 - 1, z % 3 - 1, p.cv_H, p.cv_W,
                             st + X3R_OP, wave, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {          // the next stage's pixels: 16 further along the row-major image
@@ -708,15 +708,21 @@ __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict_
 #ifndef GT_X3P_BLOCKS                              // resident blocks per CU the general instances are compiled for
 #define GT_X3P_BLOCKS 3
 #endif
-template <int LA, int HN, int CV>                  // CV: 0 plain, 1 implicit 3x3 convolution on A
+// BN = 128: 2 x 2 waves of 64 x 64;  BN = 64 (narrow outputs: the 42 / 44-channel convolutions of the down-scaler, padded to
+// 48): 4 x 1 waves of 32 x 64 -- a wave then splits ONE 32-row tile of A per stage for its twelve MFMAs, the same split-to-
+// matrix ratio as the wide tile, and a 48-column product wastes a quarter of the tile instead of five eighths.
+template <int LA, int HN, int CV, int BN = 128>     // CV: 0 plain, 1 implicit 3x3 convolution on A
 __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_kernel(const GemmP p) {
+    constexpr int MI = BN == 64 ? 1 : 2;           // 32-row tiles of A per wave
+    static_assert(BN == 128 || (BN == 64 && HN == 0 && LA == 0), "the narrow tile serves plain / convolution launches");
     constexpr int R = X3P_R, PLANES = 3;
     constexpr int STG = (HN > 0 ? X3_HN_STG : X3_EP_STG) * 4 * 4;       // bytes of epilogue staging, four waves
     constexpr int SMEM = R * X3R_OP > STG ? R * X3R_OP : STG;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = BN == 64 ? wave : wave >> 1, wn = BN == 64 ? 0 : wave & 1;
+    const int wrow = BN == 64 ? wm * 32 : wm * 64; // first tile row of this wave
     const int lr = lane & 31, lh = lane >> 5;
     int tile;
     {
@@ -725,14 +731,14 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
     const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-    const int m0 = tm * X3_BM, n0 = tn * X3_BN;
+    const int m0 = tm * X3_BM, n0 = tn * BN;
     const int kend = p.K;
     const float* A = p.A;
     const uint32_t akey = drop_key_dev(p.a_drop);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -753,14 +759,14 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
                 for (int t = 0; t < 9; ++t)
                     ok |= (((unsigned)(y + t / 3 - 1) < (unsigned)p.cv_H) && ((unsigned)(x + t % 3 - 1) < (unsigned)p.cv_W)) << t;
                 cv_ok[i] = ok;
-                cv_row[i] = A + (int64_t)m * p.cv_C;
+                cv_row[i] = A + (int64_t)m * p.lda;
             }
         }
     }
     auto issue = [&](int s) {                      // A stage s -> slot s % R : 2 load instructions per wave
         char* st = smem + (s % R) * X3R_OP;
         if (CV == 1) {
-            x3r_issue_conv(cv_row, cv_ok, cv_tap, cv_c0, p.cv_W, p.cv_C, st, wave, lane);
+            x3r_issue_conv(cv_row, cv_ok, cv_tap, cv_c0, p.cv_W, p.lda, st, wave, lane);
             cv_c0 += X3_BK;                        // channel block first, taps second, channel blocks last (gt_hip.h)
             if ((cv_c0 & (cv_cb - 1)) == 0) {
                 cv_c0 -= cv_cb;
@@ -792,14 +798,14 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bn[j][pl]) : "v"(voff), "s"(sp));
             }
     };
-    bf16x8 am[2][PLANES];
+    bf16x8 am[MI][PLANES];
     auto splita = [&](int kt) {
         const char* sa = smem + (kt % R) * X3R_OP;
         const int kbase = kt * X3_BK + 8 * lh;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
             float v[8];
-            const int row = wm * 64 + 32 * i + lr;
+            const int row = wrow + 32 * i + lr;
             x3r_frag<LA>(sa, row, lh, v);
             if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, 0, m0 + row, kbase, v);
 #ifdef GT_ABL_X3_NOSPLIT_A       // ablation builds (tools/ablate_x3.sh): timing only, results are wrong
@@ -817,7 +823,7 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
                 const int pb = s - pa;
                 if (pb < 0 || pb >= PLANES) continue;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(bn[j][pb], am[i][pa], acc[i][j]);
             }
@@ -864,11 +870,11 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
 #endif
 
     __syncthreads();                               // every wave is done with the ring: its first slots become staging
-    if (HN > 0)
+    if constexpr (HN > 0)
         x3_epilogue_hn<(HN > 0 ? HN : 32), 2>(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, lane,
                                                reinterpret_cast<float*>(smem) + wave * X3_HN_STG);
     else
-        x3_epilogue<2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * X3_EP_STG, 0, 0, 0, 0);
+        x3_epilogue<MI>(p, acc, m0 + wrow, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * X3_EP_STG, 0, 0, 0, 0);
 }
 
 // operands the ring kernel's direct loads can take (see its header comment)
@@ -882,7 +888,10 @@ static bool x3r_ok(const GemmP& p, int layout_a, int layout_b) {
 
 bool x3_shape_ok(const gt_gemm_desc* d) {
     // whole 128 x 128 tiles dominate (the padding of a partial edge tile is bounded by the sizes below)
-    return (d->ep_mode == GT_EP_NORMAL || d->ep_mode == GT_EP_HEADNORM) && d->M >= 96 && d->N >= 96 && d->K >= 16;
+    if (d->ep_mode != GT_EP_NORMAL && d->ep_mode != GT_EP_HEADNORM) return false;
+    // narrow implicit convolutions (N >= 32) ride on the 64-wide tile of the packed-B kernel
+    if (d->cv_c > 0 && !d->cv_wgrad && d->N >= 32 && d->N < 96 && d->M >= 16384 && d->K >= 16) return true;
+    return d->M >= 96 && d->N >= 96 && d->K >= 16;
 }
 
 // the fused head-norm epilogue exists on the ring kernel, three planes, 16-byte aligned everything
@@ -934,6 +943,15 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
     if (p.Bp) {                                    // packed-B kernel (x3_packed_ok said yes)
         const int hn = p.ep_mode == GT_EP_HEADNORM ? p.hn_dk : 0;
         if (hn && !x3_headnorm_ok(p, layout_a, 0, planes)) return GT_ENOTSUP;
+        if (p.N <= 64 && !hn && layout_a == 0) {   // narrow output: 128 x 64 tiles (p.tiles_n counts 128-wide tiles: one)
+            GemmP q = p;
+            q.tiles_n = (p.N + 63) / 64;
+            const dim3 gn((unsigned)(p.tiles_m * q.tiles_n));
+            if (p.cv_C > 0) hipLaunchKernelGGL((gemm_x3p_kernel<0, 0, 1, 64>), gn, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3p_kernel<0, 0, 0, 64>), gn, dim3(256), 0, st, q);
+            GT_LAUNCH_CHECK();
+            return 0;
+        }
         if (p.cv_C > 0) hipLaunchKernelGGL((gemm_x3p_kernel<0, 0, 1>), grid, dim3(256), 0, st, p);
         else if (hn == 16) hipLaunchKernelGGL((gemm_x3p_kernel<0, 16, 0>), grid, dim3(256), 0, st, p);
         else if (hn == 32) hipLaunchKernelGGL((gemm_x3p_kernel<0, 32, 0>), grid, dim3(256), 0, st, p);
@@ -991,7 +1009,7 @@ bool x3_packed_ok(const gt_gemm_desc* d, int planes, int split) {
     if (d->cv_c > 0 && d->cv_wgrad) return false;
     if (d->M < 16384 || d->M < 8 * (int64_t)d->N) return false;       // below that the extra (pack) launch is not paid back
     const bool a16 = (reinterpret_cast<uintptr_t>(d->A) & 15) == 0;
-    if (d->cv_c > 0) return a16 && d->layout_a == 0 && (d->cv_c & 15) == 0;
+    if (d->cv_c > 0) return a16 && d->layout_a == 0 && (d->cv_c & 15) == 0 && (d->lda <= d->cv_c || (d->lda & 3) == 0);
     if (!a16 || (d->lda & 3)) return false;
     return d->layout_a == 0 ? (d->K & 3) == 0 : (d->M & 3) == 0;
 }
@@ -1015,8 +1033,8 @@ int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipSt
 const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes, int hn_dk) {
     static thread_local char buf[112];
     if (p.Bp) {
-        snprintf(buf, sizeof(buf), "void gt::gemm_x3p_kernel<%d, %d, %d>(gt::GemmP)", p.cv_C > 0 ? 0 : layout_a, hn_dk,
-                 p.cv_C > 0 ? 1 : 0);
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3p_kernel<%d, %d, %d, %d>(gt::GemmP)", p.cv_C > 0 ? 0 : layout_a, hn_dk,
+                 p.cv_C > 0 ? 1 : 0, (p.N <= 64 && !hn_dk && layout_a == 0) ? 64 : 128);
         return buf;
     }
     if (hn_dk > 0) {

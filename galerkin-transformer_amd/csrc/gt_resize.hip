@@ -55,7 +55,18 @@ struct ResizeP {
     // optional affine term added to the resized value of channel c at output pixel q (NHWC outputs only):
     //   + bias[c] + sum_j rp_a[q*rp_lda + j] * rp_b[c*rp_ldb + j]
     const float* bias; int rp; const float* rp_a; int64_t rp_lda; const float* rp_b; int64_t rp_ldb;
+    // channels-last kernels only: the INPUT side (fwd: x, bwd: dx) is a padded concatenation of three column segments of
+    // segp channels each (ops.scaler_conv_chain): real channel c lives at padded column c + (segp - seg) * min(c / seg, 2);
+    // seg == 0: dense.
+    int seg, segp;
 };
+
+// padded column of real channel c
+__device__ __forceinline__ int seg_col(const ResizeP& p, int c) { return c + (p.segp - p.seg) * min(c / p.seg, 2); }
+// 4 consecutive real channels c .. c+3 of the padded-segment pixel at px (floats)
+__device__ __forceinline__ f32x4 seg_load4(const ResizeP& p, const float* __restrict__ px, int c) {
+    return f32x4{px[seg_col(p, c)], px[seg_col(p, c + 1)], px[seg_col(p, c + 2)], px[seg_col(p, c + 3)]};
+}
 
 __device__ __forceinline__ f32x4 resize_affine(const ResizeP& p, f32x4 v, int b, int c, int oy, int ox) {
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c);
@@ -443,6 +454,7 @@ struct ConvResizeP {
     int B, Cin, Cout, H, W, Ho, Wo;
     float sy, sx;
     DropDev drop;
+    int y_nhwc;                                        // y (and g) channels-last [B, Ho, Wo, Cout] instead of channels-first
 };
 
 __device__ __forceinline__ void load_patch(const float* __restrict__ xp, int H, int W, int iy, int ix,
@@ -507,7 +519,8 @@ __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP 
         // same association as the stand-alone resize: l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
         const float r = ay.l0 * (ax.l0 * cv[0] + ax.l1 * cv[1]) + ay.l1 * (ax.l0 * cv[2] + ax.l1 * cv[3]);
         (void)w00; (void)w01; (void)w10; (void)w11;
-        p.y[((int64_t)b * p.Cout + c) * p.Ho * p.Wo + e] = fmaxf(r, 0.f);
+        if (p.y_nhwc) p.y[((int64_t)b * p.Ho * p.Wo + e) * p.Cout + c] = fmaxf(r, 0.f);
+        else p.y[((int64_t)b * p.Cout + c) * p.Ho * p.Wo + e] = fmaxf(r, 0.f);
     }
 }
 
@@ -558,7 +571,7 @@ __global__ __launch_bounds__(256) void conv_resize_bwd_kernel(const ConvResizeP 
 #pragma unroll          // full unroll: acc[j][..] must be statically indexed to stay in registers
         for (int j = 0; j < CRB_CG; ++j) {
             const int c = min(c0 + j, p.Cout - 1);                 // clamped: tail channels are not stored
-            const int64_t o = ((int64_t)b * p.Cout + c) * oplane + e;
+            const int64_t o = p.y_nhwc ? ((int64_t)b * oplane + e) * p.Cout + c : ((int64_t)b * p.Cout + c) * oplane + e;
             const float go = (p.y[o] > 0.f) ? p.g[o] : 0.f;
             float cv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -633,6 +646,14 @@ __global__ __launch_bounds__(256) void resize_nhwc_fwd_kernel(const ResizeP p) {
     for (int r = 0; r < RN_RPT; ++r) {
         const int oy = min(oy0 + r, p.Ho - 1);
         ay[r] = axis_of(oy, p.sy, p.Hi);
+        if (p.seg) {          // padded three-segment input: gather the four real channels (block-uniform branch)
+            const int CP3 = 3 * p.segp;
+            v[r][0] = seg_load4(p, p.x + addr<true>(b, 0, ay[r].i0, ax.i0, CP3, p.Hi, p.Wi), c);
+            v[r][1] = seg_load4(p, p.x + addr<true>(b, 0, ay[r].i0, ax.i1, CP3, p.Hi, p.Wi), c);
+            v[r][2] = seg_load4(p, p.x + addr<true>(b, 0, ay[r].i1, ax.i0, CP3, p.Hi, p.Wi), c);
+            v[r][3] = seg_load4(p, p.x + addr<true>(b, 0, ay[r].i1, ax.i1, CP3, p.Hi, p.Wi), c);
+            continue;
+        }
         v[r][0] = *reinterpret_cast<const f32x4*>(p.x + addr<true>(b, c, ay[r].i0, ax.i0, p.C, p.Hi, p.Wi));
         v[r][1] = *reinterpret_cast<const f32x4*>(p.x + addr<true>(b, c, ay[r].i0, ax.i1, p.C, p.Hi, p.Wi));
         v[r][2] = *reinterpret_cast<const f32x4*>(p.x + addr<true>(b, c, ay[r].i1, ax.i0, p.C, p.Hi, p.Wi));
@@ -656,11 +677,23 @@ __global__ __launch_bounds__(256) void resize_nhwc_fwd_kernel(const ResizeP p) {
 // gather form of the backward (no atomics), same thread mapping over an input row; falls back to the tiled
 // kernel's generic loop when an axis has more than RS_MAXT contributing outputs
 __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
-    const int C4 = p.C >> 2;
+    // dx has p.C channels, or (p.seg != 0) the three padded column segments of 3 * p.segp channels: a thread owns four
+    // consecutive dx columns; with segments each maps to a real channel of g or to a padding column (gradient zero)
+    const int CX = p.seg ? 3 * p.segp : p.C;
+    const int C4 = CX >> 2;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= p.Wi * C4) return;
     const int ix = e / C4, c = (e - ix * C4) * 4;
     const int iy = blockIdx.y, b = blockIdx.z;
+    int cr[4] = {c, c + 1, c + 2, c + 3};          // real channel of each column, -1: padding
+    if (p.seg) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sgi = (c + j) / p.segp, r = (c + j) - sgi * p.segp;
+            const int width = sgi < 2 ? p.seg : p.C - 2 * p.seg;
+            cr[j] = r < width ? sgi * p.seg + r : -1;
+        }
+    }
     const Taps ty = taps_of(iy, p.sy, p.Hi, p.Ho);
     const Taps tx = taps_of(ix, p.sx, p.Wi, p.Wo);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -671,12 +704,23 @@ __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
 #pragma unroll
             for (int jx = 0; jx < RS_MAXT; ++jx) {
                 if (jx < tx.n) {
-                    const int64_t o = addr<true>(b, c, ty.lo + jy, tx.lo + jx, p.C, p.Ho, p.Wo);
-                    f32x4 g = *reinterpret_cast<const f32x4*>(p.x + o);
-                    if (p.gate) {
-                        const f32x4 y = *reinterpret_cast<const f32x4*>(p.gate + o);
+                    f32x4 g;
+                    if (p.seg) {
+                        const int64_t o = addr<true>(b, 0, ty.lo + jy, tx.lo + jx, p.C, p.Ho, p.Wo);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) g[j] = 0.f;
+                        for (int j = 0; j < 4; ++j) {
+                            float gv = cr[j] >= 0 ? p.x[o + cr[j]] : 0.f;
+                            if (p.gate && cr[j] >= 0 && !(p.gate[o + cr[j]] > 0.f)) gv = 0.f;
+                            g[j] = gv;
+                        }
+                    } else {
+                        const int64_t o = addr<true>(b, c, ty.lo + jy, tx.lo + jx, p.C, p.Ho, p.Wo);
+                        g = *reinterpret_cast<const f32x4*>(p.x + o);
+                        if (p.gate) {
+                            const f32x4 y = *reinterpret_cast<const f32x4*>(p.gate + o);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) g[j] = 0.f;
+                        }
                     }
                     racc += tx.w[jx] * g;
                 }
@@ -684,7 +728,7 @@ __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
             acc += ty.w[jy] * racc;
         }
     }
-    *reinterpret_cast<f32x4*>(p.y + addr<true>(b, c, iy, ix, p.C, p.Hi, p.Wi)) = acc;
+    *reinterpret_cast<f32x4*>(p.y + addr<true>(b, c, iy, ix, CX, p.Hi, p.Wi)) = acc;
 }
 
 // true when no input index of the axis has more than RS_MAXT contributing outputs (host-side bound:
@@ -705,7 +749,7 @@ extern "C" int gt_bilinear2d_fwd_affine(const float* x, float* y, int32_t B, int
     if (int rc = check_resize(x, y, B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc)) return rc;
     if (act != GT_ACT_NONE && act != GT_ACT_RELU) return GT_ENOTSUP;
     ResizeP p{x, y, nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho), scale_of(Wi, Wo), act, ceil_div(Wo, RS_TX),
-              nullptr, 0, nullptr, 0, nullptr, 0};
+              nullptr, 0, nullptr, 0, nullptr, 0, 0, 0};
     if (aff && (aff->bias || aff->rp)) {
         if (!(in_nhwc && out_nhwc)) return GT_ENOTSUP;
         if (aff->rp < 0 || aff->rp > 8 || (aff->rp && (!aff->rp_a || !aff->rp_b))) return GT_EINVAL;
@@ -741,7 +785,7 @@ extern "C" int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx
     if (act == GT_ACT_RELU && !y_saved) return GT_EINVAL;
     if (out_nhwc && y_saved && (reinterpret_cast<uintptr_t>(y_saved) & 15)) return GT_EALIGN;
     ResizeP p{g, dx, act == GT_ACT_RELU ? y_saved : nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho),
-              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX), nullptr, 0, nullptr, 0, nullptr, 0};
+              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX), nullptr, 0, nullptr, 0, nullptr, 0, 0, 0};
     dim3 grid((unsigned)(p.xtiles * ceil_div(C, RS_TC)), (unsigned)Hi, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     if (!out_nhwc && !in_nhwc) {
@@ -759,6 +803,42 @@ extern "C" int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx
     return 0;
 }
 
+// Channels-last resize whose INPUT is the padded three-segment buffer of ops.scaler_conv_chain (gt_hip.h)
+static int check_seg(int C, int seg, int segp) {
+    if (seg <= 0 || segp < seg || (segp & 3) || (C & 3) || C <= 2 * seg || C - 2 * seg > segp) return GT_EINVAL;
+    return 0;
+}
+
+extern "C" int gt_bilinear2d_seg_fwd(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
+                                     int32_t Wo, int32_t act, int32_t seg, int32_t segp, void* stream) {
+    if (int rc = check_resize(x, y, B, C, Hi, Wi, Ho, Wo, 1, 1)) return rc;
+    if (int rc = check_seg(C, seg, segp)) return rc;
+    if (act != GT_ACT_NONE && act != GT_ACT_RELU) return GT_ENOTSUP;
+    if (ceil_div(Ho, RN_RPT) > 65535) return GT_EINVAL;
+    ResizeP p{x, y, nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho), scale_of(Wi, Wo), act, ceil_div(Wo, RS_TX),
+              nullptr, 0, nullptr, 0, nullptr, 0, seg, segp};
+    dim3 ng((unsigned)ceil_div((int64_t)Wo * (C / 4), 256), (unsigned)ceil_div(Ho, RN_RPT), (unsigned)B);
+    hipLaunchKernelGGL(resize_nhwc_fwd_kernel, ng, dim3(256), 0, (hipStream_t)stream, p);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_bilinear2d_seg_bwd(const float* g, const float* y_saved, float* dx, int32_t B, int32_t C, int32_t Hi,
+                                     int32_t Wi, int32_t Ho, int32_t Wo, int32_t act, int32_t seg, int32_t segp,
+                                     void* stream) {
+    if (int rc = check_resize(dx, g, B, C, Hi, Wi, Ho, Wo, 1, 1)) return rc;
+    if (int rc = check_seg(C, seg, segp)) return rc;
+    if (act != GT_ACT_NONE && act != GT_ACT_RELU) return GT_ENOTSUP;
+    if (act == GT_ACT_RELU && !y_saved) return GT_EINVAL;
+    if (!taps_fit(Hi, Ho) || !taps_fit(Wi, Wo)) return GT_ENOTSUP;
+    ResizeP p{g, dx, act == GT_ACT_RELU ? y_saved : nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho),
+              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX), nullptr, 0, nullptr, 0, nullptr, 0, seg, segp};
+    dim3 ng((unsigned)ceil_div((int64_t)Wi * (3 * segp / 4), 256), (unsigned)Hi, (unsigned)B);
+    hipLaunchKernelGGL(resize_nhwc_bwd_kernel, ng, dim3(256), 0, (hipStream_t)stream, p);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
 static int check_conv_resize(const void* x, const void* w, const void* y, int B, int Cin, int Cout, int H, int W,
                              int Ho, int Wo, const gt_dropout* drop, int act) {
     if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return GT_EINVAL;
@@ -769,12 +849,12 @@ static int check_conv_resize(const void* x, const void* w, const void* y, int B,
     return 0;
 }
 
-extern "C" int gt_conv3x3_resize_fwd(const float* x, const float* w, float* y, int32_t B, int32_t Cin,
-                                     int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
-                                     const gt_dropout* drop, int32_t act, void* stream) {
+static int conv_resize_fwd(const float* x, const float* w, float* y, int32_t B, int32_t Cin,
+                           int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                           const gt_dropout* drop, int32_t act, int y_nhwc, void* stream) {
     if (int rc = check_conv_resize(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
     ConvResizeP p{x, w, y, nullptr, nullptr, B, Cin, Cout, H, W, Ho, Wo, scale_of(H, Ho), scale_of(W, Wo),
-                  make_drop(drop)};
+                  make_drop(drop), y_nhwc};
     dim3 grid((unsigned)ceil_div((int64_t)Ho * Wo, 256), (unsigned)ceil_div(Cout, CR_CH), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     switch (Cin) {
@@ -787,20 +867,31 @@ extern "C" int gt_conv3x3_resize_fwd(const float* x, const float* w, float* y, i
     return 0;
 }
 
+extern "C" int gt_conv3x3_resize_fwd(const float* x, const float* w, float* y, int32_t B, int32_t Cin,
+                                     int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                     const gt_dropout* drop, int32_t act, void* stream) {
+    return conv_resize_fwd(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act, 0, stream);
+}
+extern "C" int gt_conv3x3_resize_fwd_nhwc(const float* x, const float* w, float* y, int32_t B, int32_t Cin,
+                                          int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                          const gt_dropout* drop, int32_t act, void* stream) {
+    return conv_resize_fwd(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act, 1, stream);
+}
+
 extern "C" int64_t gt_conv3x3_resize_bwd_ws_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W) {
     (void)H; (void)W;      // partial slabs are per (image, strip of OUTPUT pixels): bounded by the input size
     return (int64_t)B * ceil_div((int64_t)H * W, 256 * CRB_PXT) * Cout * Cin * 9 * (int64_t)sizeof(float);
 }
 
-extern "C" int gt_conv3x3_resize_bwd(const float* g, const float* y, const float* x, const float* w, int32_t B,
-                                     int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
-                                     const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
-                                     void* stream) {
+static int conv_resize_bwd(const float* g, const float* y, const float* x, const float* w, int32_t B,
+                           int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                           const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes, int y_nhwc,
+                           void* stream) {
     if (int rc = check_conv_resize(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
     if (!g || !dw) return GT_EINVAL;
     if (!ws || ws_bytes < gt_conv3x3_resize_bwd_ws_bytes(B, Cin, Cout, H, W)) return GT_EWS;
     ConvResizeP p{x, w, const_cast<float*>(y), g, reinterpret_cast<float*>(ws), B, Cin, Cout, H, W, Ho, Wo,
-                  scale_of(H, Ho), scale_of(W, Wo), make_drop(drop)};
+                  scale_of(H, Ho), scale_of(W, Wo), make_drop(drop), y_nhwc};
     if (ceil_div((int64_t)Ho * Wo, 256 * CRB_PXT) > ceil_div((int64_t)H * W, 256 * CRB_PXT)) return GT_ENOTSUP;
     const int nx = ceil_div((int64_t)Ho * Wo, 256 * CRB_PXT);
     dim3 grid((unsigned)nx, (unsigned)ceil_div(Cout, CRB_CG), (unsigned)B);
@@ -814,4 +905,17 @@ extern "C" int gt_conv3x3_resize_bwd(const float* g, const float* y, const float
     GT_LAUNCH_CHECK();
     const int64_t n = (int64_t)Cout * Cin * 9;
     return gt_slab_reduce(p.partial, n, B * nx, n, 1.f, dw, stream);
+}
+
+extern "C" int gt_conv3x3_resize_bwd(const float* g, const float* y, const float* x, const float* w, int32_t B,
+                                     int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                     const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
+                                     void* stream) {
+    return conv_resize_bwd(g, y, x, w, B, Cin, Cout, H, W, Ho, Wo, drop, act, dw, ws, ws_bytes, 0, stream);
+}
+extern "C" int gt_conv3x3_resize_bwd_nhwc(const float* g, const float* y, const float* x, const float* w, int32_t B,
+                                          int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                          const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
+                                          void* stream) {
+    return conv_resize_bwd(g, y, x, w, B, Cin, Cout, H, W, Ho, Wo, drop, act, dw, ws, ws_bytes, 1, stream);
 }

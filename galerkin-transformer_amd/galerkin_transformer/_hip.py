@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 13          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 14          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -135,6 +135,13 @@ _PROTOS = {
                                                                           C.c_void_p, C.c_void_p, C.c_int64,
                                                                           C.c_void_p]),
     "gt_conv3x3_resize_bwd_ws_bytes": (C.c_int64, [C.c_int32] * 5),
+    "gt_conv3x3_resize_fwd_nhwc": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.POINTER(GtDropout), C.c_int32,
+                                                                               C.c_void_p]),
+    "gt_conv3x3_resize_bwd_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 7 + [C.POINTER(GtDropout), C.c_int32,
+                                                                               C.c_void_p, C.c_void_p, C.c_int64,
+                                                                               C.c_void_p]),
+    "gt_bilinear2d_seg_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p]),
+    "gt_bilinear2d_seg_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
     "gt_bilinear2d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
     "gt_grad_sqnorm_ws_bytes": (C.c_int64, []),
     "gt_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -761,34 +768,64 @@ def bilinear2d_bwd(g: torch.Tensor, y_saved: Optional[torch.Tensor], in_size, in
     return dx
 
 
-def conv3x3_resize_fwd(x: torch.Tensor, w: torch.Tensor, size, drop: Optional[GtDropout]) -> torch.Tensor:
-    """relu(resize(relu(dropout(conv3x3(x, w, padding=1))))) -- x [B,Cin,H,W], w [Cout,Cin,3,3] -> [B,Cout,Ho,Wo]."""
+def conv3x3_resize_fwd(x: torch.Tensor, w: torch.Tensor, size, drop: Optional[GtDropout], out_nhwc: bool = False) -> torch.Tensor:
+    """relu(resize(relu(dropout(conv3x3(x, w, padding=1))))) -- x [B,Cin,H,W], w [Cout,Cin,3,3] -> [B,Cout,Ho,Wo], or
+    channels-last [B,Ho,Wo,Cout] with ``out_nhwc``."""
     need_f32_cuda(x, w)
     B, Cin, Hh, Ww = x.shape
     Cout, Ho, Wo = w.shape[0], int(size[0]), int(size[1])
-    y = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device)
+    y = torch.empty((B, Ho, Wo, Cout) if out_nhwc else (B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
+    fn = lib().gt_conv3x3_resize_fwd_nhwc if out_nhwc else lib().gt_conv3x3_resize_fwd
     check(_timed("gt_conv3x3_resize_fwd", 2.0 * 36 * Cin * y.numel(), 4.0 * (x.numel() + y.numel()),
-                 lambda: lib().gt_conv3x3_resize_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, Cout, Hh, Ww,
-                                                     Ho, Wo, dp, ACT_RELU, stream_ptr()),
+                 lambda: fn(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, Cout, Hh, Ww, Ho, Wo, dp, ACT_RELU,
+                            stream_ptr()),
                  shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_fwd")
     return y
 
 
 def conv3x3_resize_bwd(g: torch.Tensor, y: torch.Tensor, x: torch.Tensor, w: torch.Tensor,
-                       drop: Optional[GtDropout]) -> torch.Tensor:
+                       drop: Optional[GtDropout], out_nhwc: bool = False) -> torch.Tensor:
+    """out_nhwc: g and y are channels-last [B,Ho,Wo,Cout] (what conv3x3_resize_fwd(out_nhwc=True) returned)."""
     need_f32_cuda(g, y, x, w)
     B, Cin, Hh, Ww = x.shape
-    Cout, Ho, Wo = w.shape[0], y.shape[2], y.shape[3]
+    Cout = w.shape[0]
+    Ho, Wo = (y.shape[1], y.shape[2]) if out_nhwc else (y.shape[2], y.shape[3])
     dw = torch.empty_like(w)
     ws = workspace(x.device, lib().gt_conv3x3_resize_bwd_ws_bytes(B, Cin, Cout, Hh, Ww))
     dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
+    fn = lib().gt_conv3x3_resize_bwd_nhwc if out_nhwc else lib().gt_conv3x3_resize_bwd
     check(_timed("gt_conv3x3_resize_bwd", 0, 4.0 * (x.numel() + 2 * y.numel()),
-                 lambda: lib().gt_conv3x3_resize_bwd(g.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), B, Cin,
-                                                     Cout, Hh, Ww, Ho, Wo, dp, ACT_RELU, dw.data_ptr(),
-                                                     ws.data_ptr(), ws.numel(), stream_ptr()),
+                 lambda: fn(g.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), B, Cin, Cout, Hh, Ww, Ho, Wo, dp,
+                            ACT_RELU, dw.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
                  shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_bwd")
     return dw
+
+
+def bilinear2d_seg_fwd(x: torch.Tensor, Cc: int, size, seg: int, segp: int, act: int = ACT_NONE) -> torch.Tensor:
+    """x [B,Hi,Wi,3*segp] (the padded three-segment buffer of ops.scaler_conv_chain) -> dense [B,Ho,Wo,Cc]."""
+    need_f32_cuda(x)
+    B, Hi, Wi, cp3 = x.shape
+    assert cp3 == 3 * segp
+    Ho, Wo = int(size[0]), int(size[1])
+    y = torch.empty(B, Ho, Wo, Cc, dtype=torch.float32, device=x.device)
+    check(_timed("gt_bilinear2d_seg_fwd", 0, 4.0 * B * Cc * (Hi * Wi + Ho * Wo),
+                 lambda: lib().gt_bilinear2d_seg_fwd(x.data_ptr(), y.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, act, seg, segp,
+                                                     stream_ptr()), shape=(B, Cc, Hi, Ho)), "gt_bilinear2d_seg_fwd")
+    return y
+
+
+def bilinear2d_seg_bwd(g: torch.Tensor, y_saved: Optional[torch.Tensor], in_size, seg: int, segp: int,
+                       act: int = ACT_NONE) -> torch.Tensor:
+    need_f32_cuda(g, y_saved)
+    B, Ho, Wo, Cc = g.shape
+    Hi, Wi = int(in_size[0]), int(in_size[1])
+    dx = torch.empty(B, Hi, Wi, 3 * segp, dtype=torch.float32, device=g.device)
+    check(_timed("gt_bilinear2d_seg_bwd", 0, 4.0 * B * Cc * (Hi * Wi + 2 * Ho * Wo),
+                 lambda: lib().gt_bilinear2d_seg_bwd(g.data_ptr(), ptr(y_saved), dx.data_ptr(), B, Cc, Hi, Wi, Ho, Wo,
+                                                     act, seg, segp, stream_ptr()), shape=(B, Cc, Hi, Ho)),
+          "gt_bilinear2d_seg_bwd")
+    return dx
 
 
 def galerkin_ktv_supported(dk: int, p: int) -> bool:

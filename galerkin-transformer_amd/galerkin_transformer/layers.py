@@ -181,15 +181,49 @@ class Interp2dEncoder(nn.Module):
                 and cv.stride == (1, 1) and cv.dilation == (1, 1) and cv.groups == 1 and cv.bias is None
                 and cv.in_channels <= 4 and x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad))
 
+    def _chain_ok(self, x, out_nhwc) -> bool:
+        """conv1 / conv2 / conv3 as ops.scaler_conv_chain: channels-last output wanted, plain ReLU blocks without
+        residual, equal dropout, widths [c, c, <= padded c] that the segment layout of the last resize describes."""
+        cs = (self.conv1, self.conv2, self.conv3)
+        if not (out_nhwc and x.is_cuda and not self.add_res and isinstance(self.activation, nn.ReLU)
+                and all(c.plain() and isinstance(c.activation, nn.ReLU) for c in cs)
+                and len({c.conv[1].p for c in cs}) == 1):
+            return False
+        s0 = self.interp_size[0]
+        if isinstance(s0, float):
+            h1, w1 = int(math.floor(x.shape[2] * s0)), int(math.floor(x.shape[3] * s0))
+        elif isinstance(s0, (tuple, list)) and not isinstance(s0[0], float):
+            h1, w1 = int(s0[0]), int(s0[1])
+        else:
+            return False
+        if x.shape[0] * h1 * w1 < 16384 or w1 < 3 or h1 < 3:      # the narrow implicit convolutions want token-row sizes
+            return False
+        convs = [c.conv[0] for c in cs]
+        widths = [c.out_channels for c in convs]
+        cp = (max(widths) + 15) // 16 * 16
+        size = self.interp_size[1]
+        size_ok = isinstance(size, float) or (isinstance(size, (tuple, list)) and not isinstance(size[0], float))
+        return (size_ok and widths[0] == widths[1] and widths[2] > 0 and widths[2] <= cp and sum(widths) % 4 == 0
+                and ops.scaler_chain_ok(convs, "relu"))
+
     def forward(self, x, out_nhwc=False):
         """x (B, C, H, W).  ``out_nhwc`` returns (B, H', W', C') with the layout change fused into the
         last resize (what DownScaler feeds the encoder)."""
+        chain = self._chain_ok(x, out_nhwc)
         if self._conv0_fusable(x):
             # conv0 -> dropout -> relu -> resize -> relu in one pass; the out_dim-channel fine map never exists
             x = ops.conv3x3_resize(x, self.conv0.conv[0].weight, self.interp_size[0], self.conv0.conv[1].p,
-                                   self.training)
+                                   self.training, out_nhwc=chain)
         else:
-            x = _resize(self.conv0(x), self.interp_size[0], self.activation)
+            x = _resize(self.conv0(x), self.interp_size[0], self.activation, out_nhwc=chain)
+        if chain:
+            # channels-last from here on: the three narrow convolutions (+ dropout + ReLU) write the column segments of
+            # ONE padded buffer (implicit GEMMs, ops.scaler_conv_chain), the last resize reads the real channels out of it
+            cs = (self.conv1, self.conv2, self.conv3)
+            seg = cs[0].conv[0].out_channels
+            n_out = sum(c.conv[0].out_channels for c in cs)
+            buf = ops.scaler_conv_chain(x, *(c.conv[0].weight for c in cs), p_drop=cs[0].conv[1].p, training=self.training)
+            return ops.bilinear_resize_seg(buf, n_out, self.interp_size[1], seg, buf.shape[-1] // 3, act="relu")
         x1 = self.conv1(x)
         x2 = self.conv2(x1)
         x3 = self.conv3(x2)

@@ -149,30 +149,59 @@ class Conv3x3ResizeFn(Function):
     when the input carries few channels and needs no gradient.  See gt_conv3x3_resize_fwd."""
 
     @staticmethod
-    def forward(ctx, x, weight, size, p_drop: float):
+    def forward(ctx, x, weight, size, p_drop: float, out_nhwc: bool = False):
         xc, wc = _c(x), _c(weight)
         salt = _next_salt(1)                     # the salt the stand-alone dropout would have drawn
         drop = H.dropout_desc(p_drop, salt, x.device) if p_drop > 0 else None
-        y = H.conv3x3_resize_fwd(xc, wc, size, drop)
+        y = H.conv3x3_resize_fwd(xc, wc, size, drop, out_nhwc)
         ctx.save_for_backward(xc, wc, y)
-        ctx.cfg = (p_drop, salt)
+        ctx.cfg = (p_drop, salt, out_nhwc)
         return y
 
     @staticmethod
     def backward(ctx, g):
         xc, wc, y = ctx.saved_tensors
-        p_drop, salt = ctx.cfg
+        p_drop, salt, out_nhwc = ctx.cfg
         if ctx.needs_input_grad[0]:
             raise RuntimeError("conv3x3_resize: the fused path has no input gradient")
         drop = H.dropout_desc(p_drop, salt, g.device) if p_drop > 0 else None
-        return None, H.conv3x3_resize_bwd(_c(g), y, xc, wc, drop), None, None
+        return None, H.conv3x3_resize_bwd(_c(g), y, xc, wc, drop, out_nhwc), None, None, None
 
 
-def conv3x3_resize(x, weight, size, p_drop: float = 0.0, training: bool = True):
+def conv3x3_resize(x, weight, size, p_drop: float = 0.0, training: bool = True, out_nhwc: bool = False):
+    """out_nhwc: return (B, Ho, Wo, Cout) channels-last (same values, same dropout mask)."""
     hi, wi = x.shape[2], x.shape[3]
     if isinstance(size, float):
         size = (int(math.floor(hi * size)), int(math.floor(wi * size)))
-    return Conv3x3ResizeFn.apply(x, weight, (int(size[0]), int(size[1])), float(p_drop) if training else 0.0)
+    return Conv3x3ResizeFn.apply(x, weight, (int(size[0]), int(size[1])), float(p_drop) if training else 0.0,
+                                 bool(out_nhwc))
+
+
+class ResizeSegFn(Function):
+    """act(F.interpolate(cat[x1, x2, x3], size, bilinear, align_corners=True)) on the padded three-segment buffer of
+    scaler_conv_chain: (B, Hi, Wi, 3 segp) -> dense channels-last (B, Ho, Wo, C) (layers.py:508-512)."""
+
+    @staticmethod
+    def forward(ctx, x, Cc: int, size, seg: int, segp: int, act: int):
+        xc = _c(x)
+        y = H.bilinear2d_seg_fwd(xc, Cc, size, seg, segp, act)
+        ctx.cfg = ((xc.shape[1], xc.shape[2]), seg, segp, act)
+        if act == H.ACT_RELU:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        in_size, seg, segp, act = ctx.cfg
+        y = ctx.saved_tensors[0] if act == H.ACT_RELU else None
+        return H.bilinear2d_seg_bwd(_c(g), y, in_size, seg, segp, act), None, None, None, None, None
+
+
+def bilinear_resize_seg(x, n_channels: int, size, seg: int, segp: int, act: str = None):
+    hi, wi = x.shape[1], x.shape[2]
+    if isinstance(size, float):
+        size = (int(math.floor(hi * size)), int(math.floor(wi * size)))
+    return ResizeSegFn.apply(x, int(n_channels), (int(size[0]), int(size[1])), int(seg), int(segp), H.ACT_CODE[act])
 
 
 class UpsampleFcFn(Function):
@@ -360,6 +389,125 @@ def conv3x3_nhwc(x, weight):
     if x.shape[0] * x.shape[1] * x.shape[2] < 96:
         return torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), weight, padding=1).permute(0, 2, 3, 1).contiguous()
     return Conv3x3NhwcFn.apply(x, weight)
+
+
+# ----------------------------------------------------------------------------------- down-scaler convolution chain
+_scaler_chain = [os.environ.get("GT_SCALER_CHAIN", "1") != "0"]          # A/B switch (tools / tests)
+
+
+def scaler_chain_ok(convs, act_name: str) -> bool:
+    """True when the three narrow 3x3 convolutions of Interp2dEncoder (layers.py:431-512: conv1, conv2, conv3, each
+    conv -> dropout -> ReLU, outputs concatenated) can run as ``scaler_conv_chain``: plain 3x3 / stride 1 / zero padding 1 /
+    bias-free, chained channel counts, the first input a multiple of 16 channels, ReLU (it commutes with the dropout
+    scale, so both ride on the product's epilogue), the split-operand arithmetic."""
+    if not (_scaler_chain[0] and act_name == "relu" and H.get_precision() == "bf16x3" and len(convs) == 3):
+        return False
+    for c in convs:
+        if not (isinstance(c, torch.nn.Conv2d) and tuple(c.kernel_size) == (3, 3) and tuple(c.stride) == (1, 1)
+                and tuple(c.padding) == (1, 1) and tuple(c.dilation) == (1, 1) and c.groups == 1 and c.bias is None
+                and c.padding_mode == "zeros"):
+            return False
+    c1, c2, c3 = convs
+    return (c1.in_channels % 16 == 0 and c2.in_channels == c1.out_channels and c3.in_channels == c2.out_channels
+            and 32 <= max(c.out_channels for c in convs) <= 64)
+
+
+def _pad_filter(w, co_p, ci_p):
+    """[co, ci, 3, 3] -> zero-padded [co_p, 9, ci_p] (tap-major) for _conv_k_order."""
+    co, ci = w.shape[:2]
+    out = torch.zeros(co_p, 9, ci_p, dtype=w.dtype, device=w.device)
+    out[:co, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, 9, ci)
+    return out
+
+
+class ScalerConvChainFn(Function):
+    """cat[x1, x2, x3] with x_i = relu(dropout(conv3x3(x_{i-1}, w_i))), channels-last, as three implicit GEMMs that write
+    straight into ONE buffer [B, H, W, 3 CP] (CP = the widest output rounded up to 16: each convolution owns a 16-byte
+    aligned CP-column segment, its padding columns come out of the product as exact zeros because the padded filter rows
+    are zero, and the next convolution reads its input segment in place -- no cat, no copies, no layout change).
+    Reference: Interp2dEncoder.forward, layers.py:497-507 (conv1 -> conv2 -> conv3 -> torch.cat) with Conv2dResBlock
+    (layers.py:88-150: conv -> dropout -> activation).  Dropout and ReLU sit in the epilogue of the product (ReLU
+    commutes with the non-negative dropout scale); the backward needs only the activated outputs: y > 0 <=> kept and
+    pre-activation > 0.  Backward: one elementwise pass masks the incoming gradient of all three segments, then per
+    convolution (last to first) the data gradient is an implicit GEMM on the tap-reversed filter whose epilogue adds it
+    into the next segment's masked gradient in place, and the weight gradient runs next to it on the side stream."""
+
+    @staticmethod
+    def forward(ctx, x0, w1, w2, w3, p_drop: float):
+        H.need_f32_cuda(x0, w1, w2, w3)
+        B, Hh, Ww, C0 = x0.shape
+        ws = (w1, w2, w3)
+        CP = (max(w.shape[0] for w in ws) + 15) // 16 * 16
+        T = B * Hh * Ww
+        dev = x0.device
+        x0c = _c(x0)
+        cat = torch.empty(T, 3 * CP, dtype=torch.float32, device=dev)
+        salt = _next_salt(3)
+        cin = (C0, CP, CP)
+        for i, w in enumerate(ws):
+            wf = _conv_k_order(_pad_filter(w, CP, cin[i]))                            # [CP, 9 cin] in k order
+            A = x0c.reshape(T, C0) if i == 0 else cat[:, (i - 1) * CP:i * CP]
+            H.gemm(A, wf, cat[:, i * CP:(i + 1) * CP], T, CP, 9 * cin[i], lda=(C0 if i == 0 else 3 * CP), ldb=9 * cin[i],
+                   ldc=3 * CP, conv=(Hh, Ww, cin[i]), act=H.ACT_RELU,
+                   drop=H.dropout_desc(p_drop, salt + i, dev) if p_drop > 0 else None, precision="bf16x3")
+        ctx.save_for_backward(x0c, w1, w2, w3, cat)
+        ctx.cfg = (p_drop, CP)
+        return cat.view(B, Hh, Ww, 3 * CP)
+
+    @staticmethod
+    def backward(ctx, g):
+        x0c, w1, w2, w3, cat = ctx.saved_tensors
+        p_drop, CP = ctx.cfg
+        B, Hh, Ww, C0 = x0c.shape
+        T = B * Hh * Ww
+        dev = g.device
+        ws = (w1, w2, w3)
+        cin = (C0, CP, CP)
+        scale = 1.0 / (1.0 - p_drop)
+        # masked gradient of the three activated outputs in one pass (the dropout scale rides on the products' alpha)
+        dpre = H.act_bwd(_c(g).reshape(T, 3 * CP), cat, H.ACT_RELU)
+        dws = [None, None, None]
+        dx0 = None
+        for i in (2, 1, 0):
+            seg = dpre[:, i * CP:(i + 1) * CP]
+            xin = x0c.reshape(T, C0) if i == 0 else cat[:, (i - 1) * CP:i * CP]
+            if ctx.needs_input_grad[1 + i]:
+                with H.side_branch(dev, T):
+                    dws[i] = _scaler_wgrad(seg, xin, ws[i], B, Hh, Ww, CP, cin[i], scale)
+            # dx[pix][ci] = scale * sum_tap sum_co dpre[pix - shift(tap)][co] W[co][ci][tap]: tap' = 8 - tap
+            if i > 0 or ctx.needs_input_grad[0]:
+                wd = _conv_k_order(_pad_filter(ws[i].flip(2, 3).transpose(0, 1), cin[i], CP))   # [cin, 9 CP] in k order
+                if i == 0:
+                    dx0 = torch.empty(T, C0, dtype=torch.float32, device=dev)
+                    H.gemm(seg, wd, dx0, T, C0, 9 * CP, lda=3 * CP, ldb=9 * CP, ldc=C0, conv=(Hh, Ww, CP), alpha=scale,
+                           precision="bf16x3")
+                else:       # + the segment's own masked gradient (res, in place), through its ReLU / dropout mask (aux)
+                    prev = dpre[:, (i - 1) * CP:i * CP]
+                    H.gemm(seg, wd, prev, T, CP, 9 * CP, lda=3 * CP, ldb=9 * CP, ldc=3 * CP, conv=(Hh, Ww, CP),
+                           alpha=scale, aux_op=H.AUX_GT0, aux=cat[:, (i - 1) * CP:i * CP], ldaux=3 * CP, res=prev,
+                           ldr=3 * CP, precision="bf16x3")
+            H.join_side(dev)        # the next weight gradient reads the segment this data gradient has just completed
+        return (None if dx0 is None else dx0.view(B, Hh, Ww, C0)), dws[0], dws[1], dws[2], None
+
+
+def _scaler_wgrad(dseg, xin, w, B, Hh, Ww, CP, cin, scale):
+    """dW[co][ci][tap] = scale * sum_pix dseg[pix][co] xin[pix + shift(tap)][ci] for one narrow convolution.  Both operands
+    are activations (no split to hoist) and one side is <= 48 wide: the library's channels-last fp32 weight-gradient
+    kernel on dense copies of the two column segments does this at ~60 % of the fp32 matrix peak, which the
+    split-operand engine does not beat here."""
+    co, ci = w.shape[0], w.shape[1]
+    gd = dseg.contiguous().view(B, Hh, Ww, CP).permute(0, 3, 1, 2)                      # dense channels-last
+    xd = xin.contiguous().view(B, Hh, Ww, cin).permute(0, 3, 1, 2)
+    wp = torch.empty(CP, cin, 3, 3, dtype=torch.float32, device=w.device).contiguous(memory_format=torch.channels_last)
+    dw = torch.ops.aten.convolution_backward(gd, xd, wp, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                             [False, True, False])[1]
+    return (dw[:co, :ci] * scale).contiguous()
+
+
+def scaler_conv_chain(x0, w1, w2, w3, p_drop: float = 0.0, training: bool = True):
+    """x0 (B, H, W, C0) channels-last -> (B, H, W, 3 CP): see ScalerConvChainFn; column segment i holds x_{i+1} in its
+    first w_i.shape[0] columns, zeros behind them."""
+    return ScalerConvChainFn.apply(x0, w1, w2, w3, float(p_drop) if training else 0.0)
 
 
 # ----------------------------------------------------------------------------------- Linear

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 13
+#define GT_ABI_VERSION 14
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -186,7 +186,10 @@ typedef struct gt_gemm_desc {
      * for the forward product (layers.py:98-100 `nn.Conv2d(.., kernel_size=3, padding=1, bias=False)` of the scaler
      * blocks), or the tap-reversed, in/out-swapped filter for the data gradient.  Split-operand ring kernel only:
      * precision != GT_PREC_F32, layout_a = layout_b = 0, cv_c % 16 == 0, no batching, no split-K, no A dropout,
-     * M, N >= 96; anything else returns GT_ENOTSUP (the caller then uses its library convolution).
+     * M, N >= 96 (N >= 32 with M >= 16384: narrow outputs run on 128 x 64 tiles of the packed-B kernel); anything else
+     * returns GT_ENOTSUP (the caller then uses its library convolution).  lda > cv_c is the pixel pitch of the image:
+     * the convolution then reads the cv_c-channel column slice A .. A + cv_c of a wider channels-last buffer in place
+     * (lda % 4 == 0); the weight-gradient form takes ldb the same way.
      *
      * cv_wgrad != 0 selects the weight gradient of the same convolution instead:
      *     C_tap[m][n] = sum_pixels A[pixel][m] * X[pixel + (dy, dx)][n]          tap = 0..8 = the batch index
@@ -420,6 +423,15 @@ int gt_bilinear2d_fwd_affine(const float* x, float* y, int32_t B, int32_t C, int
 int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx, int32_t B, int32_t C,
                       int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t in_nhwc,
                       int32_t out_nhwc, int32_t act, void* stream);
+/* Channels-last resize whose INPUT is the padded three-segment buffer the down-scaler's convolution chain writes
+ * (Interp2dEncoder, layers.py:497-512: cat[x1, x2, x3] -> F.interpolate -> activation): x [B, Hi, Wi, 3*segp] holds the
+ * C real channels in three column segments of segp channels each -- real channel c at column c + (segp - seg) * min(c / seg, 2),
+ * i.e. segment widths seg, seg, C - 2*seg, zeros behind them -- and y [B, Ho, Wo, C] is dense.  The concatenation is never
+ * materialised.  Backward: g, y_saved dense like y; dx in the padded layout (padding columns get zero). */
+int gt_bilinear2d_seg_fwd(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
+                          int32_t Wo, int32_t act, int32_t seg, int32_t segp, void* stream);
+int gt_bilinear2d_seg_bwd(const float* g, const float* y_saved, float* dx, int32_t B, int32_t C, int32_t Hi,
+                          int32_t Wi, int32_t Ho, int32_t Wo, int32_t act, int32_t seg, int32_t segp, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * First stage of the CNN down-scaler in one pass (layers.py:483-495 with Conv2dResBlock :88-150):
@@ -439,6 +451,15 @@ int gt_conv3x3_resize_bwd(const float* g, const float* y, const float* x, const 
                           const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
                           void* stream);
 int64_t gt_conv3x3_resize_bwd_ws_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W);
+/* The same with y (and g, y of the backward) channels-last [B, Ho, Wo, Cout]: what the channels-last convolution chain
+ * of the down-scaler consumes. */
+int gt_conv3x3_resize_fwd_nhwc(const float* x, const float* w, float* y, int32_t B, int32_t Cin, int32_t Cout,
+                               int32_t H, int32_t W, int32_t Ho, int32_t Wo, const gt_dropout* drop, int32_t act,
+                               void* stream);
+int gt_conv3x3_resize_bwd_nhwc(const float* g, const float* y, const float* x, const float* w, int32_t B,
+                               int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                               const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
+                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer step on ONE flat fp32 bucket: what utils_ft.py:676-681 does per batch

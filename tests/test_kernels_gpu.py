@@ -1192,3 +1192,118 @@ def test_qkv_headnorm_plain_tiles(H, gpu_device):
         val = out[s_][:, :, p:p + dk] * gamma[s_ - 1] + beta[s_ - 1]
         assert rel_l2(val, out_ref[s_][:, :, p:p + dk]) < 1e-6
         assert torch.equal(out[s_][:, :, :p], out_ref[s_][:, :, :p]) and torch.equal(out[s_][:, :, p + dk:], out_ref[s_][:, :, p + dk:])
+
+
+# ------------------------------------------------------------------------------------------- channels-last down-scaler
+def _ref_conv(x_nhwc, w):
+    """conv2d(padding=1) on a channels-last fp64 image."""
+    return torch.nn.functional.conv2d(x_nhwc.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("B,Hh,Ww,Cin,Cout,pitch_in,pitch_out", [(3, 78, 78, 128, 42, 128, 144), (3, 78, 78, 48, 44, 144, 144),
+                                                                  (5, 60, 61, 16, 64, 48, 64)])
+def test_conv3x3_narrow_tile_and_pixel_pitch(H, gpu_device, B, Hh, Ww, Cin, Cout, pitch_in, pitch_out):
+    """Implicit 3x3 convolution with a NARROW output (N = 48 / 64: the 128 x 64 tile of the packed-B kernel) reading a
+    cv_c-channel column slice of a wider channels-last buffer in place (lda = pixel pitch) and writing a column slice of
+    another (ldc): the down-scaler's 128 -> 42, 42 -> 42, 42 -> 44 convolutions (layers.py:497-507) on padded segments."""
+    from galerkin_transformer import ops
+    dev = gpu_device
+    T = B * Hh * Ww
+    CP = (Cout + 15) // 16 * 16
+    xin = rnd(T, pitch_in, dev=dev, seed=401)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, seed=402, scale=0.2)
+    off = pitch_in - Cin                                          # the slice sits at the END of the wide rows
+    wf = ops._conv_k_order(ops._pad_filter(w, CP, Cin))
+    out = torch.full((T, pitch_out), float("nan"), device=dev)
+    name = H.gemm_kernel_name(xin[:, off:], wf, T, CP, 9 * Cin, lda=pitch_in, ldb=9 * Cin, ldc=pitch_out, precision="bf16x3")
+    H.gemm(xin[:, off:], wf, out[:, :CP], T, CP, 9 * Cin, lda=pitch_in, ldb=9 * Cin, ldc=pitch_out, conv=(Hh, Ww, Cin),
+           precision="bf16x3")
+    torch.cuda.synchronize()
+    ref = _ref_conv(xin[:, off:off + Cin].reshape(B, Hh, Ww, Cin), w).reshape(T, Cout)
+    assert rel_l2(out[:, :Cout], ref) < X3_TOL["bf16x3"]
+    assert torch.equal(out[:, Cout:CP], torch.zeros(T, CP - Cout, device=dev))          # padding columns: exact zeros
+    assert torch.isnan(out[:, CP:]).all()                                                # nothing written past the segment
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_scaler_conv_chain_matches_conv2d(H, gpu_device, p_drop):
+    """ops.scaler_conv_chain (three implicit GEMMs into one padded buffer, ReLU + dropout on the epilogue, in-place
+    gradient accumulation through the chain) == relu(drop(conv)) x 3 + cat with torch's conv2d in fp64 (p = 0); with
+    dropout on, the kept entries equal the scaled reference, ~p of the positive entries are dropped, and the backward
+    is the gradient of exactly that masked function."""
+    from galerkin_transformer import ops
+    dev = gpu_device
+    B, Hh, Ww, C0 = 3, 78, 78, 128
+    widths = (42, 42, 44)
+    x0 = rnd(B, Hh, Ww, C0, dev=dev, seed=411).requires_grad_(True)
+    ws = [rnd(co, ci, 3, 3, dev=dev, seed=412 + i, scale=0.1).requires_grad_(True)
+          for i, (co, ci) in enumerate(zip(widths, (C0,) + widths[:2]))]
+    H.set_seed(77, dev)
+    buf = ops.scaler_conv_chain(x0, *ws, p_drop=p_drop, training=True)
+    CP = buf.shape[-1] // 3
+    assert CP == 48
+    got = [buf[..., i * CP:i * CP + widths[i]] for i in range(3)]
+    for i in range(3):
+        assert torch.equal(buf[..., i * CP + widths[i]:(i + 1) * CP], torch.zeros_like(buf[..., i * CP + widths[i]:(i + 1) * CP]))
+    cot = rnd(*buf.shape, dev=dev, seed=419)               # also on the padding columns: must not matter
+    buf.backward(cot)
+    torch.cuda.synchronize()
+    # reference in fp64 with the masks the run drew (read back from its own outputs: kept <=> output > 0 or pre <= 0)
+    xr = x0.detach().double().requires_grad_(True)
+    wr = [w.detach().double().requires_grad_(True) for w in ws]
+    scale = 1.0 / (1.0 - p_drop)
+    cur, refs = xr, []
+    for i in range(3):
+        pre = torch.nn.functional.conv2d(cur.permute(0, 3, 1, 2), wr[i], padding=1).permute(0, 2, 3, 1)
+        keep = ((got[i].double() > 0) | (pre <= 0)).double() if p_drop > 0 else torch.ones_like(pre)
+        cur = torch.relu(pre) * keep * scale
+        refs.append(cur)
+        if p_drop > 0:
+            pos = pre > 1e-6
+            frac = 1.0 - float((got[i][pos] > 0).double().mean())
+            assert abs(frac - p_drop) < 0.01, frac
+    rcat = torch.cat(refs, -1)
+    rcot = torch.cat([cot[..., i * CP:i * CP + widths[i]] for i in range(3)], -1).double()
+    rcat.backward(rcot)
+    for i in range(3):
+        assert rel_l2(got[i], refs[i]) < 3e-6, i
+        assert rel_l2(ws[i].grad, wr[i].grad) < 5e-6, i
+    assert rel_l2(x0.grad, xr.grad) < 5e-6
+
+
+def test_resize_seg_equals_dense_resize(H, gpu_device):
+    """gt_bilinear2d_seg_fwd/bwd (the last resize of the down-scaler reading the padded three-segment buffer) == the dense
+    channels-last resize of the gathered real channels, forward and backward (padding columns of dx: zero)."""
+    from galerkin_transformer import ops
+    dev = gpu_device
+    B, Hi, Wi, Ho, Wo, seg, segp, Cc = 2, 78, 78, 43, 43, 42, 48, 128
+    buf = rnd(B, Hi, Wi, 3 * segp, dev=dev, seed=431)
+    cols = list(range(0, 42)) + list(range(48, 90)) + list(range(96, 140))
+    dense = buf[..., cols].contiguous().requires_grad_(True)
+    bufg = buf.clone().requires_grad_(True)
+    y1 = ops.bilinear_resize_seg(bufg, Cc, (Ho, Wo), seg, segp, act="relu")
+    y2 = ops.bilinear_resize(dense, (Ho, Wo), in_nhwc=True, out_nhwc=True, act="relu")
+    assert torch.equal(y1, y2)
+    cot = rnd(B, Ho, Wo, Cc, dev=dev, seed=432)
+    y1.backward(cot); y2.backward(cot)
+    assert torch.equal(bufg.grad[..., cols], dense.grad)
+    pad = [c for c in range(3 * segp) if c not in cols]
+    assert torch.equal(bufg.grad[..., pad], torch.zeros_like(bufg.grad[..., pad]))
+
+
+def test_conv3x3_resize_channels_last_output(H, gpu_device):
+    """gt_conv3x3_resize_fwd_nhwc / _bwd_nhwc == the channels-first fused conv0 + resize, transposed (same dropout mask)."""
+    from galerkin_transformer import ops
+    dev = gpu_device
+    x = rnd(3, 1, 141, 141, dev=dev, seed=441)
+    res = []
+    for nhwc in (False, True):
+        w = rnd(128, 1, 3, 3, dev=dev, seed=442).requires_grad_(True)
+        H.set_seed(5, dev)
+        H._salt[0] = 11
+        y = ops.conv3x3_resize(x, w, 0.555, p_drop=0.05, training=True, out_nhwc=nhwc)
+        cot = rnd(3, 128, 78, 78, dev=dev, seed=443)
+        y.backward(cot.permute(0, 2, 3, 1).contiguous() if nhwc else cot)
+        res.append((y.permute(0, 3, 1, 2) if nhwc else y, w.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    assert rel_l2(res[1][1], res[0][1]) < 1e-6
