@@ -412,15 +412,16 @@ def roofline_leg(trainer, precision):
     except (OSError, ValueError):
         pmc = {}
     legs = {}
-    for label, key, sym in (("qkv_proj+headnorm_fwd", "gemm_x3p_kernel<0, 32, 0>", "gt::gemm_x3p_kernel<0, 32, 0>"),
+    for label, key, sym in (("qkv_proj+headnorm_fwd", "gemm_x3p_kernel<0, 32, 0, 128>", "gt::gemm_x3p_kernel<0, 32, 0, 128>"),
                             ("headnorm_fwd", "gt_headnorm_fwd", "gt::headnorm_fwd_v2_kernel"),
                             ("headnorm_bwd", "gt_headnorm_bwd", "gt::headnorm_bwd_v2_kernel"),
                             ("galerkin_ktv", "gt_galerkin_ktv", "gt::galerkin_ktv_kernel<2>"),
                             ("galerkin_dkv", "gt_galerkin_dkv", "gt::galerkin_dkv_kernel<2>"),
                             ("galerkin_dkv+headnorm_bwd", "gt_galerkin_dkv_ln", "gt::galerkin_dkv_ln_kernel<2, true>"),
                             ("galerkin_qp(Q'.P with fc folded)", "gemm_x3r_kernel<0, 1, 3, 3, 0, 0>", "gt::gemm_x3r_kernel<0, 1, 3, 3, 0, 0>"),
-                            ("token_gemms(packed B)", "gemm_x3p_kernel<0, 0, 0>", "gt::gemm_x3p_kernel<0, 0, 0>"),
-                            ("conv3x3_implicit", "gemm_x3p_kernel<0, 0, 1>", "gt::gemm_x3p_kernel<0, 0, 1>"),
+                            ("token_gemms(packed B)", "gemm_x3p_kernel<0, 0, 0, 128>", "gt::gemm_x3p_kernel<0, 0, 0, 128>"),
+                            ("conv3x3_implicit", "gemm_x3p_kernel<0, 0, 1, 128>", "gt::gemm_x3p_kernel<0, 0, 1, 128>"),
+                            ("conv3x3_implicit_narrow(down-scaler)", "gemm_x3p_kernel<0, 0, 1, 64>", "gt::gemm_x3p_kernel<0, 0, 1, 64>"),
                             ("conv3x3_wgrad", "gemm_x3r_kernel<1, 1, 3, 3, 0, 2>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 2>"),
                             ("weight_gradients", "gemm_x3r_kernel<1, 1, 3, 3, 0, 0>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 0>")):
         t = table.get(key) or table.get(key.replace("+splitk", ""))

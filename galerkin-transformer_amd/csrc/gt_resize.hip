@@ -59,13 +59,19 @@ struct ResizeP {
     // segp channels each (ops.scaler_conv_chain): real channel c lives at padded column c + (segp - seg) * min(c / seg, 2);
     // seg == 0: dense.
     int seg, segp;
+    // backward with segments only: the forward input itself (padded layout, the output of a ReLU): dx is zeroed where it
+    // is not positive, which is the first step of its producer's backward (ops.ScalerConvChainFn) done on the way out
+    const float* in_gate;
 };
 
 // padded column of real channel c
 __device__ __forceinline__ int seg_col(const ResizeP& p, int c) { return c + (p.segp - p.seg) * min(c / p.seg, 2); }
 // 4 consecutive real channels c .. c+3 of the padded-segment pixel at px (floats)
+// (c is a multiple of 4; seg and segp are even, so the pairs (c, c+1) and (c+2, c+3) never straddle a segment: two 8-byte loads)
 __device__ __forceinline__ f32x4 seg_load4(const ResizeP& p, const float* __restrict__ px, int c) {
-    return f32x4{px[seg_col(p, c)], px[seg_col(p, c + 1)], px[seg_col(p, c + 2)], px[seg_col(p, c + 3)]};
+    const f32x2 a = *reinterpret_cast<const f32x2*>(px + seg_col(p, c));
+    const f32x2 b = *reinterpret_cast<const f32x2*>(px + seg_col(p, c + 2));
+    return f32x4{a[0], a[1], b[0], b[1]};
 }
 
 __device__ __forceinline__ f32x4 resize_affine(const ResizeP& p, f32x4 v, int b, int c, int oy, int ox) {
@@ -473,13 +479,16 @@ __device__ __forceinline__ void load_patch(const float* __restrict__ xp, int H, 
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP p) {
     __shared__ float sw[CR_CH * CIN * 9];
-    const int c0 = blockIdx.y * CR_CH, b = blockIdx.z;
+    // channels-last output: the channel groups of a pixel strip are neighbouring blocks (they complete the strip's
+    // 512-byte rows together); channels-first: the pixel strips of a channel group are
+    const int bc = p.y_nhwc ? blockIdx.x : blockIdx.y, bx = p.y_nhwc ? blockIdx.y : blockIdx.x;
+    const int c0 = bc * CR_CH, b = blockIdx.z;
     for (int i = threadIdx.x; i < CR_CH * CIN * 9; i += 256) {
         const int c = c0 + i / (CIN * 9);
         sw[i] = (c < p.Cout) ? p.w[(int64_t)c * CIN * 9 + i % (CIN * 9)] : 0.f;
     }
     __syncthreads();
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = bx * 256 + threadIdx.x;
     if (e >= p.Ho * p.Wo) return;
     const int oy = e / p.Wo, ox = e - oy * p.Wo;
     const Axis ay = axis_of(oy, p.sy, p.H), ax = axis_of(ox, p.sx, p.W);
@@ -497,30 +506,40 @@ __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP 
     }
     const uint32_t plane = (uint32_t)(p.H * p.W);
     const float w00 = ay.l0 * ax.l0, w01 = ay.l0 * ax.l1, w10 = ay.l1 * ax.l0, w11 = ay.l1 * ax.l1;
-#pragma unroll 2
-    for (int j = 0; j < CR_CH; ++j) {
-        const int c = c0 + j;
-        if (c >= p.Cout) break;
-        float cv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int j4 = 0; j4 < CR_CH; j4 += 4) {
+        if (c0 + j4 >= p.Cout) break;
+        float r4[4];
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci)
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = j4 + jj, c = c0 + j;
+            float cv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const float wv = sw[(j * CIN + ci) * 9 + k];
+            for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) cv[t] = fmaf(wv, pt[ci][t][k], cv[t]);
+                for (int k = 0; k < 9; ++k) {
+                    const float wv = sw[(j * CIN + ci) * 9 + k];           // zero for c >= Cout
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) cv[t] = fmaf(wv, pt[ci][t][k], cv[t]);
+                }
+            const uint32_t cbase = ((uint32_t)b * (uint32_t)p.Cout + (uint32_t)c) * plane;   // mod 2^32, like the
+#pragma unroll                                                                                // stand-alone dropout
+            for (int t = 0; t < 4; ++t) {
+                const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
+                cv[t] = fmaxf(cv[t] * m, 0.f);
             }
-        const uint32_t cbase = ((uint32_t)b * (uint32_t)p.Cout + (uint32_t)c) * plane;   // mod 2^32, like the
-#pragma unroll                                                                            // stand-alone dropout
-        for (int t = 0; t < 4; ++t) {
-            const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
-            cv[t] = fmaxf(cv[t] * m, 0.f);
+            // same association as the stand-alone resize: l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
+            r4[jj] = fmaxf(ay.l0 * (ax.l0 * cv[0] + ax.l1 * cv[1]) + ay.l1 * (ax.l0 * cv[2] + ax.l1 * cv[3]), 0.f);
         }
-        // same association as the stand-alone resize: l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
-        const float r = ay.l0 * (ax.l0 * cv[0] + ax.l1 * cv[1]) + ay.l1 * (ax.l0 * cv[2] + ax.l1 * cv[3]);
         (void)w00; (void)w01; (void)w10; (void)w11;
-        if (p.y_nhwc) p.y[((int64_t)b * p.Ho * p.Wo + e) * p.Cout + c] = fmaxf(r, 0.f);
-        else p.y[((int64_t)b * p.Cout + c) * p.Ho * p.Wo + e] = fmaxf(r, 0.f);
+        const int c = c0 + j4;
+        if (p.y_nhwc) {                       // a pixel's four channels: one 16-byte store (Cout % 4 == 0 checked on the host)
+            *reinterpret_cast<f32x4*>(p.y + ((int64_t)b * p.Ho * p.Wo + e) * p.Cout + c) = f32x4{r4[0], r4[1], r4[2], r4[3]};
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (c + jj < p.Cout) p.y[((int64_t)b * p.Cout + c + jj) * p.Ho * p.Wo + e] = r4[jj];
+        }
     }
 }
 
@@ -535,7 +554,9 @@ template <int CIN>
 __global__ __launch_bounds__(256) void conv_resize_bwd_kernel(const ConvResizeP p) {
     __shared__ float sw[CRB_CG * CIN * 9];
     __shared__ float red[4][CRB_CG * CIN * 9];
-    const int c0 = blockIdx.y * CRB_CG, b = blockIdx.z;
+    const int bc = p.y_nhwc ? blockIdx.x : blockIdx.y, bx = p.y_nhwc ? blockIdx.y : blockIdx.x;   // as in the forward
+    const int nbx = p.y_nhwc ? gridDim.y : gridDim.x;
+    const int c0 = bc * CRB_CG, b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < CRB_CG * CIN * 9; i += 256) {
         const int c = c0 + i / (CIN * 9);
@@ -553,7 +574,7 @@ __global__ __launch_bounds__(256) void conv_resize_bwd_kernel(const ConvResizeP 
 
 #pragma unroll 1
     for (int it = 0; it < CRB_PXT; ++it) {
-        const int e = (blockIdx.x * CRB_PXT + it) * 256 + threadIdx.x;
+        const int e = (bx * CRB_PXT + it) * 256 + threadIdx.x;
         if (e >= oplane) continue;
         const int oy = e / p.Wo, ox = e - oy * p.Wo;
         const Axis ay = axis_of(oy, p.sy, p.H), ax = axis_of(ox, p.sx, p.W);
@@ -568,11 +589,26 @@ __global__ __launch_bounds__(256) void conv_resize_bwd_kernel(const ConvResizeP 
                 load_patch(p.x + ((int64_t)b * CIN + ci) * plane, p.H, p.W, iy, ix, pt[ci][t]);
         }
         const float wt[4] = {ay.l0 * ax.l0, ay.l0 * ax.l1, ay.l1 * ax.l0, ay.l1 * ax.l1};
+        float gl[CRB_CG], yl[CRB_CG];       // channels-last: the pixel's eight channels are 32 contiguous bytes of g and y
+        if (p.y_nhwc) {
+            const int64_t o8 = ((int64_t)b * oplane + e) * p.Cout + c0;           // Cout % 8 == 0 checked on the host
+#pragma unroll
+            for (int h = 0; h < CRB_CG / 4; ++h) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.g + o8 + 4 * h);
+                const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.y + o8 + 4 * h);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { gl[4 * h + t] = g4[t]; yl[4 * h + t] = y4[t]; }
+            }
+        }
 #pragma unroll          // full unroll: acc[j][..] must be statically indexed to stay in registers
         for (int j = 0; j < CRB_CG; ++j) {
             const int c = min(c0 + j, p.Cout - 1);                 // clamped: tail channels are not stored
-            const int64_t o = p.y_nhwc ? ((int64_t)b * oplane + e) * p.Cout + c : ((int64_t)b * p.Cout + c) * oplane + e;
-            const float go = (p.y[o] > 0.f) ? p.g[o] : 0.f;
+            float go;
+            if (p.y_nhwc) go = (yl[j] > 0.f) ? gl[j] : 0.f;
+            else {
+                const int64_t o = ((int64_t)b * p.Cout + c) * oplane + e;
+                go = (p.y[o] > 0.f) ? p.g[o] : 0.f;
+            }
             float cv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci)
@@ -612,7 +648,7 @@ __global__ __launch_bounds__(256) void conv_resize_bwd_kernel(const ConvResizeP 
     if (threadIdx.x < CRB_CG * CIN * 9) {
         const int c = c0 + threadIdx.x / (CIN * 9);
         if (c < p.Cout) {
-            float* part = p.partial + ((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * p.Cout) * CIN * 9;
+            float* part = p.partial + ((int64_t)(blockIdx.z * nbx + bx) * p.Cout) * CIN * 9;
             part[(int64_t)c0 * CIN * 9 + threadIdx.x] =
                 red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         }
@@ -705,13 +741,20 @@ __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
             for (int jx = 0; jx < RS_MAXT; ++jx) {
                 if (jx < tx.n) {
                     f32x4 g;
-                    if (p.seg) {
+                    if (p.seg) {          // the column pairs (0,1) and (2,3) are real together or padding together
                         const int64_t o = addr<true>(b, 0, ty.lo + jy, tx.lo + jx, p.C, p.Ho, p.Wo);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float gv = cr[j] >= 0 ? p.x[o + cr[j]] : 0.f;
-                            if (p.gate && cr[j] >= 0 && !(p.gate[o + cr[j]] > 0.f)) gv = 0.f;
-                            g[j] = gv;
+                        for (int h = 0; h < 2; ++h) {
+                            f32x2 gv = {0.f, 0.f};
+                            if (cr[2 * h] >= 0) {
+                                gv = *reinterpret_cast<const f32x2*>(p.x + o + cr[2 * h]);
+                                if (p.gate) {
+                                    const f32x2 y = *reinterpret_cast<const f32x2*>(p.gate + o + cr[2 * h]);
+                                    if (!(y[0] > 0.f)) gv[0] = 0.f;
+                                    if (!(y[1] > 0.f)) gv[1] = 0.f;
+                                }
+                            }
+                            g[2 * h] = gv[0]; g[2 * h + 1] = gv[1];
                         }
                     } else {
                         const int64_t o = addr<true>(b, c, ty.lo + jy, tx.lo + jx, p.C, p.Ho, p.Wo);
@@ -728,7 +771,13 @@ __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
             acc += ty.w[jy] * racc;
         }
     }
-    *reinterpret_cast<f32x4*>(p.y + addr<true>(b, c, iy, ix, CX, p.Hi, p.Wi)) = acc;
+    const int64_t od = addr<true>(b, c, iy, ix, CX, p.Hi, p.Wi);
+    if (p.in_gate) {
+        const f32x4 xin = *reinterpret_cast<const f32x4*>(p.in_gate + od);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (!(xin[j] > 0.f)) acc[j] = 0.f;
+    }
+    *reinterpret_cast<f32x4*>(p.y + od) = acc;
 }
 
 // true when no input index of the axis has more than RS_MAXT contributing outputs (host-side bound:
@@ -749,7 +798,7 @@ extern "C" int gt_bilinear2d_fwd_affine(const float* x, float* y, int32_t B, int
     if (int rc = check_resize(x, y, B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc)) return rc;
     if (act != GT_ACT_NONE && act != GT_ACT_RELU) return GT_ENOTSUP;
     ResizeP p{x, y, nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho), scale_of(Wi, Wo), act, ceil_div(Wo, RS_TX),
-              nullptr, 0, nullptr, 0, nullptr, 0, 0, 0};
+              nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr};
     if (aff && (aff->bias || aff->rp)) {
         if (!(in_nhwc && out_nhwc)) return GT_ENOTSUP;
         if (aff->rp < 0 || aff->rp > 8 || (aff->rp && (!aff->rp_a || !aff->rp_b))) return GT_EINVAL;
@@ -785,7 +834,7 @@ extern "C" int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx
     if (act == GT_ACT_RELU && !y_saved) return GT_EINVAL;
     if (out_nhwc && y_saved && (reinterpret_cast<uintptr_t>(y_saved) & 15)) return GT_EALIGN;
     ResizeP p{g, dx, act == GT_ACT_RELU ? y_saved : nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho),
-              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX), nullptr, 0, nullptr, 0, nullptr, 0, 0, 0};
+              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX), nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr};
     dim3 grid((unsigned)(p.xtiles * ceil_div(C, RS_TC)), (unsigned)Hi, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     if (!out_nhwc && !in_nhwc) {
@@ -805,7 +854,7 @@ extern "C" int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx
 
 // Channels-last resize whose INPUT is the padded three-segment buffer of ops.scaler_conv_chain (gt_hip.h)
 static int check_seg(int C, int seg, int segp) {
-    if (seg <= 0 || segp < seg || (segp & 3) || (C & 3) || C <= 2 * seg || C - 2 * seg > segp) return GT_EINVAL;
+    if (seg <= 0 || (seg & 1) || segp < seg || (segp & 3) || (C & 3) || C <= 2 * seg || C - 2 * seg > segp) return GT_EINVAL;
     return 0;
 }
 
@@ -816,7 +865,7 @@ extern "C" int gt_bilinear2d_seg_fwd(const float* x, float* y, int32_t B, int32_
     if (act != GT_ACT_NONE && act != GT_ACT_RELU) return GT_ENOTSUP;
     if (ceil_div(Ho, RN_RPT) > 65535) return GT_EINVAL;
     ResizeP p{x, y, nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho), scale_of(Wi, Wo), act, ceil_div(Wo, RS_TX),
-              nullptr, 0, nullptr, 0, nullptr, 0, seg, segp};
+              nullptr, 0, nullptr, 0, nullptr, 0, seg, segp, nullptr};
     dim3 ng((unsigned)ceil_div((int64_t)Wo * (C / 4), 256), (unsigned)ceil_div(Ho, RN_RPT), (unsigned)B);
     hipLaunchKernelGGL(resize_nhwc_fwd_kernel, ng, dim3(256), 0, (hipStream_t)stream, p);
     GT_LAUNCH_CHECK();
@@ -825,14 +874,15 @@ extern "C" int gt_bilinear2d_seg_fwd(const float* x, float* y, int32_t B, int32_
 
 extern "C" int gt_bilinear2d_seg_bwd(const float* g, const float* y_saved, float* dx, int32_t B, int32_t C, int32_t Hi,
                                      int32_t Wi, int32_t Ho, int32_t Wo, int32_t act, int32_t seg, int32_t segp,
-                                     void* stream) {
+                                     const float* x_gate, void* stream) {
     if (int rc = check_resize(dx, g, B, C, Hi, Wi, Ho, Wo, 1, 1)) return rc;
     if (int rc = check_seg(C, seg, segp)) return rc;
     if (act != GT_ACT_NONE && act != GT_ACT_RELU) return GT_ENOTSUP;
     if (act == GT_ACT_RELU && !y_saved) return GT_EINVAL;
     if (!taps_fit(Hi, Ho) || !taps_fit(Wi, Wo)) return GT_ENOTSUP;
     ResizeP p{g, dx, act == GT_ACT_RELU ? y_saved : nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho),
-              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX), nullptr, 0, nullptr, 0, nullptr, 0, seg, segp};
+              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX), nullptr, 0, nullptr, 0, nullptr, 0, seg, segp, x_gate};
+    if (x_gate && (reinterpret_cast<uintptr_t>(x_gate) & 15)) return GT_EALIGN;
     dim3 ng((unsigned)ceil_div((int64_t)Wi * (3 * segp / 4), 256), (unsigned)Hi, (unsigned)B);
     hipLaunchKernelGGL(resize_nhwc_bwd_kernel, ng, dim3(256), 0, (hipStream_t)stream, p);
     GT_LAUNCH_CHECK();
@@ -853,9 +903,11 @@ static int conv_resize_fwd(const float* x, const float* w, float* y, int32_t B, 
                            int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                            const gt_dropout* drop, int32_t act, int y_nhwc, void* stream) {
     if (int rc = check_conv_resize(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
+    if (y_nhwc && ((Cout & 7) || (reinterpret_cast<uintptr_t>(y) & 15))) return GT_ENOTSUP;
     ConvResizeP p{x, w, y, nullptr, nullptr, B, Cin, Cout, H, W, Ho, Wo, scale_of(H, Ho), scale_of(W, Wo),
                   make_drop(drop), y_nhwc};
     dim3 grid((unsigned)ceil_div((int64_t)Ho * Wo, 256), (unsigned)ceil_div(Cout, CR_CH), (unsigned)B);
+    if (y_nhwc) std::swap(grid.x, grid.y);
     hipStream_t st = (hipStream_t)stream;
     switch (Cin) {
         case 1: hipLaunchKernelGGL(conv_resize_fwd_kernel<1>, grid, dim3(256), 0, st, p); break;
@@ -889,12 +941,14 @@ static int conv_resize_bwd(const float* g, const float* y, const float* x, const
                            void* stream) {
     if (int rc = check_conv_resize(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
     if (!g || !dw) return GT_EINVAL;
+    if (y_nhwc && ((Cout & 7) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(g)) & 15))) return GT_ENOTSUP;
     if (!ws || ws_bytes < gt_conv3x3_resize_bwd_ws_bytes(B, Cin, Cout, H, W)) return GT_EWS;
     ConvResizeP p{x, w, const_cast<float*>(y), g, reinterpret_cast<float*>(ws), B, Cin, Cout, H, W, Ho, Wo,
                   scale_of(H, Ho), scale_of(W, Wo), make_drop(drop), y_nhwc};
     if (ceil_div((int64_t)Ho * Wo, 256 * CRB_PXT) > ceil_div((int64_t)H * W, 256 * CRB_PXT)) return GT_ENOTSUP;
     const int nx = ceil_div((int64_t)Ho * Wo, 256 * CRB_PXT);
     dim3 grid((unsigned)nx, (unsigned)ceil_div(Cout, CRB_CG), (unsigned)B);
+    if (y_nhwc) std::swap(grid.x, grid.y);
     hipStream_t st = (hipStream_t)stream;
     switch (Cin) {
         case 1: hipLaunchKernelGGL(conv_resize_bwd_kernel<1>, grid, dim3(256), 0, st, p); break;

@@ -141,7 +141,7 @@ _PROTOS = {
                                                                                C.c_void_p, C.c_void_p, C.c_int64,
                                                                                C.c_void_p]),
     "gt_bilinear2d_seg_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p]),
-    "gt_bilinear2d_seg_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
+    "gt_bilinear2d_seg_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p, C.c_void_p]),
     "gt_bilinear2d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
     "gt_grad_sqnorm_ws_bytes": (C.c_int64, []),
     "gt_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -816,14 +816,15 @@ def bilinear2d_seg_fwd(x: torch.Tensor, Cc: int, size, seg: int, segp: int, act:
 
 
 def bilinear2d_seg_bwd(g: torch.Tensor, y_saved: Optional[torch.Tensor], in_size, seg: int, segp: int,
-                       act: int = ACT_NONE) -> torch.Tensor:
-    need_f32_cuda(g, y_saved)
+                       act: int = ACT_NONE, x_gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x_gate: the forward input (padded layout) when it came out of a ReLU -- dx is zeroed where it is not positive."""
+    need_f32_cuda(g, y_saved, x_gate)
     B, Ho, Wo, Cc = g.shape
     Hi, Wi = int(in_size[0]), int(in_size[1])
     dx = torch.empty(B, Hi, Wi, 3 * segp, dtype=torch.float32, device=g.device)
     check(_timed("gt_bilinear2d_seg_bwd", 0, 4.0 * B * Cc * (Hi * Wi + 2 * Ho * Wo),
                  lambda: lib().gt_bilinear2d_seg_bwd(g.data_ptr(), ptr(y_saved), dx.data_ptr(), B, Cc, Hi, Wi, Ho, Wo,
-                                                     act, seg, segp, stream_ptr()), shape=(B, Cc, Hi, Ho)),
+                                                     act, seg, segp, ptr(x_gate), stream_ptr()), shape=(B, Cc, Hi, Ho)),
           "gt_bilinear2d_seg_bwd")
     return dx
 

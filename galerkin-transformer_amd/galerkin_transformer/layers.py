@@ -222,8 +222,10 @@ class Interp2dEncoder(nn.Module):
             cs = (self.conv1, self.conv2, self.conv3)
             seg = cs[0].conv[0].out_channels
             n_out = sum(c.conv[0].out_channels for c in cs)
-            buf = ops.scaler_conv_chain(x, *(c.conv[0].weight for c in cs), p_drop=cs[0].conv[1].p, training=self.training)
-            return ops.bilinear_resize_seg(buf, n_out, self.interp_size[1], seg, buf.shape[-1] // 3, act="relu")
+            buf = ops.scaler_conv_chain(x, *(c.conv[0].weight for c in cs), p_drop=cs[0].conv[1].p, training=self.training,
+                                        grad_masked=True)
+            return ops.bilinear_resize_seg(buf, n_out, self.interp_size[1], seg, buf.shape[-1] // 3, act="relu",
+                                           relu_input=True)
         x1 = self.conv1(x)
         x2 = self.conv2(x1)
         x3 = self.conv3(x2)

@@ -182,26 +182,28 @@ class ResizeSegFn(Function):
     scaler_conv_chain: (B, Hi, Wi, 3 segp) -> dense channels-last (B, Ho, Wo, C) (layers.py:508-512)."""
 
     @staticmethod
-    def forward(ctx, x, Cc: int, size, seg: int, segp: int, act: int):
+    def forward(ctx, x, Cc: int, size, seg: int, segp: int, act: int, relu_input: bool):
         xc = _c(x)
         y = H.bilinear2d_seg_fwd(xc, Cc, size, seg, segp, act)
-        ctx.cfg = ((xc.shape[1], xc.shape[2]), seg, segp, act)
-        if act == H.ACT_RELU:
-            ctx.save_for_backward(y)
+        ctx.cfg = ((xc.shape[1], xc.shape[2]), seg, segp, act, relu_input)
+        ctx.save_for_backward(y if act == H.ACT_RELU else None, xc if relu_input else None)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        in_size, seg, segp, act = ctx.cfg
-        y = ctx.saved_tensors[0] if act == H.ACT_RELU else None
-        return H.bilinear2d_seg_bwd(_c(g), y, in_size, seg, segp, act), None, None, None, None, None
+        in_size, seg, segp, act, relu_input = ctx.cfg
+        y, xin = ctx.saved_tensors
+        return H.bilinear2d_seg_bwd(_c(g), y, in_size, seg, segp, act, x_gate=xin), None, None, None, None, None, None
 
 
-def bilinear_resize_seg(x, n_channels: int, size, seg: int, segp: int, act: str = None):
+def bilinear_resize_seg(x, n_channels: int, size, seg: int, segp: int, act: str = None, relu_input: bool = False):
+    """relu_input: x is the output of a ReLU (scaler_conv_chain's buffer) -- the gradient returned for x is already zeroed
+    where x <= 0, which is what its producer's backward would do first (ScalerConvChainFn(grad_masked=True) skips it)."""
     hi, wi = x.shape[1], x.shape[2]
     if isinstance(size, float):
         size = (int(math.floor(hi * size)), int(math.floor(wi * size)))
-    return ResizeSegFn.apply(x, int(n_channels), (int(size[0]), int(size[1])), int(seg), int(segp), H.ACT_CODE[act])
+    return ResizeSegFn.apply(x, int(n_channels), (int(size[0]), int(size[1])), int(seg), int(segp), H.ACT_CODE[act],
+                             bool(relu_input))
 
 
 class UpsampleFcFn(Function):
@@ -433,7 +435,7 @@ class ScalerConvChainFn(Function):
     into the next segment's masked gradient in place, and the weight gradient runs next to it on the side stream."""
 
     @staticmethod
-    def forward(ctx, x0, w1, w2, w3, p_drop: float):
+    def forward(ctx, x0, w1, w2, w3, p_drop: float, grad_masked: bool = False):
         H.need_f32_cuda(x0, w1, w2, w3)
         B, Hh, Ww, C0 = x0.shape
         ws = (w1, w2, w3)
@@ -451,13 +453,13 @@ class ScalerConvChainFn(Function):
                    ldc=3 * CP, conv=(Hh, Ww, cin[i]), act=H.ACT_RELU,
                    drop=H.dropout_desc(p_drop, salt + i, dev) if p_drop > 0 else None, precision="bf16x3")
         ctx.save_for_backward(x0c, w1, w2, w3, cat)
-        ctx.cfg = (p_drop, CP)
+        ctx.cfg = (p_drop, CP, grad_masked)
         return cat.view(B, Hh, Ww, 3 * CP)
 
     @staticmethod
     def backward(ctx, g):
         x0c, w1, w2, w3, cat = ctx.saved_tensors
-        p_drop, CP = ctx.cfg
+        p_drop, CP, grad_masked = ctx.cfg
         B, Hh, Ww, C0 = x0c.shape
         T = B * Hh * Ww
         dev = g.device
@@ -465,7 +467,9 @@ class ScalerConvChainFn(Function):
         cin = (C0, CP, CP)
         scale = 1.0 / (1.0 - p_drop)
         # masked gradient of the three activated outputs in one pass (the dropout scale rides on the products' alpha)
-        dpre = H.act_bwd(_c(g).reshape(T, 3 * CP), cat, H.ACT_RELU)
+        # (grad_masked: the consumer -- bilinear_resize_seg(relu_input=True) -- has already zeroed it where cat <= 0; the data
+        # gradients below accumulate into it in place, so it must be this function's own buffer)
+        dpre = _c(g).reshape(T, 3 * CP) if grad_masked else H.act_bwd(_c(g).reshape(T, 3 * CP), cat, H.ACT_RELU)
         dws = [None, None, None]
         dx0 = None
         for i in (2, 1, 0):
@@ -487,7 +491,7 @@ class ScalerConvChainFn(Function):
                            alpha=scale, aux_op=H.AUX_GT0, aux=cat[:, (i - 1) * CP:i * CP], ldaux=3 * CP, res=prev,
                            ldr=3 * CP, precision="bf16x3")
             H.join_side(dev)        # the next weight gradient reads the segment this data gradient has just completed
-        return (None if dx0 is None else dx0.view(B, Hh, Ww, C0)), dws[0], dws[1], dws[2], None
+        return (None if dx0 is None else dx0.view(B, Hh, Ww, C0)), dws[0], dws[1], dws[2], None, None
 
 
 def _scaler_wgrad(dseg, xin, w, B, Hh, Ww, CP, cin, scale):
@@ -504,10 +508,12 @@ def _scaler_wgrad(dseg, xin, w, B, Hh, Ww, CP, cin, scale):
     return (dw[:co, :ci] * scale).contiguous()
 
 
-def scaler_conv_chain(x0, w1, w2, w3, p_drop: float = 0.0, training: bool = True):
+def scaler_conv_chain(x0, w1, w2, w3, p_drop: float = 0.0, training: bool = True, grad_masked: bool = False):
     """x0 (B, H, W, C0) channels-last -> (B, H, W, 3 CP): see ScalerConvChainFn; column segment i holds x_{i+1} in its
-    first w_i.shape[0] columns, zeros behind them."""
-    return ScalerConvChainFn.apply(x0, w1, w2, w3, float(p_drop) if training else 0.0)
+    first w_i.shape[0] columns, zeros behind them.  grad_masked: the ONLY consumer of the result is
+    bilinear_resize_seg(relu_input=True), whose backward hands the gradient over already multiplied by [result > 0] in a
+    buffer of its own (the in-place accumulation of the backward then works on it directly)."""
+    return ScalerConvChainFn.apply(x0, w1, w2, w3, float(p_drop) if training else 0.0, bool(grad_masked))
 
 
 # ----------------------------------------------------------------------------------- Linear

@@ -427,11 +427,14 @@ int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx, int32_t B
  * (Interp2dEncoder, layers.py:497-512: cat[x1, x2, x3] -> F.interpolate -> activation): x [B, Hi, Wi, 3*segp] holds the
  * C real channels in three column segments of segp channels each -- real channel c at column c + (segp - seg) * min(c / seg, 2),
  * i.e. segment widths seg, seg, C - 2*seg, zeros behind them -- and y [B, Ho, Wo, C] is dense.  The concatenation is never
- * materialised.  Backward: g, y_saved dense like y; dx in the padded layout (padding columns get zero). */
+ * materialised.  Backward: g, y_saved dense like y; dx in the padded layout (padding columns get zero); x_gate (optional)
+ * = the forward input x itself when it is the output of a ReLU: dx is zeroed where x <= 0, i.e. the gradient leaves
+ * already multiplied by the derivative of the ReLU that produced x (one elementwise pass less in its producer). */
 int gt_bilinear2d_seg_fwd(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
                           int32_t Wo, int32_t act, int32_t seg, int32_t segp, void* stream);
 int gt_bilinear2d_seg_bwd(const float* g, const float* y_saved, float* dx, int32_t B, int32_t C, int32_t Hi,
-                          int32_t Wi, int32_t Ho, int32_t Wo, int32_t act, int32_t seg, int32_t segp, void* stream);
+                          int32_t Wi, int32_t Ho, int32_t Wo, int32_t act, int32_t seg, int32_t segp,
+                          const float* x_gate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * First stage of the CNN down-scaler in one pass (layers.py:483-495 with Conv2dResBlock :88-150):

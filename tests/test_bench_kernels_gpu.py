@@ -1,7 +1,7 @@
 """Oracle parity on the kernel instances the headline bench runs (-m gpu).
 
 bench.py's Darcy 141^2 step runs at B = 128 per GPU: T = 236 672 token rows, where gt_gemm selects the packed-B
-split-operand kernel (`gemm_x3p_kernel`, T >= 16 384; `gemm_x3p_kernel<0, 32, 0>` for the QKV launch with the head-norm
+split-operand kernel (`gemm_x3p_kernel`, T >= 16 384; `gemm_x3p_kernel<0, 32, 0, 128>` for the QKV launch with the head-norm
 epilogue on plain tiles), the backward is the fused
 dK'/dV'/LayerNorm pass on plain tiles (`galerkin_dkv_ln_kernel<2, true>`) and the weight gradients fork to the side stream
 (T >= _hip.SIDE_MIN_ROWS).  The cases below sit just above those switches (C2 at B = 18: T = 33 282; C4 at B = 26:
@@ -76,11 +76,11 @@ def _kernels_of(fn):
 LAYER_CASES = {
     # T = B n >= _hip.SIDE_MIN_ROWS (32 768) > the packed-B threshold (16 384)
     "C2_B18": dict(B=18, n=1849, d=128, h=4, p=2, ff=256, eps=1e-7,
-                   expect=("gemm_x3p_kernel<0, 32, 0>", "gemm_x3p_kernel<0, 0, 0>", "gt_galerkin_ktv", "gt_galerkin_dkv_ln"),
+                   expect=("gemm_x3p_kernel<0, 32, 0, 128>", "gemm_x3p_kernel<0, 0, 0, 128>", "gt_galerkin_ktv", "gt_galerkin_dkv_ln"),
                    plain=True),
     # d_k = 48: no fused head-norm epilogue (widths 16 / 32 / 64), affine tiles, the fused backward in its non-plain form
     "C4_B26": dict(B=26, n=1296, d=192, h=4, p=2, ff=384, eps=1e-7,
-                   expect=("gemm_x3p_kernel<0, 0, 0>", "gt_headnorm_fwd", "gt_galerkin_ktv", "gt_galerkin_dkv_ln"),
+                   expect=("gemm_x3p_kernel<0, 0, 0, 128>", "gt_headnorm_fwd", "gt_galerkin_ktv", "gt_galerkin_dkv_ln"),
                    plain=False),
 }
 
@@ -252,7 +252,10 @@ def test_whole_model_darcy141_vs_oracle(gpu_device, mode, scaler_act):
                       "worst_outside_downscaler": max(v for k, v in errs.items() if not k.startswith("downscaler.")),
                       "oracle_f32_worst": max(noise.values()) if noise else None}))
     if gt.get_precision() == "bf16x3":
-        for k in ("gemm_x3p_kernel<0, 32, 0>", "gemm_x3p_kernel<0, 0, 0>", "gemm_x3p_kernel<0, 0, 1>", "gt_galerkin_dkv_ln"):
+        want = ["gemm_x3p_kernel<0, 32, 0, 128>", "gemm_x3p_kernel<0, 0, 0, 128>", "gemm_x3p_kernel<0, 0, 1, 128>", "gt_galerkin_dkv_ln"]
+        if scaler_act == "relu":               # the down-scaler's narrow convolutions on the 128 x 64 tile
+            want += ["gemm_x3p_kernel<0, 0, 1, 64>", "gt_bilinear2d_seg_fwd"]
+        for k in want:
             assert k in kernels, (k, sorted(kernels))
 
 
