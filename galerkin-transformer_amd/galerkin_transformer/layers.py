@@ -367,12 +367,19 @@ class SimpleAttention(nn.Module):
         use_pos = pos is not None and self.pos_dim > 0
         if use_pos:
             assert pos.size(-1) == self.pos_dim
+            wfc, bfc = self.fc.weight, self.fc.bias
         else:
-            raise NotImplementedError("the HIP path folds fc into the attention product and needs pos "
-                                      "(every reference config passes it)")
+            # reference layers.py:869-874, 894-897: without coordinates the heads are not widened and `fc` is skipped --
+            # the same operator with zero coordinate columns and the identity in fc's place
+            pos = None
+            d = self.n_head * self.d_k
+            key = (x.device, d)
+            if getattr(self, "_eye", (None, None))[0] != key:
+                self._eye = (key, torch.eye(d, dtype=torch.float32, device=x.device))
+            wfc, bfc = self._eye[1], None
         wqkv, bqkv, gamma, beta, mask = self._packed()
         kind = "galerkin" if self.attention_type == "galerkin" else "fourier"
-        out, w = ops.simple_attention(x, pos, wqkv, bqkv, gamma, beta, self.fc.weight, self.fc.bias,
+        out, w = ops.simple_attention(x, pos, wqkv, bqkv, gamma, beta, wfc, bfc,
                                       kind=kind, n_head=self.n_head, norm_mask=mask, eps=self.eps,
                                       res=residual, sign=sign, p_out=p_out, need_weights=need_weights)
         self.attn_weight = w
@@ -437,13 +444,18 @@ class SpectralConv1d(nn.Module):
         self.debug = debug
 
     def forward(self, x):
-        if self.return_freq:
-            raise NotImplementedError("return_freq is outside the HIP hot path")
+        act = _act_name(self.activation)
+        args = (self.linear.weight, self.linear.bias, self.fourier_weight, self.modes)
         if self.training and self.dropout.p > 0:
-            # NB the reference drops the FFT branch input only (layers.py:1083); p is 0 in every config
-            raise NotImplementedError("decoder dropout > 0 inside SpectralConv1d has no HIP path")
-        return spectral.spectral_conv1d(x, self.linear.weight, self.linear.bias, self.fourier_weight,
-                                        self.modes, _act_name(self.activation))
+            # the reference drops the input of the FFT branch only (layers.py:1083-1084: res = linear(x); x = dropout(x)).
+            # By linearity  spec(xs) + lin(x) = [spec(xs) + lin(xs)] + lin(x - xs): the fused operator on the dropped input
+            # plus one pointwise Linear on the difference (p is 0 in every shipped config)
+            xs = ops.dropout(x, self.dropout.p, True)
+            pre = spectral.spectral_conv1d(xs, *args, "none", return_freq=self.return_freq)
+            pre, ft = pre if self.return_freq else (pre, None)
+            y = self.activation(pre + ops.linear(x - xs, self.linear.weight, None))
+            return (y, ft) if self.return_freq else y
+        return spectral.spectral_conv1d(x, *args, act, return_freq=self.return_freq)
 
 
 class SpectralConv2d(nn.Module):
@@ -473,15 +485,20 @@ class SpectralConv2d(nn.Module):
             n = int(x.size(1) ** 0.5)
         else:
             raise ValueError("Dimension not implemented")
-        if self.return_freq:
-            raise NotImplementedError("return_freq is outside the HIP hot path")
         if self.norm != "ortho":
             raise NotImplementedError("only norm='ortho' (the reference default) has a HIP path")
         B, flat = x.size(0), x.ndim == 3
         h = x.reshape(B, n, n, self.in_dim)
+        args = (self.linear.weight, self.linear.bias, self.fourier_weight[0], self.fourier_weight[1], self.modes)
+        ft = None
         if self.training and self.dropout.p > 0:
-            # NB the reference drops the FFT branch input only (layers.py:1173); p is 0 in every config
-            raise NotImplementedError("decoder dropout > 0 inside SpectralConv2d has no HIP path")
-        y = spectral.spectral_conv2d(h, self.linear.weight, self.linear.bias, self.fourier_weight[0],
-                                     self.fourier_weight[1], self.modes, _act_name(self.activation))
-        return y.reshape(B, n * n, self.out_dim) if flat else y
+            # dropout on the input of the FFT branch only (layers.py:1172-1173); see SpectralConv1d.forward
+            hs = ops.dropout(h, self.dropout.p, True)
+            pre = spectral.spectral_conv2d(hs, *args, "none", return_freq=self.return_freq)
+            pre, ft = pre if self.return_freq else (pre, None)
+            y = self.activation(pre + ops.linear(h - hs, self.linear.weight, None))
+        else:
+            y = spectral.spectral_conv2d(h, *args, _act_name(self.activation), return_freq=self.return_freq)
+            y, ft = y if self.return_freq else (y, None)
+        y = y.reshape(B, n * n, self.out_dim) if flat else y
+        return (y, ft) if self.return_freq else y

@@ -69,7 +69,7 @@ def _bases(n: int, m: int, device: torch.device):
 
 class SpectralConv2dFn(Function):
     @staticmethod
-    def forward(ctx, x, wlin, blin, w0, w1, modes: int, act: int):
+    def forward(ctx, x, wlin, blin, w0, w1, modes: int, act: int, want_freq: bool = False):
         H.need_f32_cuda(x, wlin, blin, w0, w1)
         B, n, n2, C = x.shape
         assert n == n2
@@ -108,10 +108,12 @@ class SpectralConv2dFn(Function):
                    K2=C, A2=xc, lda2=C, a2_bs=(n * C, 0), B2=wlT, ldb2=Co)
         ctx.save_for_backward(xc, wl, w0c, w1c, X2, pre)
         ctx.cfg = (B, n, C, Co, m, act, blin is not None)
-        return out
+        Yout = Y if want_freq else Y.new_empty(0)        # the mixed retained modes [B, 2, 2 m m, Co] (detached)
+        ctx.mark_non_differentiable(Yout)
+        return out, Yout
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gfreq=None):
         xc, wl, w0c, w1c, X2, pre = ctx.saved_tensors
         B, n, C, Co, m, act, has_b = ctx.cfg
         dev = gy.device
@@ -148,12 +150,12 @@ class SpectralConv2dFn(Function):
         dwl = torch.empty(Co, C, **f32)
         dbl = torch.empty(Co, **f32) if has_b else None
         H.gemm(dpre, xc, dwl, Co, C, T, layout_a=1, layout_b=1, lda=Co, ldb=C, ldc=C, split_k=0, a_colsum=dbl)
-        return dx, dwl, dbl, dw0, dw1, None, None
+        return dx, dwl, dbl, dw0, dw1, None, None, None
 
 
 class SpectralConv1dFn(Function):
     @staticmethod
-    def forward(ctx, x, wlin, blin, w, modes: int, act: int):
+    def forward(ctx, x, wlin, blin, w, modes: int, act: int, want_freq: bool = False):
         H.need_f32_cuda(x, wlin, blin, w)
         B, n, C = x.shape
         m, Co = modes, wlin.shape[0]
@@ -175,10 +177,12 @@ class SpectralConv1dFn(Function):
                K2=C, A2=xc, lda2=C, a2_bs=(n * C, 0), B2=wlT, ldb2=Co)
         ctx.save_for_backward(xc, wl, wc, X, pre)
         ctx.cfg = (B, n, C, Co, m, act, blin is not None)
-        return out
+        Yout = Y if want_freq else Y.new_empty(0)
+        ctx.mark_non_differentiable(Yout)
+        return out, Yout
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gfreq=None):
         xc, wl, wc, X, pre = ctx.saved_tensors
         B, n, C, Co, m, act, has_b = ctx.cfg
         dev = gy.device
@@ -200,12 +204,28 @@ class SpectralConv1dFn(Function):
         dwl = torch.empty(Co, C, **f32)
         dbl = torch.empty(Co, **f32) if has_b else None
         H.gemm(dpre, xc, dwl, Co, C, T, layout_a=1, layout_b=1, lda=Co, ldb=C, ldc=C, split_k=0, a_colsum=dbl)
-        return dx, dwl, dbl, dw, None, None
+        return dx, dwl, dbl, dw, None, None, None
 
 
-def spectral_conv2d(x, wlin, blin, w0, w1, modes: int, act: str = "silu"):
-    return SpectralConv2dFn.apply(x, wlin, blin, w0, w1, int(modes), H.ACT_CODE[act])
+def spectral_conv2d(x, wlin, blin, w0, w1, modes: int, act: str = "silu", return_freq: bool = False):
+    """return_freq: also the zero-padded half spectrum of the mixed modes, (B, Cout, n, n//2 + 1) complex64, as the reference
+    returns it (layers.py:1179-1197) -- assembled from the retained coefficients, detached (a diagnostic output)."""
+    out, Y = SpectralConv2dFn.apply(x, wlin, blin, w0, w1, int(modes), H.ACT_CODE[act], bool(return_freq))
+    if not return_freq:
+        return out
+    B, n, m, Co = x.shape[0], x.shape[1], int(modes), wlin.shape[0]
+    blk = torch.complex(Y[:, 0], Y[:, 1]).view(B, 2 * m, m, Co).permute(0, 3, 1, 2)     # [B, Co, (low | high) rows, ky]
+    ft = torch.zeros(B, Co, n, n // 2 + 1, dtype=torch.complex64, device=x.device)
+    ft[:, :, :m, :m] = blk[:, :, :m]
+    ft[:, :, n - m:, :m] = blk[:, :, m:]
+    return out, ft
 
 
-def spectral_conv1d(x, wlin, blin, w, modes: int, act: str = "silu"):
-    return SpectralConv1dFn.apply(x, wlin, blin, w, int(modes), H.ACT_CODE[act])
+def spectral_conv1d(x, wlin, blin, w, modes: int, act: str = "silu", return_freq: bool = False):
+    out, Y = SpectralConv1dFn.apply(x, wlin, blin, w, int(modes), H.ACT_CODE[act], bool(return_freq))
+    if not return_freq:
+        return out
+    B, n, m, Co = x.shape[0], x.shape[1], int(modes), wlin.shape[0]
+    ft = torch.zeros(B, Co, n // 2 + 1, dtype=torch.complex64, device=x.device)
+    ft[:, :, :m] = torch.complex(Y[:, 0], Y[:, 1]).permute(0, 2, 1)                        # [B, m, Co] -> [B, Co, m]
+    return out, ft

@@ -180,8 +180,11 @@ def _cmul(a_re, a_im, w, eq):
 
 
 def spectral_conv2d(sd: Mapping[str, Tensor], x: Tensor, *, modes: int,
-                    activation: Optional[str] = "silu", norm: str = "ortho") -> Tensor:
-    """x: (B,n,n,Cin) or (B,n*n,Cin) -> same leading shape with Cout."""
+                    activation: Optional[str] = "silu", norm: str = "ortho", return_freq: bool = False,
+                    spec_mask: Optional[Tensor] = None):
+    """x: (B,n,n,Cin) or (B,n*n,Cin) -> same leading shape with Cout.  spec_mask: multiplicative dropout mask on the
+    input of the FFT branch only (layers.py:1172-1173: res = linear(x); x = dropout(x)); return_freq: also the
+    zero-padded half spectrum (B,Cout,n,n//2+1) complex (layers.py:1194-1197)."""
     B = x.shape[0]
     flat = x.dim() == 3
     n = int(round(math.sqrt(x.shape[1]))) if flat else x.shape[1]
@@ -189,6 +192,8 @@ def spectral_conv2d(sd: Mapping[str, Tensor], x: Tensor, *, modes: int,
     x = x.reshape(B, n, n, cin)
     res = F.linear(x, sd["linear.weight"], sd["linear.bias"])
     cout = res.shape[-1]
+    if spec_mask is not None:
+        x = x * spec_mask.to(x.dtype).reshape(x.shape)
     xf = torch.fft.rfft2(x.permute(0, 3, 1, 2), s=(n, n), norm=norm)
     m = modes
     of_re = x.new_zeros(B, cout, n, n // 2 + 1)
@@ -202,14 +207,16 @@ def spectral_conv2d(sd: Mapping[str, Tensor], x: Tensor, *, modes: int,
     of_im[:, :, :m, :m] = lo_im
     of_re[:, :, -m:, :m] = hi_re
     of_im[:, :, -m:, :m] = hi_im
-    y = torch.fft.irfft2(torch.complex(of_re, of_im), s=(n, n), norm=norm)
+    oft = torch.complex(of_re, of_im)
+    y = torch.fft.irfft2(oft, s=(n, n), norm=norm)
     y = _act(activation)(y.permute(0, 2, 3, 1) + res)
-    return y.reshape(B, n * n, cout) if flat else y
+    y = y.reshape(B, n * n, cout) if flat else y
+    return (y, oft) if return_freq else y
 
 
 def spectral_conv1d(sd: Mapping[str, Tensor], x: Tensor, *, modes: int,
-                    activation: Optional[str] = "silu") -> Tensor:
-    """x: (B,n,Cin) -> (B,n,Cout)."""
+                    activation: Optional[str] = "silu", return_freq: bool = False):
+    """x: (B,n,Cin) -> (B,n,Cout) (and the padded half spectrum (B,Cout,n//2+1) with return_freq, layers.py:1102-1106)."""
     B, n, _ = x.shape
     res = F.linear(x, sd["linear.weight"], sd["linear.bias"])
     cout = res.shape[-1]
@@ -220,8 +227,10 @@ def spectral_conv1d(sd: Mapping[str, Tensor], x: Tensor, *, modes: int,
     of_im = x.new_zeros(B, cout, n // 2 + 1)
     of_re[:, :, :modes] = o_re
     of_im[:, :, :modes] = o_im
-    y = torch.fft.irfft(torch.complex(of_re, of_im), n=n, norm="ortho")
-    return _act(activation)(y.permute(0, 2, 1) + res)
+    oft = torch.complex(of_re, of_im)
+    y = torch.fft.irfft(oft, n=n, norm="ortho")
+    y = _act(activation)(y.permute(0, 2, 1) + res)
+    return (y, oft) if return_freq else y
 
 
 def spectral_regressor(sd: Mapping[str, Tensor], x: Tensor, grid: Optional[Tensor], *,

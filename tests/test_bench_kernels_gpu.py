@@ -331,3 +331,79 @@ def test_training_trajectory_vs_oracle(gpu_device):
     print(json.dumps(rec))
     assert loss_err < 1e-5, rec
     assert e_hip <= 3.0 * e_f32 + 2e-5, rec
+
+
+@pytest.mark.parametrize("prec,out_tol,stack_tol,grad_tol", [("bf16", 1.5e-2, 2.5e-2, 0.25), ("bf16x2", 5e-5, 1e-4, 2e-3)])
+def test_throughput_precision_modes_model_gate(gpu_device, prec, out_tol, stack_tol, grad_tol):
+    """The throughput arithmetic modes as a product (BASELINE configs[1] names bf16): `set_precision("bf16")` (operands
+    rounded to bf16, fp32 accumulate and storage) and "bf16x2", on the Darcy 141^2 model against the float64 oracle with
+    the attention and ReLU masks replayed -- (i) the six-layer encoder stack on the model's own down-scaled activations,
+    (ii) the whole model's prediction and (iii) every parameter gradient outside the kinked down-scaler, within the
+    mode's recorded bounds.  Measured: bf16 1.2e-2 (stack) / 6.3e-3 (prediction) / 3e-2 (gradients, median) -- SURVEY
+    section 8c's 2-2.5e-3 for bf16-rounded operands holds for unit-scale random activations, not for the model's own
+    small-amplitude ones; bf16x2 1.1e-5 / 4e-5; default bf16x3 3.7e-7 / 4e-6.  bf16 is a 1e-2-class mode, and is
+    documented as such."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import galerkin_transformer as gt
+    from galerkin_transformer import ops
+    from oracle import galerkin_oracle as O
+    B = 4
+    cfg = _zero_dropout_cfg(bench)
+    torch.manual_seed(47)
+    model = gt.FourierTransformer2D(**cfg)
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.add_(0.02 * torch.randn_like(prm))
+    b = bench.synthetic_batch(B, torch.device("cpu"), seed=83)
+    cot = torch.randn(B, bench.N_FINE, bench.N_FINE, 1)
+    L, h, Dr = cfg["num_encoder_layers"], cfg["n_head"], cfg["n_hidden"] // cfg["n_head"] + 2
+    masks = [(torch.rand(B, h, Dr, Dr) >= 0.5).float() * 2.0 for _ in range(L)]
+    sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    dev = gpu_device
+    model = model.to(dev).train()
+    bd = {k: v.to(dev) for k, v in b.items()}
+    old = gt.set_precision(prec)
+    gt.set_attention_dropout("replay")
+    relu_masks = []
+    try:
+        # (i) the encoder stack alone, on the float64 down-scaler output
+        with torch.no_grad():
+            x0 = O.interp_downscaler(O._sub(sd64, "downscaler."), b["node"].double(), interp_size=cfg["downscaler_size"],
+                                     activation=cfg.get("downscaler_activation")).reshape(B, -1, cfg["n_hidden"])
+            gt.push_attention_masks([m.to(dev) for m in masks])
+            ops.set_relu_mask_sink(relu_masks)
+            xs = x0.float().to(dev)
+            for layer in model.encoder_layers:
+                xs = layer(xs, bd["pos"])
+            ops.set_relu_mask_sink(None)
+            ek = O._enc_kwargs(cfg)
+            xr = x0
+            for li in range(L):
+                xr = O.encoder_layer(O._sub(sd64, f"encoder_layers.{li}."), xr, b["pos"].double(), attn_drop=masks[li],
+                                     relu_mask=relu_masks[li].cpu(), **ek)
+        stack_err = rel_l2(xs, xr)
+        # (ii), (iii) the whole model
+        relu_masks.clear()
+        gt.push_attention_masks([m.to(dev) for m in masks])
+        ops.set_relu_mask_sink(relu_masks)
+        out = model(bd["node"], None, bd["pos"], bd["grid"])["preds"]
+        out.backward(cot.to(dev))
+        torch.cuda.synchronize()
+        ops.set_relu_mask_sink(None)
+        rm = [m.cpu() for m in relu_masks]
+        ref, _, ref_dp = O.grads_of(
+            lambda s: O.fourier_transformer_2d(s, cfg, b["node"].double(), b["pos"].double(), b["grid"].double(),
+                                               attn_drops=masks, relu_masks=rm), sd64, [], cot.double())
+    finally:
+        ops.set_relu_mask_sink(None)
+        gt.set_attention_dropout("reference")
+        gt.set_precision(old)
+    errs = {k: rel_l2(v.grad, ref_dp[k]) for k, v in dict(model.named_parameters()).items() if not k.startswith("downscaler.")}
+    out_err = rel_l2(out, ref)
+    rec = dict(precision=prec, encoder_stack=stack_err, prediction=out_err, grad_max=max(errs.values()),
+               grad_median=sorted(errs.values())[len(errs) // 2])
+    print(json.dumps(rec))
+    with open(os.path.join(ROOT, "gpurun_out", f"parity_precision_{prec}.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    assert stack_err < stack_tol and out_err < out_tol and max(errs.values()) < grad_tol, rec

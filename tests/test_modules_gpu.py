@@ -20,12 +20,14 @@ def GT(gpu_device):
 def build_module(gt, g: Golden):
     m, kind = g.meta, g.meta["kind"]
     if kind == "encoder_layer":
-        kw = {k: v for k, v in m.items() if k not in ("kind", "B", "n", "base")}
+        kw = {k: v for k, v in m.items() if k not in ("kind", "B", "n", "base", "nopos")}
         return gt.SimpleTransformerEncoderLayer(dropout=0.0, ffn_dropout=0.0, **kw)
     if kind == "spectral_conv2d":
-        return gt.SpectralConv2d(m["in_dim"], m["out_dim"], m["modes"], dropout=0.0, activation=m["activation"])
+        return gt.SpectralConv2d(m["in_dim"], m["out_dim"], m["modes"], dropout=m.get("dropout", 0.0),
+                                 activation=m["activation"], return_freq=bool(m.get("return_freq")))
     if kind == "spectral_conv1d":
-        return gt.SpectralConv1d(m["in_dim"], m["out_dim"], m["modes"], dropout=0.0)
+        return gt.SpectralConv1d(m["in_dim"], m["out_dim"], m["modes"], dropout=0.0,
+                                 return_freq=bool(m.get("return_freq")))
     if kind == "spectral_regressor":
         kw = {k: v for k, v in m.items() if k != "kind"}
         return gt.SpectralRegressor(dropout=0.0, **kw)
@@ -48,8 +50,12 @@ def build_module(gt, g: Golden):
 def run_module(mod, g: Golden, ins):
     kind = g.meta["kind"]
     if kind == "encoder_layer":
-        return mod(ins["x"], ins["pos"])
+        return mod(ins["x"], ins.get("pos"))          # corner_enc_galerkin_nopos: no coordinates, no fc
     if kind in ("spectral_conv2d", "spectral_conv1d"):
+        if g.meta.get("return_freq"):                 # (out, out_ft) in the layout make_golden_corners.py recorded
+            out, ft = mod(ins["x"])
+            assert ft.dtype == torch.complex64 and not ft.requires_grad
+            return torch.cat([out.flatten(), ft.real.flatten(), ft.imag.flatten()])
         return mod(ins["x"])
     if kind in ("spectral_regressor", "pointwise_regressor"):
         return mod(ins["x"], grid=ins["grid"])
@@ -72,16 +78,21 @@ def test_module_matches_reference_golden(GT, gpu_device, name):
         GT.push_attention_masks([m.to(dev) for m in g.masks])
     else:
         GT.set_attention_dropout("off")
+    from galerkin_transformer import ops
+    real_dropout = ops.dropout
     try:
         ins = {k: v.to(dev) for k, v in g.inputs.items()}
         for k in g.din:
             ins[k].requires_grad_(True)
+        if "dropmask" in ins:       # corner_sconv2d_dropmask: the Bernoulli mask of the FFT-branch dropout, replayed
+            ops.dropout = lambda x, p, training=True: x * ins["dropmask"].reshape(x.shape)
         out = run_module(mod, g, ins)
         assert out.shape == g.out.shape
         e_out = rel_l2(out, g.out)
         out.backward(g.cot.to(dev))
         torch.cuda.synchronize()
     finally:
+        ops.dropout = real_dropout
         GT.set_attention_dropout("reference")
     errs = {"out": e_out}
     for k in g.din:

@@ -18,13 +18,20 @@ def _enc_kwargs(meta):
 def run_oracle(g: Golden, sd, inputs):
     m, kind = g.meta, g.meta["kind"]
     drops = g.masks if g.masks else None
+    def cat_freq(out, ft):                       # the layout make_golden_corners.py records (out, out_ft) in
+        ft = ft.detach()
+        return torch.cat([out.flatten(), ft.real.flatten(), ft.imag.flatten()])
+
     if kind == "encoder_layer":
-        return O.encoder_layer(sd, inputs["x"], inputs["pos"],
+        return O.encoder_layer(sd, inputs["x"], inputs.get("pos"),
                                attn_drop=drops[0] if drops else None, **_enc_kwargs(m))
     if kind == "spectral_conv2d":
-        return O.spectral_conv2d(sd, inputs["x"], modes=m["modes"], activation=m["activation"])
+        y = O.spectral_conv2d(sd, inputs["x"], modes=m["modes"], activation=m["activation"],
+                              return_freq=bool(m.get("return_freq")), spec_mask=inputs.get("dropmask"))
+        return cat_freq(*y) if m.get("return_freq") else y
     if kind == "spectral_conv1d":
-        return O.spectral_conv1d(sd, inputs["x"], modes=m["modes"])
+        y = O.spectral_conv1d(sd, inputs["x"], modes=m["modes"], return_freq=bool(m.get("return_freq")))
+        return cat_freq(*y) if m.get("return_freq") else y
     if kind == "spectral_regressor":
         return O.spectral_regressor(sd, inputs["x"], inputs["grid"], modes=m["modes"],
                                     num_spectral_layers=m["num_spectral_layers"],

@@ -22,6 +22,8 @@ for step in "$@"; do
     pytest) L=$O/pytest_$(echo $arg | tr '/:. ' '____' | cut -c1-60).log; ( time timeout 1200 python -m pytest $arg -q -x ) > $L 2>&1; grep -E "passed|failed|^E  " $L | cut -c1-300 | tail -n 8;;
     micro) ( env $(echo $arg | tr ',' ' ') timeout 300 python tools/x3_micro.py 2>>$O/micro.err | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); r['env']='$arg'; print(json.dumps(r))" ) >> $O/micro.jsonl
            python -c "import sys,json; r=json.loads(open('$O/micro.jsonl').read().strip().splitlines()[-1]); print('$arg', ' | '.join('%s %.0f' % (k[:18], v['us']) for k, v in r.items() if isinstance(v, dict)))";;
+    benchp) ( timeout 400 python bench.py $BENCH_FAST --precision $arg 2>$O/bench.err | tail -1 ) > $O/bench_prec_$arg.json
+           python -c "import json,sys; r=json.load(open(sys.argv[1])); print('precision $arg', r['value'], r['ms_per_step'], r['config']['final_loss'])" $O/bench_prec_$arg.json;;
     bench) ( env $(echo $arg | tr ',' ' ') timeout 400 python bench.py $BENCH_FAST 2>$O/bench.err | tail -1 ) > $O/bench_$(echo "$arg" | tr '=,/ ' '____').json
            python -c "import json,sys; r=json.load(open(sys.argv[1])); print('$arg', r['value'], r['ms_per_step'])" $O/bench_$(echo "$arg" | tr '=,/ ' '____').json;;
     prof)
