@@ -524,6 +524,32 @@ def accuracy_leg(precision, seeds=(1, 2, 3)):
     return out
 
 
+def parity_record():
+    """The deterministic half of the accuracy metric, recorded by the GPU test-suite (tests/test_bench_kernels_gpu.py,
+    committed under profiles/): whole-model prediction / gradient parity at 141^2 and the 5-step training trajectory
+    against the float64 oracle.  Quoted here, not recomputed (the bench does not run the checker)."""
+    out = {}
+    for key, fn in (("trajectory_5_steps", "r03_parity_trajectory.json"),
+                    ("whole_model_replay", "r03_parity_whole_model_replay_relu.json"),
+                    ("whole_model_exact_math", "r03_parity_whole_model_off_silu.json")):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                r = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if key == "trajectory_5_steps":
+            out[key] = {k: r[k] for k in ("steps", "batch", "loss_rel_err_max", "param_rel_l2_hip_vs_f64",
+                                          "param_rel_l2_oracle_f32_vs_f64", "precision") if k in r}
+        else:
+            e = r.get("hip_vs_f64", {})
+            if e:
+                vals = [v for k, v in e.items() if k != "out" and not k.startswith("downscaler.")]
+                out[key] = {"prediction_rel_l2": e.get("out"), "gradients_rel_l2_max": max(vals),
+                            "gradients_rel_l2_median": sorted(vals)[len(vals) // 2], "precision": r.get("precision")}
+    out["source"] = "profiles/r03_parity_*.json, written by tests/test_bench_kernels_gpu.py on MI355X"
+    return out if len(out) > 1 else None
+
+
 DTYPE_TEXT = {
     "f32": "f32",
     "bf16x3": "f32 (operands split exactly into 3 bf16 terms, 6 plane products on the bf16 MFMA pipe, f32 accumulate; "
@@ -652,7 +678,7 @@ def main():
             "f32_mfma_exact": f32_leg,
             # algorithmic work of the whole step (19.3 GFLOP per sample fwd + bwd) over the step time
             "useful_tflops": (round(19.3e9 * gb / (elapsed / a.steps) / 1e12, 2) if a.workload == "ex2_darcy141" else None),
-            "roofline": roof, "cpu_baseline": cpu, "accuracy": acc,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity_record(), "accuracy": acc,
         }
         if a.table and table:
             with open(a.table, "w") as f:

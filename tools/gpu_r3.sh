@@ -48,6 +48,32 @@ for step in "$@"; do
       python tools/pmc_summary.py $O/pmc 50 > $O/pmc_summary.txt 2>&1
       rm -rf $O/pmc
       head -30 $O/pmc_summary.txt | cut -c1-170;;
+    sweep)
+      echo "[" > $O/sweep.json
+      for B in 4 16 64 128 256; do
+        timeout 300 python bench.py --batch $B --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-accuracy --no-f32-leg 2>/dev/null | tail -1 >> $O/sweep.json
+        echo "," >> $O/sweep.json
+      done
+      timeout 300 python bench.py --batch 4 --no-graph --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-accuracy --no-f32-leg 2>/dev/null | tail -1 >> $O/sweep.json
+      echo "]" >> $O/sweep.json
+      python -c "
+import json
+for r in json.load(open('$O/sweep.json')): print(r['config']['per_gpu_batch'], 'graph' if r['config']['hip_graph'] else 'eager', r['value'], r['ms_per_step'])";;
+    work)
+      for w in ex2_darcy211_fourier ex3_darcy_inv ex4_ns ex1_burgers; do
+        timeout 400 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-f32-leg 2>/dev/null | tail -1 > $O/bench_$w.json
+        python -c "import json; r=json.load(open('$O/bench_$w.json')); print('$w', r['value'], r['ms_per_step'])"
+      done
+      timeout 400 python bench.py --loss weighted_l2 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-accuracy --no-f32-leg 2>/dev/null | tail -1 > $O/bench_weighted_l2.json
+      python -c "import json; r=json.load(open('$O/bench_weighted_l2.json')); print('weighted_l2', r['value'], r['ms_per_step'])";;
+    fullprof)
+      cd /tmp
+      timeout 900 rocprofv3 --kernel-trace --stats -d $O/fprof -o trace --output-format csv -- \
+          python $R/bench.py --no-cpu-baseline --no-accuracy > $O/fullprof.log 2>&1
+      cd $R
+      python tools/prof_csv_summary.py $O/fprof 60 > $O/kernel_stats_whole_process.txt 2>&1
+      rm -rf $O/fprof
+      head -12 $O/kernel_stats_whole_process.txt | cut -c1-150;;
     full) ( time timeout 900 python bench.py --table $O/table.json ) > $O/bench_full.log 2> $O/bench_full.err; tail -1 $O/bench_full.log | cut -c1-700;;
     probe) ( env $(echo $arg | tr ',' ' ') timeout 300 python tools/parity_probe.py 18 2>>$O/probe.err | tail -1 ) >> $O/probe.jsonl; tail -1 $O/probe.jsonl | cut -c1-900;;
     probe64) ( env $(echo $arg | tr ',' ' ') timeout 300 python tools/parity_probe.py 18 f64 2>>$O/probe.err | tail -1 ) >> $O/probe.jsonl; tail -1 $O/probe.jsonl | cut -c1-900;;
