@@ -388,7 +388,8 @@ class Conv3x3NhwcFn(Function):
 def conv3x3_nhwc(x, weight):
     """x (B, H, W, Cin) channels-last, weight (Cout, Cin, 3, 3) -> (B, H, W, Cout); see Conv3x3NhwcFn.  Less than one
     tile of pixels (< 96) goes to the library convolution on the same buffers."""
-    if x.shape[0] * x.shape[1] * x.shape[2] < 96:
+    if x.shape[0] * x.shape[1] * x.shape[2] < 96 or H.get_precision() == "f32":
+        # (the implicit GEMM exists on the split-operand engine only: gt_hip.h says GT_ENOTSUP -> the library convolution)
         return torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), weight, padding=1).permute(0, 2, 3, 1).contiguous()
     return Conv3x3NhwcFn.apply(x, weight)
 

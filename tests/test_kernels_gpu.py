@@ -1016,7 +1016,8 @@ def test_upscaler_channels_last_path_equals_channels_first(H, gpu_device):
     for implicit in (True, False):
         ops._conv_implicit[0] = implicit
         try:
-            assert up.features_nhwc() == implicit
+            # the implicit GEMM lives on the split-operand engine: under GT_PRECISION=f32 both passes are the library's
+            assert up.features_nhwc() == (implicit and H.get_precision() != "f32")
             up.zero_grad()
             xx = x.clone().requires_grad_(True)
             y = up(xx, in_nhwc=True, out_nhwc=True)

@@ -131,7 +131,9 @@ def test_bench_two_ranks_on_one_gpu_gloo(gpu_device):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["hip_graph"]
     assert rec["value"] > 0 and np.isfinite(rec["config"]["final_loss"])
-    assert rec["roofline"] and rec["f32_mfma_exact"]["value"] > 0
+    assert rec["roofline"]
+    if rec["config"]["precision"] != "f32":               # the fp32-MFMA leg is the comparison run of the other modes
+        assert rec["f32_mfma_exact"]["value"] > 0
 
 
 def _run_bench_ranks(extra, port, timeout=900):
