@@ -119,12 +119,139 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 // r02m_pmc_step_summary.txt).  The wave therefore transposes its 32 x 64 row tile through a private LDS tile first:
 // afterwards 16 consecutive lanes hold one row's 64 columns and every global access of the fused epilogue is a full
 // 256-byte row segment.  mtile0 / ntile0: first row / column of the wave's tile.  stg: 32 x X3_EP_SW floats.
+#ifndef GT_X3_EP_FAST                              // 0: every tile through ep_row (the round-2 epilogue), for A/B timing
+#define GT_X3_EP_FAST 1
+#endif
 constexpr int X3_EP_SW = 68;                     // staging row pitch in floats (64 + 4: conflict-free both ways)
 constexpr int X3_EP_STG = 32 * X3_EP_SW;
 
+// The epilogue's four bias values of a lane (columns ntile0 + 4 (lane & 15) ..): a kernel that fetches them in front of
+// its K loop takes one memory round trip out of every block's epilogue.
+__device__ __forceinline__ void x3_bias4(const GemmP& p, int ntile0, int lane, float (&b)[4]) {
+    const int nb = ntile0 + 4 * (lane & 15);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
+}
+
+// Batched form of the fused epilogue for whole, 16-byte aligned tiles (every token GEMM of the hot path).  ep_row handles
+// one row segment at a time behind run-time switches: each segment's res / aux load was followed by its use, and the
+// s_waitcnt vmcnt(0) in front of that use also waited for the STORES of the segments before it -- sixteen store round
+// trips in a row per wave.  A block of the FFN launch spent 15.6 us of its 28.7 us in the epilogue writing 64 KB, and
+// 55-60 % of the resident blocks of the chip were in that state at any time (tools/x3p_prof.py, profiles/r03z_*).
+// Here a wave works in batches of four segments (16 rows x 256 B): the res / aux loads of batch b + 1 are issued before
+// the stores of batch b, the values of a batch are computed together, and nothing ever waits for a store.
+template <int MI>
+__device__ __forceinline__ void x3_epilogue_fast(const GemmP& p, const f32x16 (&acc)[MI][2], int mtile0, int nb, int lane,
+                                                 float* __restrict__ stg, float* __restrict__ C, int z, int b0, int b1,
+                                                 const float (&biasv)[4], uint32_t dkey) {
+    constexpr int NB = 2 * MI, HB = 4;
+    const int lr = lane & 31, lh = lane >> 5, c4 = lane & 15, rsub = lane >> 4;
+    const float* resb = p.res ? p.res + b0 * p.r_bs0 + b1 * p.r_bs1 + nb : nullptr;
+    const float* auxb = p.aux_op ? p.aux + b0 * p.aux_bs0 + b1 * p.aux_bs1 + nb : nullptr;
+    f32x4 rs[HB], ax[HB];
+    auto loads = [&](int b) {
+        f32x4 (&r)[HB] = rs;
+        f32x4 (&a)[HB] = ax;
+        if (resb) {
+#pragma unroll
+            for (int k = 0; k < HB; ++k)
+                r[k] = *reinterpret_cast<const f32x4*>(resb + (int64_t)(mtile0 + 16 * b + 4 * k + rsub) * p.ldr);
+        }
+        if (auxb) {
+#pragma unroll
+            for (int k = 0; k < HB; ++k)
+                a[k] = *reinterpret_cast<const f32x4*>(auxb + (int64_t)(mtile0 + 16 * b + 4 * k + rsub) * p.ldaux);
+        }
+    };
+    loads(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = b >> 1;
+        if ((b & 1) == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(stg + lr * X3_EP_SW + 32 * j + 8 * g + 4 * lh) =
+                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            // wave-private tile, LDS operations of one wave execute in order: a compiler fence + counter wait is enough
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        f32x4 v[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k)
+            v[k] = *reinterpret_cast<const f32x4*>(stg + (16 * (b & 1) + 4 * k + rsub) * X3_EP_SW + 4 * c4);
+        if (b & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next tile is staged
+        const int m0b = mtile0 + 16 * b + rsub;                       // row of segment k: m0b + 4 k
+#pragma unroll
+        for (int k = 0; k < HB; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[k][t] = p.alpha * v[k][t] + biasv[t];
+        if (p.pre) {
+#pragma unroll
+            for (int k = 0; k < HB; ++k)
+                *reinterpret_cast<f32x4*>(p.pre + ((int64_t)z * p.M + m0b + 4 * k) * p.ldpre + nb) = v[k];
+        }
+        if (p.act == GT_ACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < HB; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[k][t] = fmaxf(v[k][t], 0.f);
+        } else if (p.act == GT_ACT_SILU) {
+#pragma unroll
+            for (int k = 0; k < HB; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[k][t] = silu_f(v[k][t]);
+        }
+        if (auxb) {
+            const f32x4 (&a)[HB] = ax;
+            if (p.aux_op == GT_AUX_GT0) {
+#pragma unroll
+                for (int k = 0; k < HB; ++k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[k][t] *= a[k][t] > 0.f ? p.aux_scale : 0.f;
+            } else if (p.aux_op == GT_AUX_DSILU) {
+#pragma unroll
+                for (int k = 0; k < HB; ++k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[k][t] *= dsilu_f(a[k][t]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < HB; ++k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[k][t] *= a[k][t] * p.aux_scale;
+            }
+        }
+        if (p.drop.thresh) {
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const uint32_t di = (uint32_t)(((int64_t)z * p.M + m0b + 4 * k) * p.drop_ld + p.n_off + nb);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[k][t] *= drop_mul(p.drop, dkey, di + t);
+            }
+        }
+        if (resb) {
+            const f32x4 (&r)[HB] = rs;
+#pragma unroll
+            for (int k = 0; k < HB; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[k][t] = r[k][t] + p.out_scale * v[k][t];
+        } else {
+#pragma unroll
+            for (int k = 0; k < HB; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[k][t] *= p.out_scale;
+        }
+        if (b + 1 < NB) loads(b + 1);          // rs / ax are consumed: the next batch's loads go out in front of the stores
+#pragma unroll
+        for (int k = 0; k < HB; ++k) *reinterpret_cast<f32x4*>(C + (int64_t)(m0b + 4 * k) * p.ldc + nb) = v[k];
+    }
+}
+
 template <int MI>
 __device__ __forceinline__ void x3_epilogue(const GemmP& p, const f32x16 (&acc)[MI][2], int mtile0, int ntile0, int lane,
-                                            float* __restrict__ stg, int z, int b0, int b1, int sidx) {
+                                            float* __restrict__ stg, int z, int b0, int b1, int sidx,
+                                            const float* bias_pre = nullptr) {     // bias_pre: x3_bias4() of this lane
     const int64_t coff = b0 * p.c_bs0 + b1 * p.c_bs1 + (int64_t)sidx * p.c_split;
     float* __restrict__ C = p.C + coff;
     const uint32_t dkey = drop_key_dev(p.drop);
@@ -134,7 +261,13 @@ __device__ __forceinline__ void x3_epilogue(const GemmP& p, const f32x16 (&acc)[
     const bool col_ok = nb < p.N, full = nb + 4 <= p.N;
     float biasv[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) biasv[t] = (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
+    for (int t = 0; t < 4; ++t) biasv[t] = bias_pre ? bias_pre[t] : (p.bias && nb + t < p.N) ? p.bias[nb + t] : 0.f;
+#if GT_X3_EP_FAST
+    if (p.c_vec && !p.raw && !p.rp && !p.add && ntile0 + 64 <= p.N && mtile0 + 32 * MI <= p.M) {   // wave-uniform
+        x3_epilogue_fast<MI>(p, acc, mtile0, nb, lane, stg, C, z, b0, b1, biasv, dkey);
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -181,6 +314,22 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
     const bool normed = (p.hn_mask >> stream) & 1;
     const bool store_raw = !((p.hn_skip_raw >> stream) & 1);   // the raw projection of this stream goes to C
     const int ni = __popc(p.hn_mask & ((1 << stream) - 1));
+    // What the tile loop reads from memory (bias, the rows' coordinates) is fetched here, in front of the first store: a
+    // load inside the loop is followed by its use, and the s_waitcnt vmcnt(0) in front of that use also waits for every
+    // store issued before it (the serialisation x3_epilogue_fast removes from the plain epilogue).  gamma / beta stay in
+    // the loop: the hot path writes plain tiles (hn_plain), and 64 more registers would spill.
+    f32x4 bv[NSEG][GPS];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg)
+#pragma unroll
+        for (int q = 0; q < GPS; ++q)
+            bv[sg][q] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nwave + sg * DK + 8 * q + 4 * lh) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float posv[MI][4];                                        // hn_p <= 4 coordinates of this lane's rows (lane half 0 writes them)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            posv[i][jj] = (lh == 0 && jj < p.hn_p && mrow + 32 * i < p.M) ? p.hn_pos[(int64_t)(mrow + 32 * i) * p.hn_p + jj] : 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = mrow + 32 * i;
@@ -194,9 +343,8 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
             for (int q = 0; q < GPS; ++q) {
                 const int c = sg * DK + 8 * q;                // column offset of this group inside the wave's 64 (+ 4 lh)
                 const int j = c >> 5, g = (c & 31) >> 3;
-                const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nwave + c + 4 * lh) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[q][t] = p.alpha * acc[i][j][4 * g + t] + bv[t];
+                for (int t = 0; t < 4; ++t) v[q][t] = p.alpha * acc[i][j][4 * g + t] + bv[sg][q][t];
                 if (row_ok && store_raw)
                     *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + nwave + c + 4 * lh) = f32x4{v[q][0], v[q][1], v[q][2], v[q][3]};
             }
@@ -221,17 +369,24 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
                 const int dim = 8 * q + 4 * lh;
                 float y[4] = {v[q][0], v[q][1], v[q][2], v[q][3]};
                 if (normed) {
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(p.hn_gamma + (ni * p.hn_h + head) * DK + dim);
-                    const f32x4 bt = *reinterpret_cast<const f32x4*>(p.hn_beta + (ni * p.hn_h + head) * DK + dim);
+                    if (p.hn_plain) {                         // the product path of the Galerkin layers: no load in the loop
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) y[t] = p.hn_plain ? (y[t] - mu) * rstd : (y[t] - mu) * rstd * gm[t] + bt[t];
+                        for (int t = 0; t < 4; ++t) y[t] = (y[t] - mu) * rstd;
+                    } else {
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.hn_gamma + (ni * p.hn_h + head) * DK + dim);
+                        const f32x4 bt = *reinterpret_cast<const f32x4*>(p.hn_beta + (ni * p.hn_h + head) * DK + dim);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) y[t] = (y[t] - mu) * rstd * gm[t] + bt[t];
+                    }
                 }
                 float* dst = seg + p.hn_p + dim;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dst[t] = y[t];
             }
             if (lh == 0) {                                    // one lane of the pair: coordinates, padding, statistics
-                for (int jj = 0; jj < p.hn_p; ++jj) seg[jj] = row_ok ? p.hn_pos[(int64_t)m * p.hn_p + jj] : 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    if (jj < p.hn_p) seg[jj] = posv[i][jj];
                 for (int jj = p.hn_p + DK; jj < DP; ++jj) seg[jj] = 0.f;
                 if (normed && row_ok)
                     *reinterpret_cast<f32x2*>(p.hn_stats + (((int64_t)ni * p.M + m) * p.hn_h + head) * 2) = f32x2{mu, rstd};
@@ -708,11 +863,23 @@ __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict_
 #ifndef GT_X3P_BLOCKS                              // resident blocks per CU the general instances are compiled for
 #define GT_X3P_BLOCKS 3
 #endif
+#ifndef GT_X3P_BSETS                               // register sets for the B fragments (2: requested one stage ahead)
+#define GT_X3P_BSETS 2
+#endif
+#ifdef GT_X3P_PROF                                 // tools/x3p_prof.py: wall-clock stamps (100 MHz) of every block's phases
+__device__ unsigned long long x3p_prof[8 * 8192];
+extern "C" int gt_debug_x3p_prof(void* dst, long long bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(x3p_prof), (size_t)bytes);
+}
+#define X3P_STAMP(i) const unsigned long long ts##i = __builtin_amdgcn_s_memrealtime()
+#else
+#define X3P_STAMP(i)
+#endif
 // BN = 128: 2 x 2 waves of 64 x 64;  BN = 64 (narrow outputs: the 42 / 44-channel convolutions of the down-scaler, padded to
 // 48): 4 x 1 waves of 32 x 64 -- a wave then splits ONE 32-row tile of A per stage for its twelve MFMAs, the same split-to-
 // matrix ratio as the wide tile, and a 48-column product wastes a quarter of the tile instead of five eighths.
 template <int LA, int HN, int CV, int BN = 128>     // CV: 0 plain, 1 implicit 3x3 convolution on A
-__global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_kernel(const GemmP p) {
+__global__ __launch_bounds__(256, ((HN > 0 || LA == 1 || CV == 1) ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_kernel(const GemmP p) {
     constexpr int MI = BN == 64 ? 1 : 2;           // 32-row tiles of A per wave
     static_assert(BN == 128 || (BN == 64 && HN == 0 && LA == 0), "the narrow tile serves plain / convolution launches");
     constexpr int R = X3P_R, PLANES = 3;
@@ -720,6 +887,7 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
     constexpr int SMEM = R * X3R_OP > STG ? R * X3R_OP : STG;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
+    X3P_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = BN == 64 ? wave : wave >> 1, wn = BN == 64 ? 0 : wave & 1;
     const int wrow = BN == 64 ? wm * 32 : wm * 64; // first tile row of this wave
@@ -736,6 +904,8 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
     const float* A = p.A;
     const uint32_t akey = drop_key_dev(p.a_drop);
 
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};         // the plain epilogue's bias, fetched under the K loop
+    if (HN == 0) x3_bias4(p, n0 + wn * 64, lane, bias4);
     f32x16 acc[MI][2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -746,7 +916,7 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
 
     const int nk = (kend + X3_BK - 1) / X3_BK;
     const float* cv_row[2] = {A, A};
-    int cv_ok[2] = {0, 0}, cv_tap = 0, cv_c0 = 0;
+    int cv_ok[2] = {0, 0}, cv_none[2] = {0, 0}, cv_tap = 0, cv_c0 = 0;      // cv_none: a stage past the end of K reads zeros
     const int cv_cb = (p.cv_C & 31) ? 16 : 32;
     if (CV == 1) {
 #pragma unroll
@@ -766,7 +936,7 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
     auto issue = [&](int s) {                      // A stage s -> slot s % R : 2 load instructions per wave
         char* st = smem + (s % R) * X3R_OP;
         if (CV == 1) {
-            x3r_issue_conv(cv_row, cv_ok, cv_tap, cv_c0, p.cv_W, p.lda, st, wave, lane);
+            x3r_issue_conv(cv_row, s < nk ? cv_ok : cv_none, cv_tap, cv_c0, p.cv_W, p.lda, st, wave, lane);
             cv_c0 += X3_BK;                        // channel block first, taps second, channel blocks last (gt_hip.h)
             if ((cv_c0 & (cv_cb - 1)) == 0) {
                 cv_c0 -= cv_cb;
@@ -784,6 +954,110 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
     const char* bbase = reinterpret_cast<const char*>(p.Bp) + (int64_t)((n0 + wn_u * 64) >> 5) * p.bp_KS * 1024;
     const int64_t bplane = (int64_t)p.bp_NT * p.bp_KS * 1024;
     const uint32_t voff = lane * 16;
+#if GT_X3P_BSETS == 2
+    // Two register sets for B, one stage apart: B(kt + 1) is requested at the TOP of iteration kt, before the A stage of that
+    // iteration, and is consumed one iteration later.  Vector-memory loads retire in order, so a wait for B also waits for
+    // every A stage requested before it: with ONE set the loads of B(kt + 1) can only go out behind the MFMAs of B(kt), and
+    // their latency (plus that of the A stage requested one iteration earlier) stands in front of every stage's MFMAs --
+    // load, matrix and store time of a launch add up instead of overlapping (tools/ablate_x3.sh: 37 + 15 + 30 = 82 us).
+    bf16x8 bn0[2][PLANES], bn1[2][PLANES];
+    auto loadb = [&](int ks, bf16x8 (&bn)[2][PLANES]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) {
+#ifdef GT_ABL_X3_NOSPLIT_B       // ablation: every stage reads the same (cache-resident) fragment
+                const char* sp = bbase + pl * bplane + (int64_t)j * p.bp_KS * 1024;
+#else
+                const char* sp = bbase + pl * bplane + ((int64_t)j * p.bp_KS + ks) * 1024;
+#endif
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bn[j][pl]) : "v"(voff), "s"(sp));
+            }
+    };
+    // one 32-row tile of A at a time: its fragment is split and goes through its twelve MFMAs before the next one is read
+    // (the three planes of ONE tile are live, not of both: the second B set has to fit under 168 registers)
+    auto stage = [&](int kt, bf16x8 (&bn)[2][PLANES]) {
+        const char* sa = smem + (kt % R) * X3R_OP;
+        const int kbase = kt * X3_BK + 8 * lh;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float v[8];
+            bf16x8 am[PLANES];
+            const int row = wrow + 32 * i + lr;
+            x3r_frag<LA>(sa, row, lh, v);
+            if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, 0, m0 + row, kbase, v);
+#ifdef GT_ABL_X3_NOSPLIT_A       // ablation builds (tools/ablate_x3.sh): timing only, results are wrong
+            for (int pl = 0; pl < PLANES; ++pl) am[pl] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(v[0]), __float_as_uint(v[2]), __float_as_uint(v[4]), __float_as_uint(v[6])});
+#else
+            x3r_split<PLANES>(v, am);
+#endif
+#pragma unroll
+            for (int s = PLANES - 1; s >= 0; --s) {      // plane pairs (pa, pb) with pa + pb = s, smallest terms first
+#pragma unroll
+                for (int pa = 0; pa < PLANES; ++pa) {
+                    const int pb = s - pa;
+                    if (pb < 0 || pb >= PLANES) continue;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(bn[j][pb], am[pa], acc[i][j]);
+                }
+            }
+        }
+    };
+    // Request order of a wave:  B(0) A(0) .. A(R-2) | B(1) A(R-1) | B(2) A(R) | ...   (A = 2 loads, B = 6).
+    // Top of iteration kt >= 1: A(kt) and B(kt) must have landed; the only request behind B(kt) is A(kt+R-2): vmcnt(2).
+    // The barrier makes every wave's pieces of A(kt) visible and frees slot (kt-1) % R for the request of A(kt+R-1).
+    // Tying the set to the statement keeps its MFMAs behind the wait.  Every iteration issues the same requests -- past
+    // the end of K the A loader reads the zero line into a free slot and B re-reads its last stage -- so the counts hold
+    // to the last stage and no load sits under a branch: a conditional asm load makes hipcc allocate fresh registers for
+    // it and COPY them into the set at the join, before the data has arrived (seen in the ISA of a first version).
+#define X3P_WAIT_AB_(N, bn)                                                                                            \
+    asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier"                                                                \
+                 : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[0][2]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(bn[1][2])      \
+                 :                                                                                                     \
+                 : "memory")
+#ifdef GT_X3P_PROF                                 // time spent in the waits of the K loop (wave 0)
+    unsigned long long tw_sum = 0;
+#define X3P_WAIT_AB(N, bn)                                                                                             \
+    do {                                                                                                               \
+        const unsigned long long w0_ = __builtin_amdgcn_s_memrealtime();                                              \
+        X3P_WAIT_AB_(N, bn);                                                                                           \
+        tw_sum += __builtin_amdgcn_s_memrealtime() - w0_;                                                              \
+    } while (0)
+#else
+#define X3P_WAIT_AB(N, bn) X3P_WAIT_AB_(N, bn)
+#endif
+    const int klast = nk - 1;
+    loadb(0, bn0);
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s) issue(s);
+    if (R == 3) X3P_WAIT_AB(2, bn0);               // iteration 0: behind A(0) are the R - 2 other stages of the prologue
+    else if (R == 4) X3P_WAIT_AB(4, bn0);
+    else if (R == 5) X3P_WAIT_AB(6, bn0);
+    else X3P_WAIT_AB(8, bn0);
+    X3P_STAMP(1);
+    loadb(klast < 1 ? klast : 1, bn1);
+    issue(R - 1);
+    stage(0, bn0);
+    int kt = 1;
+    for (; kt + 1 < nk; kt += 2) {
+        X3P_WAIT_AB(2, bn1);
+        loadb(kt + 1, bn0);
+        issue(kt + R - 1);
+        stage(kt, bn1);
+        X3P_WAIT_AB(2, bn0);
+        loadb(kt + 2 < klast ? kt + 2 : klast, bn1);
+        issue(kt + R);
+        stage(kt + 1, bn0);
+    }
+    if (kt < nk) {                                 // odd stage out (nk even): nothing left to request
+        X3P_WAIT_AB(2, bn1);
+        stage(kt, bn1);
+    }
+    X3P_STAMP(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero stages requested past the end of K: the ring becomes staging
+#undef X3P_WAIT_AB
+#undef X3P_WAIT_AB_
+#else
     bf16x8 bn[2][PLANES];
     auto loadb = [&](int ks) {
 #pragma unroll
@@ -865,6 +1139,7 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
         if (kt + 1 < nk) loadb(kt + 1);
     }
 #undef X3P_WAIT_B
+#endif
 #ifdef GT_ABL_X3_NOSTORE
     if (acc[0][0][0] != 12345.678f) return;
 #endif
@@ -874,7 +1149,20 @@ __global__ __launch_bounds__(256, (HN > 0 ? 3 : GT_X3P_BLOCKS)) void gemm_x3p_ke
         x3_epilogue_hn<(HN > 0 ? HN : 32), 2>(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, lane,
                                                reinterpret_cast<float*>(smem) + wave * X3_HN_STG);
     else
-        x3_epilogue<MI>(p, acc, m0 + wrow, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * X3_EP_STG, 0, 0, 0, 0);
+        x3_epilogue<MI>(p, acc, m0 + wrow, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * X3_EP_STG, 0, 0, 0, 0,
+                        bias4);
+#ifdef GT_X3P_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the block's stores have left
+    X3P_STAMP(3);
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned long long* o = x3p_prof + 8 * blockIdx.x;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID: cu / sh / se
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // XCC_ID
+        o[6] = tile;
+        o[7] = tw_sum;
+    }
+#endif
 }
 
 // operands the ring kernel's direct loads can take (see its header comment)
@@ -898,6 +1186,7 @@ bool x3_shape_ok(const gt_gemm_desc* d) {
 bool x3_headnorm_ok(const GemmP& p, int layout_a, int layout_b, int planes) {
     if (layout_a || layout_b || planes != 3 || !x3r_ok(p, 0, 0)) return false;
     if (p.hn_dk != 16 && p.hn_dk != 32 && p.hn_dk != 64) return false;
+    if (p.hn_p > 4) return false;                  // the epilogue keeps a row's coordinates in four registers
     if (!p.c_vec || (p.N & 63) || (64 / p.hn_dk) * p.hn_DP + 4 > 88) return false;      // staging row fits X3_HN_STG
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     return al(p.bias) && al(p.hn_gamma) && al(p.hn_beta) && al(p.hn_out) && al(p.hn_stats);

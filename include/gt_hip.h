@@ -156,7 +156,7 @@ typedef struct gt_gemm_desc {
      * the raw projection) and in the same pass every row's head segments go to hn_out [3][M][h][DP] (normalised where
      * hn_norm_mask says so, coordinates in columns [0, hn_p), zero pad) and hn_stats [#normed][M][h][2] = (mean,
      * rstd).  Runs on the split-operand ring kernel only (precision != GT_PREC_F32, 16-byte aligned operands,
-     * K % 4 == 0): dk in {16, 32, 64}, layout_a = layout_b = 0, no batching, no split-K, no other epilogue field but
+     * K % 4 == 0): dk in {16, 32, 64}, hn_p <= 4, layout_a = layout_b = 0, no batching, no split-K, no other epilogue field but
      * alpha and bias; anything else returns GT_ENOTSUP and the caller runs gt_gemm + gt_headnorm_fwd. */
     const float* hn_gamma; const float* hn_beta; const float* hn_pos;
     float* hn_out; float* hn_stats;
