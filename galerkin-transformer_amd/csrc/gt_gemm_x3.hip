@@ -826,19 +826,14 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
 //     Bp[plane][n-tile of 32][k-stage of 16][lane 0..63] = 8 bf16  (k = 16 ks + 8 (lane >> 5) + e, n = 32 nt + (lane & 31)),
 // zero beyond N and K, n-tiles padded to whole 128-column block tiles.  A wave then reads a B fragment of a stage as ONE
 // coalesced 1-KB global load straight into the registers the MFMA takes it from (the planes stay L2-resident: 3 x 2 bytes
-// per weight), B needs no LDS, and the ring holds A only (8 KB per stage, depth 4).  The loads of stage kt + 1 are
-// issued behind the MFMAs of stage kt, so their latency sits under the next barrier and A split.
-// Counted waits (VMEM retires in order):  top of iteration kt -- A(kt) must have landed; requested after it are the A
-// stages kt+1 .. kt+R-2 (2 loads each) and B(kt) (6 loads): vmcnt(2 newer + 6);  before the MFMAs -- B(kt) must have
-// landed; after it only A(kt+R-1) (2 loads) was requested: the compiler's own vmcnt(2) (vmcnt(0) in the tail loop).
+// per weight), B needs no LDS, and the ring holds A only (8 KB per stage, depth 4).  The fragments of stage kt + 1 are
+// requested at the top of iteration kt into a second register set; the counted waits (vector-memory loads retire in
+// order) are written out next to the loop.
 #ifndef GT_X3P_RING                                // A-ring depth of the packed-B kernel (stages of 8 KB)
 #define GT_X3P_RING 4
 #endif
 constexpr int X3P_R = GT_X3P_RING;
 static_assert(X3P_R >= 3 && X3P_R <= 6, "the counted waits below are written out for ring depths 3..6");
-#define X3P_STR2(x) #x
-#define X3P_STR(x) X3P_STR2(x)
-#define X3P_WAIT_A(N) asm volatile("s_waitcnt vmcnt(" X3P_STR(N) ")\n\ts_barrier" ::: "memory")
 
 __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K,
                                                         int NT, int KS, u32x4* __restrict__ out) {
@@ -862,9 +857,6 @@ __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict_
 
 #ifndef GT_X3P_BLOCKS                              // resident blocks per CU the general instances are compiled for
 #define GT_X3P_BLOCKS 3
-#endif
-#ifndef GT_X3P_BSETS                               // register sets for the B fragments (2: requested one stage ahead)
-#define GT_X3P_BSETS 2
 #endif
 #ifdef GT_X3P_PROF                                 // tools/x3p_prof.py: wall-clock stamps (100 MHz) of every block's phases
 __device__ unsigned long long x3p_prof[8 * 8192];
@@ -954,7 +946,6 @@ __global__ __launch_bounds__(256, ((HN > 0 || LA == 1 || CV == 1) ? 3 : GT_X3P_B
     const char* bbase = reinterpret_cast<const char*>(p.Bp) + (int64_t)((n0 + wn_u * 64) >> 5) * p.bp_KS * 1024;
     const int64_t bplane = (int64_t)p.bp_NT * p.bp_KS * 1024;
     const uint32_t voff = lane * 16;
-#if GT_X3P_BSETS == 2
     // Two register sets for B, one stage apart: B(kt + 1) is requested at the TOP of iteration kt, before the A stage of that
     // iteration, and is consumed one iteration later.  Vector-memory loads retire in order, so a wait for B also waits for
     // every A stage requested before it: with ONE set the loads of B(kt + 1) can only go out behind the MFMAs of B(kt), and
@@ -962,6 +953,9 @@ __global__ __launch_bounds__(256, ((HN > 0 || LA == 1 || CV == 1) ? 3 : GT_X3P_B
     // load, matrix and store time of a launch add up instead of overlapping (tools/ablate_x3.sh: 37 + 15 + 30 = 82 us).
     bf16x8 bn0[2][PLANES], bn1[2][PLANES];
     auto loadb = [&](int ks, bf16x8 (&bn)[2][PLANES]) {
+#ifdef GT_ABL_X3_NOLOADB         // ablation: the B fragments are fetched for the first two stages only (timing; wrong results)
+        if (ks > 1) return;
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1057,89 +1051,6 @@ __global__ __launch_bounds__(256, ((HN > 0 || LA == 1 || CV == 1) ? 3 : GT_X3P_B
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero stages requested past the end of K: the ring becomes staging
 #undef X3P_WAIT_AB
 #undef X3P_WAIT_AB_
-#else
-    bf16x8 bn[2][PLANES];
-    auto loadb = [&](int ks) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int pl = 0; pl < PLANES; ++pl) {
-#ifdef GT_ABL_X3_NOSPLIT_B       // ablation: every stage reads the same (cache-resident) fragment
-                const char* sp = bbase + pl * bplane + (int64_t)j * p.bp_KS * 1024;
-#else
-                const char* sp = bbase + pl * bplane + ((int64_t)j * p.bp_KS + ks) * 1024;
-#endif
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bn[j][pl]) : "v"(voff), "s"(sp));
-            }
-    };
-    bf16x8 am[MI][PLANES];
-    auto splita = [&](int kt) {
-        const char* sa = smem + (kt % R) * X3R_OP;
-        const int kbase = kt * X3_BK + 8 * lh;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            float v[8];
-            const int row = wrow + 32 * i + lr;
-            x3r_frag<LA>(sa, row, lh, v);
-            if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, 0, m0 + row, kbase, v);
-#ifdef GT_ABL_X3_NOSPLIT_A       // ablation builds (tools/ablate_x3.sh): timing only, results are wrong
-            for (int pl = 0; pl < PLANES; ++pl) am[i][pl] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(v[0]), __float_as_uint(v[2]), __float_as_uint(v[4]), __float_as_uint(v[6])});
-#else
-            x3r_split<PLANES>(v, am[i]);
-#endif
-        }
-    };
-    auto mfmas = [&]() {
-#pragma unroll
-        for (int s = PLANES - 1; s >= 0; --s) {          // plane pairs (pa, pb) with pa + pb = s, smallest terms first
-#pragma unroll
-            for (int pa = 0; pa < PLANES; ++pa) {
-                const int pb = s - pa;
-                if (pb < 0 || pb >= PLANES) continue;
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(bn[j][pb], am[i][pa], acc[i][j]);
-            }
-        }
-    };
-    // B(kt) has landed once at most `N` younger loads are outstanding; tying bn to the statement keeps the MFMAs behind it
-#define X3P_WAIT_B(N)                                                                                                  \
-    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                             \
-                 : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[0][2]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(bn[1][2]))
-
-#pragma unroll
-    for (int s = 0; s < R - 1; ++s)
-        if (s < nk) issue(s);
-    if (nk > 0) loadb(0);
-
-    const int nfast = nk - (R - 1);                // iterations that still request a new A stage
-    int kt = 0;
-    for (; kt < nfast; ++kt) {
-        if (R == 3) X3P_WAIT_A(8);                 // 2 (R - 2) newer A loads + 6 of B(kt)
-        else if (R == 4) X3P_WAIT_A(10);
-        else if (R == 5) X3P_WAIT_A(12);
-        else X3P_WAIT_A(14);
-        issue(kt + R - 1);
-        splita(kt);
-        X3P_WAIT_B(2);
-        mfmas();
-        loadb(kt + 1);
-    }
-    for (; kt < nk; ++kt) {
-        const int newer = nk - 1 - kt;             // 0 .. R - 2 A stages still in flight behind A(kt)
-        if (newer >= 4) X3P_WAIT_A(14);
-        else if (newer == 3) X3P_WAIT_A(12);
-        else if (newer == 2) X3P_WAIT_A(10);
-        else if (newer == 1) X3P_WAIT_A(8);
-        else X3P_WAIT_A(6);
-        splita(kt);
-        X3P_WAIT_B(0);
-        mfmas();
-        if (kt + 1 < nk) loadb(kt + 1);
-    }
-#undef X3P_WAIT_B
-#endif
 #ifdef GT_ABL_X3_NOSTORE
     if (acc[0][0][0] != 12345.678f) return;
 #endif
