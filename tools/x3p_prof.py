@@ -98,6 +98,35 @@ def main():
         res[name] = r
         print(name, {k: v for k, v in r.items() if not k.startswith("timeline") and not k.startswith("one_cu")})
         print("  timeline (prologue, loop, epilogue blocks):", " ".join("%d/%d/%d" % tuple(x) for x in r["timeline_prologue_loop_epilogue"][::2]))
+    # the QKV projection with the head-norm epilogue (plain K' / V' tiles, no raw projection): the product path's launch
+    h, dk, pd = 4, 32, 2
+    d = h * dk
+    DP = H.round4(dk + pd)
+    sets = []
+    for r in range(3):
+        sets.append(dict(x=torch.randn(T, d, device=dev), w=torch.randn(3 * d, d, device=dev) * 0.1,
+                         b=torch.randn(3 * d, device=dev), pos=torch.rand(T, pd, device=dev),
+                         out=torch.empty(3, T, h, DP, device=dev), st=torch.zeros(2, T, h, 2, device=dev),
+                         g=torch.ones(2, h, dk, device=dev), bt=torch.zeros(2, h, dk, device=dev)))
+
+    def run_qkv(i):
+        q = sets[i % 3]
+        H.gemm(q["x"], q["w"], None, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=q["b"], precision="bf16x3",
+               hn=dict(gamma=q["g"], beta=q["bt"], pos=q["pos"], out=q["out"], stats=q["st"], h=h, dk=dk, p=pd,
+                       norm_mask=0b110, eps=1e-7, skip_raw=7, plain=True))
+    for i in range(6):
+        run_qkv(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(12):
+        run_qkv(i)
+    e1.record()
+    torch.cuda.synchronize()
+    r = analyse(stamps(((T + 127) // 128) * 3))
+    r["us_per_launch_events"] = round(e0.elapsed_time(e1) * 1000 / 12, 1)
+    res["qkv+headnorm N384 K128 plain tiles"] = r
+    print("qkv+headnorm", {k: v for k, v in r.items() if not k.startswith("timeline") and not k.startswith("one_cu")})
     if out_path:
         os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
         with open(out_path, "w") as f:
