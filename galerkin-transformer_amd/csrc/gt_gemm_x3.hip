@@ -324,6 +324,9 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
 #pragma unroll
         for (int q = 0; q < GPS; ++q)
             bv[sg][q] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nwave + sg * DK + 8 * q + 4 * lh) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // granule walk of the tile store below: lane's first granule (row, 16-byte column) and the step of 64 granules
+    const int g_r0 = lane / W4, g_c0 = lane - g_r0 * W4, g_dr = 64 / W4, g_dc = 64 - g_dr * W4;
+    const int nit = (32 * W4 + 63) >> 6, rstride = p.hn_h * DP;
     float posv[MI][4];                                        // hn_p <= 4 coordinates of this lane's rows (lane half 0 writes them)
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -394,13 +397,27 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
         }
         // the tile is wave-private and LDS operations of one wave execute in order: a compiler fence is enough
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the tile's rows go out as whole 16-byte granules, 64 per instruction (lane -> granule e = lane + 64 it of the
+        // 32 x W4 tile, walked incrementally), three instructions' worth of LDS reads in front of their three stores:
+        // the straightforward loop (a division and 64-bit address arithmetic per granule, every read waited for before
+        // its store) was 45 instructions + an LDS round trip per granule, 18 times per wave
         const int mbase = mrow - lr + 32 * i;
-        for (int e = lane; e < 32 * W4; e += 64) {
-            const int r = e / W4, c4 = e - r * W4;
-            if (mbase + r < p.M) {
-                const f32x4 val = *reinterpret_cast<const f32x4*>(stg + r * sw + 4 * c4);
-                *reinterpret_cast<f32x4*>(p.hn_out + (((int64_t)stream * p.M + mbase + r) * p.hn_h + head0) * DP + 4 * c4) = val;
+        float* __restrict__ gtile = p.hn_out + (((int64_t)stream * p.M + mbase) * p.hn_h + head0) * DP;
+        const int nrows = p.M - mbase < 32 ? p.M - mbase : 32;
+        int r = g_r0, c4 = g_c0;
+        for (int it = 0; it < nit; it += 3) {
+            f32x4 val[3];
+            int off[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                off[u] = r < nrows ? r * rstride + 4 * c4 : -1;
+                if (r < 32) val[u] = *reinterpret_cast<const f32x4*>(stg + r * sw + 4 * c4);
+                r += g_dr; c4 += g_dc;
+                if (c4 >= W4) { c4 -= W4; ++r; }
             }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (off[u] >= 0) *reinterpret_cast<f32x4*>(gtile + off[u]) = val[u];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next row tile overwrites the staging
     }
