@@ -78,6 +78,23 @@ __device__ inline float wave_sum(float v) {
     return v;
 }
 
+// Wave64 sum on the DPP path: six v_add_f32 with a lane-permuted operand, no LDS traffic and no waits (a __shfl_xor step is
+// a ds_bpermute_b32 + s_waitcnt).  The TOTAL ends up in lane 63 only (quad swaps, row shifts by 4 and 8, then the row
+// broadcasts 15 / 31 of the gfx9 DPP set); for kernels that reduce many values per lane and let one lane store them.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v) {      // the permuted operand; 0 where a lane has no source / is masked
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += dpp_term<0xb1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v += dpp_term<0x4e, 0xf>(v);      // quad_perm [2,3,0,1]
+    v += dpp_term<0x114, 0xf>(v);     // row_shr:4
+    v += dpp_term<0x118, 0xf>(v);     // row_shr:8   -> lanes 12..15 of a row hold the row sum
+    v += dpp_term<0x142, 0xa>(v);     // row_bcast:15 into rows 1, 3
+    v += dpp_term<0x143, 0xc>(v);     // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave sum
+    return v;
+}
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // tall-skinny weight-gradient path of gt_gemm (gt_tsmm.hip)
