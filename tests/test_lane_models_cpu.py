@@ -466,3 +466,168 @@ def test_packed_b_kernel_lane_map(conv):
     else:
         ref = A @ Bmat.T
     assert not np.isnan(C).any() and np.allclose(C, ref, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------- round 3, second half
+def _dpp(v, ctrl, row_mask=0xF):
+    """One v_mov_b32_dpp with old = 0 and bound_ctrl on a 64-lane vector (gfx9 DPP controls used by wave_sum_lane63 in
+    gt_common.h): quad_perm (ctrl < 0x100: two bits per lane of a quad), row_shr:n (0x110 + n), row_bcast:15 (0x142),
+    row_bcast:31 (0x143).  Lanes of a masked row and lanes without a source receive 0."""
+    out = np.zeros(64)
+    for lane in range(64):
+        row, idx = lane >> 4, lane & 15
+        if not (row_mask >> row) & 1:
+            continue
+        if ctrl < 0x100:
+            src = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3)
+        elif 0x111 <= ctrl <= 0x11F:
+            n = ctrl - 0x110
+            src = lane - n if idx >= n else None
+        elif ctrl == 0x142:
+            src = 16 * row - 1 if row > 0 else None              # lane 15 of the previous row
+        elif ctrl == 0x143:
+            src = 31 if row >= 2 else None                       # lane 31 into rows 2 and 3
+        else:
+            raise AssertionError(hex(ctrl))
+        out[lane] = v[src] if src is not None else 0.0
+    return out
+
+
+def test_wave_sum_lane63_dpp_model():
+    """wave_sum_lane63 (gt_common.h): after the six DPP adds lane 63 holds the sum of all 64 lanes (the other lanes hold
+    partial sums) -- the one-lane store of conv_resize_bwd_kernel's 72 accumulators reads lane 63."""
+    rng = np.random.default_rng(63)
+    for _ in range(4):
+        v = rng.standard_normal(64)
+        total = v.sum()
+        for ctrl, mask in ((0xB1, 0xF), (0x4E, 0xF), (0x114, 0xF), (0x118, 0xF), (0x142, 0xA), (0x143, 0xC)):
+            v = v + _dpp(v, ctrl, mask)
+        assert abs(v[63] - total) < 1e-12 * max(1.0, abs(total))
+
+
+@pytest.mark.parametrize("W4", [9, 10, 13, 17, 18, 20, 21])
+def test_headnorm_tile_store_walk(W4):
+    """x3_epilogue_hn (gt_gemm_x3.hip): the staged 32 x W4 tile of 16-byte granules is stored 64 granules per instruction;
+    lane l owns granules e = l + 64 it and walks (row, column) incrementally -- the walk equals divmod(e, W4), covers every
+    granule of the 32 rows exactly once in nit = ceil(32 W4 / 64) iterations (+ the chunk-of-three overrun, all past row 31)."""
+    nit = (32 * W4 + 63) >> 6
+    dr, dc = 64 // W4, 64 - (64 // W4) * W4
+    seen = np.zeros((32, W4), dtype=int)
+    for lane in range(64):
+        r, c = lane // W4, lane - (lane // W4) * W4
+        for it in range(0, nit, 3):
+            for u in range(3):
+                e = lane + 64 * (it + u)
+                assert (r, c) == divmod(e, W4)
+                if r < 32:
+                    seen[r, c] += 1
+                r, c = r + dr, c + dc
+                if c >= W4:
+                    r, c = r + 1, c - W4
+    assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("MI", [1, 2])
+def test_fast_epilogue_batches_cover_wave_tile(MI):
+    """x3_epilogue_fast (gt_gemm_x3.hip): a wave's (32 MI) x 64 tile leaves in 2 MI batches of four 256-byte row segments
+    per lane group; batch b reads staging rows 16 (b & 1) + 4 k + rsub of row tile b >> 1 and writes output row
+    mtile0 + 16 b + 4 k + rsub, columns 4 c4 .. + 3 -- every element exactly once, from the accumulator the MFMA left it in."""
+    acc = np.arange(MI * 2 * 64 * 16, dtype=np.int64).reshape(MI, 2, 64, 16)     # [i][j][lane][register]
+    out = -np.ones((32 * MI, 64), dtype=np.int64)
+    for i in range(MI):
+        stg = np.zeros((32, 68), dtype=np.int64)
+        for lane in range(64):
+            lr, lh = lane & 31, lane >> 5
+            for j in range(2):
+                for g in range(4):
+                    stg[lr, 32 * j + 8 * g + 4 * lh: 32 * j + 8 * g + 4 * lh + 4] = acc[i, j, lane, 4 * g: 4 * g + 4]
+        for b in (2 * i, 2 * i + 1):
+            for lane in range(64):
+                c4, rsub = lane & 15, lane >> 4
+                for k in range(4):
+                    row = 16 * b + 4 * k + rsub
+                    assert (out[row, 4 * c4: 4 * c4 + 4] == -1).all()
+                    out[row, 4 * c4: 4 * c4 + 4] = stg[16 * (b & 1) + 4 * k + rsub, 4 * c4: 4 * c4 + 4]
+    # 32x32 MFMA result map with the N-side tile as the A operand (x3_epilogue's header): lane (lr, lh) holds output row
+    # 32 i + lr and, in register 4 g + t of accumulator (i, j), column 32 j + 8 g + 4 lh + t
+    for i in range(MI):
+        for j in range(2):
+            for lane in range(64):
+                lr, lh = lane & 31, lane >> 5
+                for g in range(4):
+                    for t in range(4):
+                        assert out[32 * i + lr, 32 * j + 8 * g + 4 * lh + t] == acc[i, j, lane, 4 * g + t]
+
+
+@pytest.mark.parametrize("R", [3, 4, 5, 6])
+@pytest.mark.parametrize("nk", [1, 2, 3, 4, 7, 8, 9, 27])
+def test_packed_b_request_order_and_counted_waits(R, nk):
+    """K loop of gemm_x3p_kernel (gt_gemm_x3.hip) as a request queue that retires in order: requests B(0) A(0) .. A(R-2) |
+    B(1) A(R-1) | B(2) A(R) | ... (A = 2 loads, B = 6, the same in every iteration: zero stages / a repeated last B stage
+    past the end of K).  At each wait `vmcnt(N)` everything but the N youngest loads has landed: the stage about to be
+    consumed (A(kt) in its ring slot, B(kt) in its register set) must be among it, the slot an A request overwrites must
+    already have been consumed, and a register set must not be re-requested before its MFMAs were issued."""
+    queue = []                                   # issue order: (kind, stage)
+    landed_before = {}                           # wait index -> set of landed requests
+
+    def issue_a(s):
+        queue.extend([("A", s)] * 2)
+
+    def load_b(s, which):
+        queue.extend([("B", s, which)] * 6)
+
+    def wait(n):
+        return set(queue[:len(queue) - n]) if n else set(queue)
+
+    klast = nk - 1
+    consumed_a, slot_of = set(), {}
+    set_holds = {0: None, 1: None}
+
+    def request_a(s):
+        slot = s % R
+        prev = slot_of.get(slot)
+        assert prev is None or prev in consumed_a, f"slot {slot} of stage {prev} overwritten by stage {s} before use"
+        slot_of[slot] = s
+        issue_a(s)
+
+    def request_b(s, which):
+        held = set_holds[which]
+        assert held is None or ("done", held) in done, f"B set {which} re-requested before stage {held} was consumed"
+        set_holds[which] = s
+        load_b(s, which)
+
+    done = set()
+
+    def consume(kt, which, n_wait):
+        have = wait(n_wait)
+        assert ("A", kt) in have and ("B", min(kt, klast), which) in have or set_holds[which] != min(kt, klast) and False, \
+            f"stage {kt} consumed before it landed (vmcnt({n_wait}))"
+        assert set_holds[which] == kt
+        consumed_a.add(kt)
+        done.add(("done", kt))
+
+    request_b(0, 0)
+    for s in range(R - 1):
+        request_a(s)
+    # iteration 0
+    have = wait(2 * (R - 2))
+    assert ("A", 0) in have and ("B", 0, 0) in have
+    request_b(min(1, klast), 1)
+    request_a(R - 1)
+    consumed_a.add(0)
+    done.add(("done", 0))
+    kt = 1
+    while kt + 1 < nk:
+        consume(kt, 1, 2)                        # X3P_WAIT_AB(2, bn1)
+        # set 0 held stage kt - 1 (consumed): request B(kt + 1) into it, then A(kt + R - 1) into the slot of stage kt - 1
+        set_holds[0] = None if ("done", set_holds[0]) in done else set_holds[0]
+        request_b(kt + 1, 0)
+        request_a(kt + R - 1)
+        consume(kt + 1, 0, 2)                    # X3P_WAIT_AB(2, bn0)
+        set_holds[1] = None if ("done", set_holds[1]) in done else set_holds[1]
+        request_b(min(kt + 2, klast), 1)
+        request_a(kt + R)
+        kt += 2
+    if kt < nk:
+        consume(kt, 1, 2)
+    assert consumed_a >= set(range(nk))
