@@ -110,6 +110,36 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// Sign-alternating accumulation (GT_X3_ALT, default on).  Measured on gfx950 (tools/mfma_chain_probe.hip,
+// profiles/r05_mfma_chain_probe.json): the bf16 MFMA does not round its sum to nearest -- addends whose low bits fall below
+// the accumulator's guard bits are chopped toward -infinity.  Per instruction that is ~2^-9 ulp, but it has ONE direction:
+// a chain of six plane products per stage ends ~0.1 of its rms error below the exact sum in EVERY output element, whatever
+// the operand signs (K = 1152: mean signed error -2.7e-9 sum|a||b| against an rms of 2.4e-8; negate one operand and the
+// mean becomes +2.8e-9; the fp32 MFMA chain: 1e-11).  A coherent offset like that survives every later reduction over
+// tokens or pixels that the zero-mean part averages away: it was the 10x excess of the default arithmetic in the
+// exact-math gradient parity of the whole model.  The kernels therefore negate the operand rows of
+// odd index on both sides (the M-side row in registers, the N-side row at pack / split time; the packed-B kernel, which
+// has no register left for a per-lane sign, alternates its M side per 32-row tile instead), so the chain of output
+// (m, n) is accumulated with the sign (-1)^(m+n), and undo it on the accumulator before the epilogue: per-element
+// accuracy is unchanged, the offset alternates in a checkerboard and cancels in any sum over rows or columns.
+#ifndef GT_X3_ALT
+#define GT_X3_ALT 1
+#endif
+// sign of operand row `parity & 1`
+__device__ __forceinline__ float x3_alt_sign(int parity) { return (GT_X3_ALT && (parity & 1)) ? -1.f : 1.f; }
+// accumulator register e of a lane = output (m = the lane's own row, n = .. + 8 (e >> 2) + 4 lh + (e & 3)): n's parity is e & 1
+template <int NI, int NJ>
+__device__ __forceinline__ void x3_alt_undo(f32x16 (&acc)[NI][NJ], float rsgn) {
+#if GT_X3_ALT
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] *= (e & 1) ? -rsgn : rsgn;
+#endif
+}
+
 // Epilogue shared by both kernels.  Result registers of the 32x32 MFMA with the N-side tile as its A operand: lane
 // (lr = lane & 31, lh = lane >> 5) holds output row  mrow + 32 i  of accumulator (i, j) and the four 4-column groups
 // ncol + 32 j + 8 g .. + 3  (ncol already includes 4 * lh).
@@ -480,6 +510,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmP p) {
     auto r2s = [&](int buf) {                     // first use of the loaded registers: the vmcnt wait lands here
         if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, adoff, m0 + arow, ka, ra);
         if (LA == 1 && do_acs) asum += ((ra[0] + ra[1]) + (ra[2] + ra[3])) + ((ra[4] + ra[5]) + (ra[6] + ra[7]));
+        if (GT_X3_ALT) {                          // odd operand rows enter negated (tile origins are even)
+            const float sa_ = x3_alt_sign(arow), sb_ = x3_alt_sign(brow);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ra[j] *= sa_; rb[j] *= sb_; }
+        }
         char* st = smem + buf * STAGE;
         x3_store8<PLANES>(st, arow, akh, ra);
         x3_store8<PLANES>(st + PLANES * X3_PLANE, brow, bkh, rb);
@@ -552,6 +587,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmP p) {
     }
 
     __syncthreads();                               // every wave is done with the stages: they become staging tiles
+    x3_alt_undo(acc, x3_alt_sign(lr));
     x3_epilogue<2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * X3_EP_STG, z, b0, b1,
                    (int)blockIdx.y);
 }
@@ -700,6 +736,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     float asum[2] = {0.f, 0.f};
+    const float rsgn = x3_alt_sign(lr);
 
     const int nk = (kend > kbeg) ? (kend - kbeg + X3_BK - 1) / X3_BK : 0;
     // convolution: this lane's two pixels of the A image (fixed over the stages), and the running (tap, channel) of
@@ -784,6 +821,10 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
             x3r_frag<LA>(sa, row, lh, v);
             if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, adoff, m0 + row, kbase, v);
             if (LA == 1 && do_acs) asum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            if (GT_X3_ALT) {                      // row parity = lane parity on both sides (see x3_alt_undo)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= rsgn;
+            }
 #ifdef GT_ABL_X3_NOSPLIT_A       // ablation builds (tools/ablate_x3.sh): timing only, results are wrong
             for (int pl = 0; pl < PLANES; ++pl) am[i][pl] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(v[0]), __float_as_uint(v[2]), __float_as_uint(v[4]), __float_as_uint(v[6])});
 #else
@@ -794,6 +835,10 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
         for (int j = 0; j < 2; ++j) {
             float v[8];
             x3r_frag<LB>(sb, wn * 64 + 32 * j + lr, lh, v);
+            if (GT_X3_ALT) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= rsgn;
+            }
 #ifdef GT_ABL_X3_NOSPLIT_B
             for (int pl = 0; pl < PLANES; ++pl) bn[j][pl] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(v[1]), __float_as_uint(v[3]), __float_as_uint(v[5]), __float_as_uint(v[7])});
 #else
@@ -825,6 +870,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
             if (lh == 0 && m < p.M) p.acs[((int64_t)by * gridDim.z + z) * p.M + m] = t;
         }
     }
+    x3_alt_undo(acc, rsgn);
     if (HN > 0) {
         __syncthreads();                           // every wave is done with the ring: its first slots become staging
         x3_epilogue_hn<(HN > 0 ? HN : 32), 2>(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, lane,
@@ -863,6 +909,7 @@ __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict_
     for (int e = 0; e < 8; ++e) {
         const int k = k0 + e;
         v[e] = (n < N && k < K) ? (layout_b == 0 ? B[(int64_t)n * ldb + k] : B[(int64_t)k * ldb + n]) : 0.f;
+        v[e] *= x3_alt_sign(n);                    // GT_X3_ALT: odd rows of the N-side operand enter negated
     }
     uint32_t q[4][3];
 #pragma unroll
@@ -924,6 +971,10 @@ __global__ __launch_bounds__(256, ((HN > 0 || LA == 1 || CV == 1) ? 3 : GT_X3P_B
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = (kend + X3_BK - 1) / X3_BK;
+    // GT_X3_ALT in this kernel (no register to spare for a per-lane sign): the M-side sign alternates per 32-ROW TILE -- a
+    // compile-time constant of the unrolled tile loop for the 64-row wave tile (a source modifier of the split's first
+    // instructions), the wave's parity (a scalar) for the 32-row one -- the N-side per column (x3_pack_b_kernel)
+    const float tsgn = x3_alt_sign(BN == 64 ? __builtin_amdgcn_readfirstlane(wm) : 0);
     const float* cv_row[2] = {A, A};
     int cv_ok[2] = {0, 0}, cv_none[2] = {0, 0}, cv_tap = 0, cv_c0 = 0;      // cv_none: a stage past the end of K reads zeros
     const int cv_cb = (p.cv_C & 31) ? 16 : 32;
@@ -997,6 +1048,10 @@ __global__ __launch_bounds__(256, ((HN > 0 || LA == 1 || CV == 1) ? 3 : GT_X3P_B
             const int row = wrow + 32 * i + lr;
             x3r_frag<LA>(sa, row, lh, v);
             if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, 0, m0 + row, kbase, v);
+            if (GT_X3_ALT && (MI == 1 || (i & 1))) {   // M-side: the sign alternates per 32-row tile (see below)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = MI == 1 ? v[q] * tsgn : -v[q];
+            }
 #ifdef GT_ABL_X3_NOSPLIT_A       // ablation builds (tools/ablate_x3.sh): timing only, results are wrong
             for (int pl = 0; pl < PLANES; ++pl) am[pl] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(v[0]), __float_as_uint(v[2]), __float_as_uint(v[4]), __float_as_uint(v[6])});
 #else
@@ -1072,6 +1127,17 @@ __global__ __launch_bounds__(256, ((HN > 0 || LA == 1 || CV == 1) ? 3 : GT_X3P_B
     if (acc[0][0][0] != 12345.678f) return;
 #endif
 
+#if GT_X3_ALT
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float sg = MI == 1 ? tsgn : ((i & 1) ? -1.f : 1.f);
+                acc[i][j][e] *= (e & 1) ? -sg : sg;
+            }
+#endif
     __syncthreads();                               // every wave is done with the ring: its first slots become staging
     if constexpr (HN > 0)
         x3_epilogue_hn<(HN > 0 ? HN : 32), 2>(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, lane,

@@ -294,6 +294,40 @@ def get_precision() -> str:
     return {v: k for k, v in PREC_CODE.items()}[_precision[0]]
 
 
+# Per-launch-class arithmetic (diagnostics: tools/parity_bisect.py finds which class of contraction carries an error).
+# Classes of a gt_gemm launch:  "hn" QKV projection with the head-norm epilogue * "conv" implicit 3x3 convolution
+# (forward / data gradient) * "convw" its weight gradient * "wgrad" token-contracted weight gradients (both operands
+# x-contiguous, unbatched) * "batched" per-sample products (Q'P, dP^T, the dQ block) * "tok" every other token-row
+# product.  A class named here overrides both the module mode and a launch's own `precision=` argument.
+# GT_PREC_CLASS="wgrad=f32,tok=f32" sets it from the environment.
+_prec_class = {}
+
+
+def set_precision_classes(classes: Optional[dict]):
+    """classes: {"wgrad": "f32", ...} or None / {} to switch the override off; returns the previous mapping."""
+    old = dict(_prec_class)
+    _prec_class.clear()
+    for k, v in (classes or {}).items():
+        if k not in ("hn", "conv", "convw", "wgrad", "batched", "tok") or v not in PREC_CODE:
+            raise ValueError(f"set_precision_classes: bad entry {k}={v}")
+        _prec_class[k] = v
+    return old
+
+
+if os.environ.get("GT_PREC_CLASS"):
+    set_precision_classes(dict(kv.split("=") for kv in os.environ["GT_PREC_CLASS"].split(",") if kv))
+
+
+def gemm_class(layout_a: int, layout_b: int, batch, hn, conv, conv_wgrad: bool) -> str:
+    if hn is not None:
+        return "hn"
+    if conv is not None:
+        return "convw" if conv_wgrad else "conv"
+    if tuple(batch) != (1, 1):
+        return "batched"
+    return "wgrad" if (layout_a == 1 and layout_b == 1) else "tok"
+
+
 # ----------------------------------------------------------------------------------- scratch / rng state
 _ws_cache = {}            # (device, stream) -> [buffer, pinned]; insertion order = recency (re-inserted on use)
 _ws_retired = []          # outgrown / evicted PINNED buffers stay alive: a captured HIP graph has their pointer baked in
@@ -465,6 +499,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     d.batch0, d.batch1 = batch
     d.split_k = split_k
     d.precision = _precision[0] if precision is None else PREC_CODE[precision]
+    if _prec_class:
+        pc = _prec_class.get(gemm_class(layout_a, layout_b, batch, hn, conv, conv_wgrad))
+        if pc is not None:
+            d.precision = PREC_CODE[pc]
     d.A, d.lda, d.a_bs0, d.a_bs1 = A.data_ptr(), lda, a_bs[0], a_bs[1]
     d.B, d.ldb, d.b_bs0, d.b_bs1 = B.data_ptr(), ldb, b_bs[0], b_bs[1]
     d.C, d.ldc, d.c_bs0, d.c_bs1 = ptr(Cout), ldc, c_bs[0], c_bs[1]

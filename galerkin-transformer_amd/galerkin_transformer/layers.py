@@ -202,9 +202,19 @@ class Interp2dEncoder(nn.Module):
         widths = [c.out_channels for c in convs]
         cp = (max(widths) + 15) // 16 * 16
         size = self.interp_size[1]
-        size_ok = isinstance(size, float) or (isinstance(size, (tuple, list)) and not isinstance(size[0], float))
-        return (size_ok and widths[0] == widths[1] and widths[2] > 0 and widths[2] <= cp and sum(widths) % 4 == 0
-                and ops.scaler_chain_ok(convs, "relu"))
+        if isinstance(size, float):
+            h2, w2 = int(math.floor(h1 * size)), int(math.floor(w1 * size))
+        elif isinstance(size, (tuple, list)) and not isinstance(size[0], float):
+            h2, w2 = int(size[0]), int(size[1])
+        else:
+            return False
+        # what the segment resize kernels take (gt_resize.hip: check_seg, taps_fit): an even segment width (out_dim = 112 /
+        # 160 give 37 / 53: those run the conv1 / conv2 / conv3 + cat path below), and in the backward at most RS_MAXT = 6
+        # output rows / columns per input cell, i.e. an up-sampling factor below ~2
+        def taps_fit(ni, no):
+            return no <= 6 if ni <= 1 else 2.0 * (no - 1) / (ni - 1) + 2.0 <= 6.0
+        return (widths[0] == widths[1] and widths[0] % 2 == 0 and 0 < widths[2] <= cp and sum(widths) % 4 == 0
+                and h2 > 0 and w2 > 0 and taps_fit(h1, h2) and taps_fit(w1, w2) and ops.scaler_chain_ok(convs, "relu"))
 
     def forward(self, x, out_nhwc=False):
         """x (B, C, H, W).  ``out_nhwc`` returns (B, H', W', C') with the layout change fused into the

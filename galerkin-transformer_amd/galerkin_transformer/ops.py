@@ -432,8 +432,9 @@ class ScalerConvChainFn(Function):
     (layers.py:88-150: conv -> dropout -> activation).  Dropout and ReLU sit in the epilogue of the product (ReLU
     commutes with the non-negative dropout scale); the backward needs only the activated outputs: y > 0 <=> kept and
     pre-activation > 0.  Backward: one elementwise pass masks the incoming gradient of all three segments, then per
-    convolution (last to first) the data gradient is an implicit GEMM on the tap-reversed filter whose epilogue adds it
-    into the next segment's masked gradient in place, and the weight gradient runs next to it on the side stream."""
+    convolution (last to first) the data gradient is an implicit GEMM on the tap-reversed filter whose epilogue adds the
+    next segment's masked gradient to it (into a buffer of the backward: the incoming gradient is read-only), and the
+    weight gradient runs next to it on the side stream."""
 
     @staticmethod
     def forward(ctx, x0, w1, w2, w3, p_drop: float, grad_masked: bool = False):
@@ -468,13 +469,16 @@ class ScalerConvChainFn(Function):
         cin = (C0, CP, CP)
         scale = 1.0 / (1.0 - p_drop)
         # masked gradient of the three activated outputs in one pass (the dropout scale rides on the products' alpha)
-        # (grad_masked: the consumer -- bilinear_resize_seg(relu_input=True) -- has already zeroed it where cat <= 0; the data
-        # gradients below accumulate into it in place, so it must be this function's own buffer)
-        dpre = _c(g).reshape(T, 3 * CP) if grad_masked else H.act_bwd(_c(g).reshape(T, 3 * CP), cat, H.ACT_RELU)
+        # (grad_masked: the consumer -- bilinear_resize_seg(relu_input=True) -- has already zeroed it where cat <= 0).
+        # The incoming gradient is never written: the completed gradients of segments 0 and 1 (their own masked gradient
+        # + the data gradient of the convolution behind them) go to a buffer of this function, so a hook / retain_grad on
+        # the chain's output, or a second consumer summed by autograd, sees and produces what it should.
+        gsrc = _c(g).reshape(T, 3 * CP) if grad_masked else H.act_bwd(_c(g).reshape(T, 3 * CP), cat, H.ACT_RELU)
+        acc = torch.empty(T, 2 * CP, dtype=torch.float32, device=dev)
         dws = [None, None, None]
         dx0 = None
         for i in (2, 1, 0):
-            seg = dpre[:, i * CP:(i + 1) * CP]
+            seg, ldseg = (gsrc[:, 2 * CP:], 3 * CP) if i == 2 else (acc[:, i * CP:(i + 1) * CP], 2 * CP)
             xin = x0c.reshape(T, C0) if i == 0 else cat[:, (i - 1) * CP:i * CP]
             if ctx.needs_input_grad[1 + i]:
                 with H.side_branch(dev, T):
@@ -484,13 +488,12 @@ class ScalerConvChainFn(Function):
                 wd = _conv_k_order(_pad_filter(ws[i].flip(2, 3).transpose(0, 1), cin[i], CP))   # [cin, 9 CP] in k order
                 if i == 0:
                     dx0 = torch.empty(T, C0, dtype=torch.float32, device=dev)
-                    H.gemm(seg, wd, dx0, T, C0, 9 * CP, lda=3 * CP, ldb=9 * CP, ldc=C0, conv=(Hh, Ww, CP), alpha=scale,
+                    H.gemm(seg, wd, dx0, T, C0, 9 * CP, lda=ldseg, ldb=9 * CP, ldc=C0, conv=(Hh, Ww, CP), alpha=scale,
                            precision="bf16x3")
-                else:       # + the segment's own masked gradient (res, in place), through its ReLU / dropout mask (aux)
-                    prev = dpre[:, (i - 1) * CP:i * CP]
-                    H.gemm(seg, wd, prev, T, CP, 9 * CP, lda=3 * CP, ldb=9 * CP, ldc=3 * CP, conv=(Hh, Ww, CP),
-                           alpha=scale, aux_op=H.AUX_GT0, aux=cat[:, (i - 1) * CP:i * CP], ldaux=3 * CP, res=prev,
-                           ldr=3 * CP, precision="bf16x3")
+                else:       # + the segment's own masked gradient (res), through its ReLU / dropout mask (aux)
+                    H.gemm(seg, wd, acc[:, (i - 1) * CP:i * CP], T, CP, 9 * CP, lda=ldseg, ldb=9 * CP, ldc=2 * CP,
+                           conv=(Hh, Ww, CP), alpha=scale, aux_op=H.AUX_GT0, aux=cat[:, (i - 1) * CP:i * CP], ldaux=3 * CP,
+                           res=gsrc[:, (i - 1) * CP:i * CP], ldr=3 * CP, precision="bf16x3")
             H.join_side(dev)        # the next weight gradient reads the segment this data gradient has just completed
         return (None if dx0 is None else dx0.view(B, Hh, Ww, C0)), dws[0], dws[1], dws[2], None, None
 
@@ -512,8 +515,8 @@ def _scaler_wgrad(dseg, xin, w, B, Hh, Ww, CP, cin, scale):
 def scaler_conv_chain(x0, w1, w2, w3, p_drop: float = 0.0, training: bool = True, grad_masked: bool = False):
     """x0 (B, H, W, C0) channels-last -> (B, H, W, 3 CP): see ScalerConvChainFn; column segment i holds x_{i+1} in its
     first w_i.shape[0] columns, zeros behind them.  grad_masked: the ONLY consumer of the result is
-    bilinear_resize_seg(relu_input=True), whose backward hands the gradient over already multiplied by [result > 0] in a
-    buffer of its own (the in-place accumulation of the backward then works on it directly)."""
+    bilinear_resize_seg(relu_input=True), whose backward hands the gradient over already multiplied by [result > 0] (the
+    masking pass of the backward is then skipped; the gradient itself is only read)."""
     return ScalerConvChainFn.apply(x0, w1, w2, w3, float(p_drop) if training else 0.0, bool(grad_masked))
 
 

@@ -306,8 +306,10 @@ def _enc_kwargs(cfg: Mapping) -> dict:
 
 def fourier_transformer_2d(sd: Mapping[str, Tensor], cfg: Mapping, node: Tensor, pos: Tensor,
                            grid: Tensor, *, attn_drops: Optional[Sequence[AttnDrop]] = None,
-                           normalizer=None, relu_masks: Optional[Sequence[Tensor]] = None) -> Tensor:
-    """FourierTransformer2D.forward (model.py:953-1017) -> preds (B,n,n,n_targets)."""
+                           normalizer=None, relu_masks: Optional[Sequence[Tensor]] = None,
+                           ffn_activation: Optional[str] = None) -> Tensor:
+    """FourierTransformer2D.forward (model.py:953-1017) -> preds (B,n,n,n_targets).  ffn_activation: the FeedForward
+    activation of the encoder layers when a probe has swapped it (the reference builds them with 'relu', model.py:1127-1141)."""
     B = node.shape[0]
     ns = int(round(math.sqrt(pos.shape[1])))
     nh = cfg["n_hidden"]
@@ -319,6 +321,8 @@ def fourier_transformer_2d(sd: Mapping[str, Tensor], cfg: Mapping, node: Tensor,
         x = F.linear(x, sd["downscaler.id.weight"], sd["downscaler.id.bias"])
     x = x.reshape(B, -1, nh)
     ek = _enc_kwargs(cfg)
+    if ffn_activation is not None:
+        ek["activation_type"] = ffn_activation
     for li in range(cfg["num_encoder_layers"]):
         ad = None if attn_drops is None else attn_drops[li]
         x = encoder_layer(_sub(sd, f"encoder_layers.{li}."), x, pos, attn_drop=ad,
@@ -372,6 +376,8 @@ def fourier_transformer_2d_lite(sd: Mapping[str, Tensor], cfg: Mapping, node: Te
     x = torch.cat([node.reshape(B, -1, node.shape[-1]), pos], dim=-1)
     x = F.linear(x, sd["feat_extract.id.weight"], sd["feat_extract.id.bias"])
     ek = _enc_kwargs(cfg)
+    if ffn_activation is not None:
+        ek["activation_type"] = ffn_activation
     for li in range(cfg["num_encoder_layers"]):
         ad = None if attn_drops is None else attn_drops[li]
         x = encoder_layer(_sub(sd, f"encoder_layers.{li}."), x, pos, attn_drop=ad, **ek)

@@ -264,3 +264,23 @@ def test_fused_backward_and_packing_eligibility_cpu():
     assert _hip.galerkin_dkv_ln_supported(32, 2, 0b110) and _hip.galerkin_dkv_ln_supported(16, 1, 0b110)
     assert not _hip.galerkin_dkv_ln_supported(32, 2, 0b011) and not _hip.galerkin_dkv_ln_supported(64, 2, 0b110)
     assert not _hip.galerkin_dkv_ln_supported(30, 2, 0b110)
+
+
+def test_scaler_chain_eligibility_mirrors_the_segment_kernels_cpu():
+    """Interp2dEncoder._chain_ok must not admit what gt_bilinear2d_seg_fwd/bwd reject (gt_resize.hip: check_seg wants
+    an even segment width, the backward at most RS_MAXT = 6 contributing outputs per input cell) -- the chain path has no
+    fallback once taken.  out_dim = 128 (42 / 42 / 44) is the bench's case; 112 (37 / 37 / 38) and 160 (53 / 53 / 54) have odd
+    segments, and a >= 3x up-sampling second resize does not fit the backward's taps: those take the conv + cat path."""
+    from types import SimpleNamespace
+    from galerkin_transformer.layers import Interp2dEncoder
+
+    def ok(out_dim, size1, in_hw=141, B=128):
+        enc = Interp2dEncoder(1, out_dim, interp_size=((78, 78), size1), activation_type="relu", dropout=0.0)
+        x = SimpleNamespace(is_cuda=True, shape=(B, 1, in_hw, in_hw))
+        return enc._chain_ok(x, True)
+
+    assert ok(128, (43, 43))
+    assert not ok(112, (43, 43)) and not ok(160, (43, 43))
+    assert ok(128, (150, 150)) and not ok(128, (240, 240))       # 2 (no - 1)/(ni - 1) + 2 <= 6  <=>  no <= 155 from 78
+    assert ok(128, 0.555) and not ok(128, 3.5)
+    assert not ok(128, (43, 43), B=2)                            # below the token-row size of the narrow implicit GEMMs

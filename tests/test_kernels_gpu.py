@@ -1272,6 +1272,52 @@ def test_scaler_conv_chain_matches_conv2d(H, gpu_device, p_drop):
     assert rel_l2(x0.grad, xr.grad) < 5e-6
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_scaler_chain_with_masked_segment_resize_matches_reference(H, gpu_device, p_drop):
+    """The down-scaler's production combination (layers.py Interp2dEncoder.forward): scaler_conv_chain(grad_masked=True)
+    -> bilinear_resize_seg(relu_input=True, act="relu"), i.e. the in_gate branch of resize_nhwc_bwd_kernel handing the
+    chain a gradient that is already ReLU-masked, against conv2d x 3 + cat + F.interpolate(bilinear, align_corners) + ReLU
+    in fp64 (reference layers.py:497-512) -- at the tolerance of the other down-scaler tests.  Also: the gradient autograd
+    hands the chain is left untouched (retain_grad / hooks on the chain's output see the true gradient)."""
+    from galerkin_transformer import ops
+    dev = gpu_device
+    B, Hh, Ww, C0, Ho, Wo = 3, 78, 78, 128, 43, 43
+    widths = (42, 42, 44)
+    x0 = rnd(B, Hh, Ww, C0, dev=dev, seed=451).requires_grad_(True)
+    ws = [rnd(co, ci, 3, 3, dev=dev, seed=452 + i, scale=0.1).requires_grad_(True)
+          for i, (co, ci) in enumerate(zip(widths, (C0,) + widths[:2]))]
+    H.set_seed(79, dev)
+    buf = ops.scaler_conv_chain(x0, *ws, p_drop=p_drop, training=True, grad_masked=True)
+    buf.retain_grad()
+    seen = []
+    buf.register_hook(lambda gr: seen.append(gr.clone()))
+    CP = buf.shape[-1] // 3
+    y = ops.bilinear_resize_seg(buf, sum(widths), (Ho, Wo), widths[0], CP, act="relu", relu_input=True)
+    cot = rnd(*y.shape, dev=dev, seed=459)
+    y.backward(cot)
+    torch.cuda.synchronize()
+    assert len(seen) == 1 and torch.equal(buf.grad, seen[0])          # nobody wrote into the handed-over gradient
+    got = [buf[..., i * CP:i * CP + widths[i]] for i in range(3)]
+    xr = x0.detach().double().requires_grad_(True)
+    wr = [w.detach().double().requires_grad_(True) for w in ws]
+    scale = 1.0 / (1.0 - p_drop)
+    cur, refs = xr, []
+    for i in range(3):
+        pre = torch.nn.functional.conv2d(cur.permute(0, 3, 1, 2), wr[i], padding=1).permute(0, 2, 3, 1)
+        keep = ((got[i].double() > 0) | (pre <= 0)).double() if p_drop > 0 else torch.ones_like(pre)
+        cur = torch.relu(pre) * keep * scale
+        refs.append(cur)
+    rcat = torch.cat(refs, -1).permute(0, 3, 1, 2)
+    ry = torch.relu(torch.nn.functional.interpolate(rcat, size=(Ho, Wo), mode="bilinear", align_corners=True)).permute(0, 2, 3, 1)
+    ry.backward(cot.double())
+    assert rel_l2(y, ry) < 3e-6
+    for i in range(3):
+        assert rel_l2(ws[i].grad, wr[i].grad) < 5e-6, i
+    assert rel_l2(x0.grad, xr.grad) < 5e-6
+    # the gradient handed over is the masked one: zero wherever the chain's output is not positive
+    assert torch.equal(buf.grad[buf.detach() <= 0], torch.zeros_like(buf.grad[buf.detach() <= 0]))
+
+
 def test_resize_seg_equals_dense_resize(H, gpu_device):
     """gt_bilinear2d_seg_fwd/bwd (the last resize of the down-scaler reading the padded three-segment buffer) == the dense
     channels-last resize of the gathered real channels, forward and backward (padding columns of dx: zero)."""
