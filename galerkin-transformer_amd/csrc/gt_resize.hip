@@ -494,6 +494,12 @@ __device__ __forceinline__ void load_patch_clamped(const float* __restrict__ xp,
     }
 }
 
+// Parity hook (gt_debug_conv0_mask): when set, the forward records the ReLU decision it takes for every fine-grid value
+// of the fused convolution it evaluates -- mask[(b * Cout + c) * H * W + pixel] = 1 (kept and positive) or 0 -- so a
+// float64 checker can replay exactly these decisions (tests/test_bench_kernels_gpu.py; pixels no output touches stay as
+// the caller initialised them).  One pointer load per thread when unset.
+__device__ unsigned char* g_conv0_mask = nullptr;
+
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP p) {
     __shared__ float sw[CR_CH * CIN * 9];
@@ -511,6 +517,7 @@ __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP 
     const int oy = e / p.Wo, ox = e - oy * p.Wo;
     const Axis ay = axis_of(oy, p.sy, p.H), ax = axis_of(ox, p.sx, p.W);
     const uint32_t key = drop_key_dev(p.drop);
+    unsigned char* const dbg_mask = g_conv0_mask;
     // 3x3 input patches around the 4 source pixels, kept in registers for every output channel
     float pt[CIN][4][9];
     uint32_t toff[4];
@@ -545,6 +552,7 @@ __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP 
             for (int t = 0; t < 4; ++t) {
                 const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
                 cv[t] = fmaxf(cv[t] * m, 0.f);
+                if (dbg_mask && c < p.Cout) dbg_mask[cbase + toff[t]] = cv[t] > 0.f ? 1 : 0;
             }
             // same association as the stand-alone resize: l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
             r4[jj] = fmaxf(ay.l0 * (ax.l0 * cv[0] + ax.l1 * cv[1]) + ay.l1 * (ax.l0 * cv[2] + ax.l1 * cv[3]), 0.f);
@@ -955,6 +963,12 @@ static int conv_resize_fwd(const float* x, const float* w, float* y, int32_t B, 
     }
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gt_debug_conv0_mask(void* mask, void* stream) {
+    unsigned char* m = reinterpret_cast<unsigned char*>(mask);
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GT_EINVAL;     // launches in flight keep their setting
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv0_mask), &m, sizeof(m), 0, hipMemcpyHostToDevice);
 }
 
 extern "C" int gt_conv3x3_resize_fwd(const float* x, const float* w, float* y, int32_t B, int32_t Cin,

@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 14          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 15          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -140,6 +140,10 @@ _PROTOS = {
     "gt_conv3x3_resize_bwd_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 7 + [C.POINTER(GtDropout), C.c_int32,
                                                                                C.c_void_p, C.c_void_p, C.c_int64,
                                                                                C.c_void_p]),
+    "gt_debug_conv0_mask": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gt_conv3x3_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 5 +
+                              [C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gt_conv3x3_wgrad_nhwc_ws_bytes": (C.c_int64, [C.c_int32] * 5),
     "gt_bilinear2d_seg_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p]),
     "gt_bilinear2d_seg_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p, C.c_void_p]),
     "gt_bilinear2d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
@@ -820,6 +824,33 @@ def conv3x3_resize_fwd(x: torch.Tensor, w: torch.Tensor, size, drop: Optional[Gt
                             stream_ptr()),
                  shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_fwd")
     return y
+
+
+def conv3x3_wgrad_nhwc(gy: torch.Tensor, ldg: int, x: torch.Tensor, ldx: int, B: int, Hh: int, Ww: int, Cin: int,
+                       Cout: int, alpha: float = 1.0) -> torch.Tensor:
+    """dw [Cout, Cin, 3, 3] of a narrow channels-last 3x3 convolution (gt_hip.h: gt_conv3x3_wgrad_nhwc).  gy / x: 2-D views
+    [B*H*W, >= Cout / Cin] whose row pitch is ldg / ldx (column segments of wider buffers are read in place).  Raises
+    GtNotSupported for shapes the kernel does not take (the caller owns the fallback)."""
+    need_f32_cuda(gy, x)
+    L = lib()
+    need = L.gt_conv3x3_wgrad_nhwc_ws_bytes(B, Hh, Ww, Cin, Cout)
+    if need <= 0:
+        raise GtNotSupported("gt_conv3x3_wgrad_nhwc: " + _ERR[-4])
+    ws = workspace(gy.device, need)
+    dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=gy.device)
+    check(_timed("gt_conv3x3_wgrad_nhwc", 18.0 * B * Hh * Ww * Cin * Cout, 4.0 * B * Hh * Ww * (Cin + Cout),
+                 lambda: L.gt_conv3x3_wgrad_nhwc(gy.data_ptr(), ldg, x.data_ptr(), ldx, dw.data_ptr(), B, Hh, Ww, Cin, Cout,
+                                                 float(alpha), ws.data_ptr(), ws.numel(), stream_ptr()),
+                 shape=(B, Hh, Ww, Cin, Cout)), "gt_conv3x3_wgrad_nhwc")
+    return dw
+
+
+def debug_conv0_mask(mask: Optional[torch.Tensor]):
+    """Register (or, with None, remove) the byte buffer [B, Cout, H, W] in which gt_conv3x3_resize_fwd records its ReLU
+    decisions (gt_hip.h: gt_debug_conv0_mask) -- parity tests replay them in the float64 checker."""
+    if mask is not None and (mask.dtype != torch.uint8 or not mask.is_cuda or not mask.is_contiguous()):
+        raise TypeError("debug_conv0_mask: a contiguous uint8 device tensor")
+    check(lib().gt_debug_conv0_mask(ptr(mask), stream_ptr()), "gt_debug_conv0_mask")
 
 
 def conv3x3_resize_bwd(g: torch.Tensor, y: torch.Tensor, x: torch.Tensor, w: torch.Tensor,

@@ -53,6 +53,16 @@ def set_relu_mask_sink(sink):
     _relu_mask_sink[0] = sink
 
 
+_scaler_mask_sink = [None]
+
+
+def set_scaler_mask_sink(sink):
+    """sink: a list that every scaler_conv_chain forward appends its three ReLU masks to ([B, H, W, width_i] booleans:
+    output > 0, i.e. kept by the dropout and positive), or None.  Parity runs replay them in the checker, like
+    set_relu_mask_sink's."""
+    _scaler_mask_sink[0] = sink
+
+
 _qkvnorm_fused = [True]         # QKV projection + head norm in one launch when the library supports the shape
 _next_salt = H.next_salt        # call-site salt counter (rewound by _hip.set_seed / utils.get_seed)
 
@@ -454,6 +464,9 @@ class ScalerConvChainFn(Function):
             H.gemm(A, wf, cat[:, i * CP:(i + 1) * CP], T, CP, 9 * cin[i], lda=(C0 if i == 0 else 3 * CP), ldb=9 * cin[i],
                    ldc=3 * CP, conv=(Hh, Ww, cin[i]), act=H.ACT_RELU,
                    drop=H.dropout_desc(p_drop, salt + i, dev) if p_drop > 0 else None, precision="bf16x3")
+        if _scaler_mask_sink[0] is not None:
+            c4 = cat.view(B, Hh, Ww, 3 * CP)
+            _scaler_mask_sink[0].append([c4[..., i * CP:i * CP + w.shape[0]] > 0 for i, w in enumerate(ws)])
         ctx.save_for_backward(x0c, w1, w2, w3, cat)
         ctx.cfg = (p_drop, CP, grad_masked)
         return cat.view(B, Hh, Ww, 3 * CP)
@@ -479,10 +492,10 @@ class ScalerConvChainFn(Function):
         dx0 = None
         for i in (2, 1, 0):
             seg, ldseg = (gsrc[:, 2 * CP:], 3 * CP) if i == 2 else (acc[:, i * CP:(i + 1) * CP], 2 * CP)
-            xin = x0c.reshape(T, C0) if i == 0 else cat[:, (i - 1) * CP:i * CP]
+            xin, ldx = (x0c.reshape(T, C0), C0) if i == 0 else (cat[:, (i - 1) * CP:i * CP], 3 * CP)
             if ctx.needs_input_grad[1 + i]:
                 with H.side_branch(dev, T):
-                    dws[i] = _scaler_wgrad(seg, xin, ws[i], B, Hh, Ww, CP, cin[i], scale)
+                    dws[i] = _scaler_wgrad(seg, ldseg, xin, ldx, ws[i], B, Hh, Ww, CP, cin[i], scale)
             # dx[pix][ci] = scale * sum_tap sum_co dpre[pix - shift(tap)][co] W[co][ci][tap]: tap' = 8 - tap
             if i > 0 or ctx.needs_input_grad[0]:
                 wd = _conv_k_order(_pad_filter(ws[i].flip(2, 3).transpose(0, 1), cin[i], CP))   # [cin, 9 CP] in k order
@@ -498,12 +511,21 @@ class ScalerConvChainFn(Function):
         return (None if dx0 is None else dx0.view(B, Hh, Ww, C0)), dws[0], dws[1], dws[2], None, None
 
 
-def _scaler_wgrad(dseg, xin, w, B, Hh, Ww, CP, cin, scale):
-    """dW[co][ci][tap] = scale * sum_pix dseg[pix][co] xin[pix + shift(tap)][ci] for one narrow convolution.  Both operands
-    are activations (no split to hoist) and one side is <= 48 wide: the library's channels-last fp32 weight-gradient
-    kernel on dense copies of the two column segments does this at ~60 % of the fp32 matrix peak, which the
-    split-operand engine does not beat here."""
+_scaler_wgrad_hip = [os.environ.get("GT_SCALER_WGRAD", "hip") != "miopen"]     # A/B switch (tools / tests)
+
+
+def _scaler_wgrad(dseg, ldg, xin, ldx, w, B, Hh, Ww, CP, cin, scale):
+    """dW[co][ci][tap] = scale * sum_pix dseg[pix][co] xin[pix + shift(tap)][ci] for one narrow convolution: both operands are
+    activations (column segments read in place through their row pitches), one side is <= 48 wide, nine taps share them:
+    gt_conv3x3_wgrad_nhwc (gt_convw.hip) -- operands split once per block into LDS planes, all nine taps co-resident.
+    Shapes outside that kernel (or GT_SCALER_WGRAD=miopen, the round-3 path) use the library's channels-last fp32
+    weight-gradient kernel on dense copies of the two segments."""
     co, ci = w.shape[0], w.shape[1]
+    if _scaler_wgrad_hip[0]:
+        try:
+            return H.conv3x3_wgrad_nhwc(dseg, ldg, xin, ldx, B, Hh, Ww, cin, CP, alpha=scale)[:co, :ci].contiguous()
+        except H.GtNotSupported:
+            pass
     gd = dseg.contiguous().view(B, Hh, Ww, CP).permute(0, 3, 1, 2)                      # dense channels-last
     xd = xin.contiguous().view(B, Hh, Ww, cin).permute(0, 3, 1, 2)
     wp = torch.empty(CP, cin, 3, 3, dtype=torch.float32, device=w.device).contiguous(memory_format=torch.channels_last)

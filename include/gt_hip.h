@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 14
+#define GT_ABI_VERSION 15
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -463,6 +463,28 @@ int gt_conv3x3_resize_bwd_nhwc(const float* g, const float* y, const float* x, c
                                int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                                const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
                                void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight gradient of a NARROW channels-last 3x3 convolution (padding 1, stride 1, no bias): the three convolutions of the
+ * down-scaler's chain, reference libs/layers.py:463-482 (Interp2dEncoder conv1 / conv2 / conv3 = Conv2dResBlock,
+ * layers.py:88-150), whose weight gradients autograd would compute with cudnn/MIOpen's conv2d weight backward:
+ *     dw[co][ci][ky][kx] = alpha * sum_{b,y,x} gy[(b H + y) W + x][co] * x[(b H + y + ky - 1) W + x + kx - 1][ci]
+ * gy / x: channels-last images with pixel pitches ldg >= Cout / ldx >= Cin (a column segment of a wider buffer is read in
+ * place), 16-byte aligned, pitches multiples of 4.  dw: [Cout][Cin][3][3], the reference's layout.  Arithmetic: the three-plane
+ * split-operand products of gt_gemm (GT_PREC_BF16X3), each operand value split once per block (gt_convw.hip).
+ * GT_ENOTSUP unless Cout == 48, Cin % 16 == 0, W <= 80.  Deterministic: partial results per (image, row chunk) in ws
+ * (>= gt_conv3x3_wgrad_nhwc_ws_bytes), summed in a fixed order.
+ * ------------------------------------------------------------------------------------------- */
+int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* x, int64_t ldx, float* dw, int32_t B, int32_t H,
+                          int32_t W, int32_t Cin, int32_t Cout, float alpha, void* ws, int64_t ws_bytes, void* stream);
+int64_t gt_conv3x3_wgrad_nhwc_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+
+/* Parity hook for the fused convolution's ReLU (reference: Conv2dResBlock's activation, layers.py:139-149, which the fused
+ * pass never materialises): with a device buffer `mask` [B, Cout, H, W] of bytes registered, every following
+ * gt_conv3x3_resize_fwd(_nhwc) records the decision it takes for each fine-grid value it evaluates (1: kept by the dropout
+ * and positive, 0: not; values no output pixel touches keep what the caller stored).  NULL switches it off.  The pointer is
+ * a process-wide device variable: tests only. */
+int gt_debug_conv0_mask(void* mask, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer step on ONE flat fp32 bucket: what utils_ft.py:676-681 does per batch

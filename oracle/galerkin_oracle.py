@@ -270,15 +270,31 @@ def _interp(x: Tensor, size) -> Tensor:
 
 
 def interp_downscaler(sd: Mapping[str, Tensor], node: Tensor, *, interp_size,
-                      activation: Optional[str] = "silu") -> Tensor:
-    """node: (B,n,n,Cin) -> (B,nc,nc,Cout).  conv0 -> interp -> act -> conv1,2,3 -> cat -> interp -> act."""
+                      activation: Optional[str] = "silu", relu_masks: Optional[Mapping] = None) -> Tensor:
+    """node: (B,n,n,Cin) -> (B,nc,nc,Cout).  conv0 -> interp -> act -> conv1,2,3 -> cat -> interp -> act
+    (layers.py:483-512).  relu_masks (ReLU down-scaler only, mask replay for parity runs at sizes where some pre-activation
+    lies within rounding of the kink): {"conv0": (B,C,n,n) with 1 / 0 = the decision to replay and anything else = take
+    this function's own, "chain": three (B,nc',nc',c_i) 0/1 masks of conv1..3}.  The two ReLUs behind the interpolations act
+    on non-negative values and have no kink to replay."""
     act = _act(activation)
     x = node.permute(0, 3, 1, 2)
-    x = act(F.conv2d(x, sd["downsample.conv0.conv.0.weight"], padding=1))
+
+    def gated(pre, m):
+        if m is None:
+            return act(pre)
+        m = m.to(pre.device)
+        own = (pre > 0)
+        dec = torch.where(m == 1, torch.ones_like(own), torch.where(m == 0, torch.zeros_like(own), own))
+        return pre * dec.to(pre.dtype)
+
+    rm = relu_masks or {}
+    chain = rm.get("chain") or [None, None, None]
+    chain = [None if m is None else m.permute(0, 3, 1, 2) for m in chain]
+    x = gated(F.conv2d(x, sd["downsample.conv0.conv.0.weight"], padding=1), rm.get("conv0"))
     x = act(_interp(x, interp_size[0]))
-    x1 = act(F.conv2d(x, sd["downsample.conv1.conv.0.weight"], padding=1))
-    x2 = act(F.conv2d(x1, sd["downsample.conv2.conv.0.weight"], padding=1))
-    x3 = act(F.conv2d(x2, sd["downsample.conv3.conv.0.weight"], padding=1))
+    x1 = gated(F.conv2d(x, sd["downsample.conv1.conv.0.weight"], padding=1), chain[0])
+    x2 = gated(F.conv2d(x1, sd["downsample.conv2.conv.0.weight"], padding=1), chain[1])
+    x3 = gated(F.conv2d(x2, sd["downsample.conv3.conv.0.weight"], padding=1), chain[2])
     out = torch.cat([x1, x2, x3], dim=1)
     out = act(_interp(out, interp_size[1]))
     return out.permute(0, 2, 3, 1)
@@ -307,7 +323,7 @@ def _enc_kwargs(cfg: Mapping) -> dict:
 def fourier_transformer_2d(sd: Mapping[str, Tensor], cfg: Mapping, node: Tensor, pos: Tensor,
                            grid: Tensor, *, attn_drops: Optional[Sequence[AttnDrop]] = None,
                            normalizer=None, relu_masks: Optional[Sequence[Tensor]] = None,
-                           ffn_activation: Optional[str] = None) -> Tensor:
+                           ffn_activation: Optional[str] = None, scaler_masks: Optional[Mapping] = None) -> Tensor:
     """FourierTransformer2D.forward (model.py:953-1017) -> preds (B,n,n,n_targets).  ffn_activation: the FeedForward
     activation of the encoder layers when a probe has swapped it (the reference builds them with 'relu', model.py:1127-1141)."""
     B = node.shape[0]
@@ -315,7 +331,7 @@ def fourier_transformer_2d(sd: Mapping[str, Tensor], cfg: Mapping, node: Tensor,
     nh = cfg["n_hidden"]
     if cfg.get("downscaler_size"):
         x = interp_downscaler(_sub(sd, "downscaler."), node, interp_size=cfg["downscaler_size"],
-                              activation=cfg.get("downscaler_activation"))
+                              activation=cfg.get("downscaler_activation"), relu_masks=scaler_masks)
     else:
         x = torch.cat([node, pos.reshape(B, ns, ns, -1)], dim=-1)
         x = F.linear(x, sd["downscaler.id.weight"], sd["downscaler.id.bias"])
@@ -376,8 +392,6 @@ def fourier_transformer_2d_lite(sd: Mapping[str, Tensor], cfg: Mapping, node: Te
     x = torch.cat([node.reshape(B, -1, node.shape[-1]), pos], dim=-1)
     x = F.linear(x, sd["feat_extract.id.weight"], sd["feat_extract.id.bias"])
     ek = _enc_kwargs(cfg)
-    if ffn_activation is not None:
-        ek["activation_type"] = ffn_activation
     for li in range(cfg["num_encoder_layers"]):
         ad = None if attn_drops is None else attn_drops[li]
         x = encoder_layer(_sub(sd, f"encoder_layers.{li}."), x, pos, attn_drop=ad, **ek)

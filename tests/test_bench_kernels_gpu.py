@@ -15,10 +15,11 @@ T = 33 696), are compared with the CPU oracle in float64 at the 1e-5 bar, and as
 ReLU kinks.  At these sizes a layer evaluates ~1e7 ReLUs and some pre-activation always lies within fp32 rounding
 (|pre| ~ 1e-7) of zero: there the derivative is decided by the last bit of the accumulation, ANY two fp32 implementations
 (the oracle in float32 on two hosts included -- measured) can disagree, and one disagreement moves the parameter
-gradients by ~1e-4 relative.  So the FeedForward ReLU decisions of the HIP run are captured (ops.set_relu_mask_sink) and
-replayed in the float64 oracle, exactly as the attention dropout masks are; the down-scaler's ReLUs (inside fused conv /
-resize kernels, no mask to capture) only touch the four down-scaler filters, which get a kink-aware bound in (b); a second,
-all-smooth run (attention dropout off, SiLU down-scaler) is gated relative to the float32 oracle's own distance from float64.
+gradients by ~1e-4 relative.  So the ReLU decisions of the HIP run are captured and replayed in the float64 oracle, exactly
+as the attention dropout masks are: the FeedForward's (ops.set_relu_mask_sink), the down-scaler chain's
+(ops.set_scaler_mask_sink: its saved outputs > 0) and the fused conv0 + resize kernel's (_hip.debug_conv0_mask: the library
+records the decision of every fine-grid value it evaluates).  Every gate is relative to the float32 ORACLE's own distance
+from the float64 one on the same replayed decisions: max(2e-5, 12 x that) per parameter, no special cases.
 """
 import json
 import math
@@ -159,21 +160,22 @@ def _zero_dropout_cfg(bench):
 def test_whole_model_darcy141_vs_oracle(gpu_device, mode, scaler_act):
     """FourierTransformer2D of the bench configuration (down-scaler -> 6 layers -> implicit-conv up-scaler -> upsample_fc
     -> 2 x SpectralConv2d -> head) at its own size, B = 18 / 9: prediction and every parameter gradient vs the float64 oracle
-    (FeedForward ReLU masks replayed).  The prediction is held to 1e-5 (the north-star bar) in both runs.
+    with the run's ReLU decisions replayed.  The prediction is held to 1e-5 (the north-star bar) in both runs, every
+    gradient to max(2e-5, 12 x the float32 oracle's own deviation of that parameter).
 
     ("replay", "relu") is the bench configuration with the attention masks replayed (the reference applies that dropout
-    in train and eval alike): every gradient outside the down-scaler at 2e-5 (the float32 oracle itself sits at 2-7e-6
-    from the float64 one here; measured HIP maximum 9.4e-6); the four down-scaler filters pass through the down-scaler's
-    own ~1e8 ReLU evaluations (fused kernels, no mask to replay) and get the kink-aware bound 2e-3.
+    in train and eval alike).  Measured (round 4): every gradient outside the down-scaler <= 5.2e-6 (float32 oracle 6.1e-6);
+    the four down-scaler filters 1.6e-4 / 5.9e-5 / 1.2e-5 / 2.6e-5 -- and the float32 ORACLE shows the same four numbers to
+    three digits (1.61e-4 / 5.93e-5 / 1.14e-5 / 2.63e-5): F.interpolate(align_corners=True) computes its source coordinates
+    in the tensor's dtype, so every float32 evaluation of the reference (the reference's own CPU path included) shares
+    that offset from the float64 one; the HIP result is additionally held to the float32 oracle directly (2e-5) there.
     ("off", "silu") is the exact-math run (no attention dropout, smooth down-scaler): on these strongly correlated
-    activations the un-masked K^T V / Q(.) backward cancels heavily and float32 arithmetic itself is ill-conditioned -- the
-    float32 ORACLE deviates from the float64 one by up to 7e-5 (median 5e-6) on the encoder parameters, growing from the
-    last layer to the first.  Measured HIP: fp32 MFMA kernels (GT_PRECISION=f32) 3.5e-5 / 3.6e-6 (max / median) = the
-    oracle's class; default split-operand arithmetic 2.9e-4 / 4.6e-5, i.e. ~10x the float32 noise in this mode only (the
-    switches GT_PLAIN_TILES / GT_DKV_LN / GT_DUAL_STREAM do not move it; single layers on the same activations with a
-    random cotangent sit at 2e-5 worst, dx 2.6e-7 -- tools/parity_probe2.py).  Gate: every gradient within
-    max(2e-5, 12 x the float32 oracle's own deviation of that parameter); the encoder parameters in the default
-    arithmetic get the recorded bound 1e-3 instead (DESIGN.md section 2 states this as a known limit of the exact-math mode)."""
+    activations the un-masked K^T V / Q(.) backward cancels heavily and float32 arithmetic itself is ill-conditioned (the
+    float32 oracle deviates from the float64 one by up to 1e-5 on the encoder parameters at B = 9).  Until round 4 the
+    default split-operand arithmetic sat ~10x above that (1.6e-4 at B = 9): the bf16 MFMA chops addends toward -infinity,
+    a coherent offset that every reduction over tokens preserves (tools/parity_bisect.py, tools/mfma_chain_probe.hip,
+    DESIGN.md section 2); with the sign-alternating accumulation of gt_gemm_x3.hip it measures 1.2e-5 (float32 oracle
+    9.2e-6, fp32-MFMA kernels 1.4e-5) and takes the same gate as everything else."""
     sys.path.insert(0, ROOT)
     import bench
     import galerkin_transformer as gt
@@ -204,49 +206,64 @@ def test_whole_model_darcy141_vs_oracle(gpu_device, mode, scaler_act):
         out.backward(cot.to(dev))
         return out
 
-    def oracle(dt, rm):
+    def oracle(dt, rm, sm=None):
         sd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
         return O.grads_of(
             lambda s: O.fourier_transformer_2d(s, cfg, b["node"].to(dt), b["pos"].to(dt), b["grid"].to(dt),
-                                               attn_drops=masks, relu_masks=rm), sd, [], cot.to(dt))
+                                               attn_drops=masks, relu_masks=rm, scaler_masks=sm), sd, [], cot.to(dt))
 
     gt.set_attention_dropout(mode)
-    relu_masks = []
+    relu_masks, chain_masks = [], []
+    conv0_mask = None
     ops.set_relu_mask_sink(relu_masks)
+    if scaler_act == "relu":        # the ReLU decisions of the down-scaler: the three chain convolutions' from their saved
+        # outputs, the fused conv0's through the library's parity hook (2 = "no output pixel touches this value")
+        ops.set_scaler_mask_sink(chain_masks)
+        conv0_mask = torch.full((B, cfg["n_hidden"], bench.N_FINE, bench.N_FINE), 2, dtype=torch.uint8, device=dev)
+        _hip.debug_conv0_mask(conv0_mask)
     try:
         out = run()
         torch.cuda.synchronize()
         ops.set_relu_mask_sink(None)
+        ops.set_scaler_mask_sink(None)
+        _hip.debug_conv0_mask(None)
         assert len(relu_masks) == L
         rm = [m.cpu() for m in relu_masks]
-        ref, _, ref_dp = oracle(torch.float64, rm)
+        sm = None
+        if scaler_act == "relu":
+            assert len(chain_masks) == 1 and int((conv0_mask < 2).sum()) > 0
+            sm = {"conv0": conv0_mask.cpu(), "chain": [m.cpu().to(torch.uint8) for m in chain_masks[0]]}
+        ref, _, ref_dp = oracle(torch.float64, rm, sm)
         errs = {"out": rel_l2(out, ref)}
         for k, v in dict(model.named_parameters()).items():
             errs[k] = rel_l2(v.grad, ref_dp[k])
         kernels = set(_kernels_of(run))
     finally:
         ops.set_relu_mask_sink(None)
+        ops.set_scaler_mask_sink(None)
+        _hip.debug_conv0_mask(None)
         gt.set_attention_dropout("reference")
-    noise = {}
-    if mode == "off":                                      # the float32 oracle's own distance from the float64 one
-        y32, _, dp32 = oracle(torch.float32, rm)
-        noise = {k: rel_l2(dp32[k], ref_dp[k]) for k in ref_dp}
-        noise["out"] = rel_l2(y32, ref)
+    # the float32 oracle's own distance from the float64 one (same replayed decisions): the yardstick of every gate below
+    y32, _, dp32 = oracle(torch.float32, rm, sm)
+    noise = {k: rel_l2(dp32[k], ref_dp[k]) for k in ref_dp}
+    noise["out"] = rel_l2(y32, ref)
+    vs32 = {k: rel_l2(v.grad, dp32[k]) for k, v in dict(model.named_parameters()).items()}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"parity_whole_model_{mode}_{scaler_act}.json"), "w") as f:
-        json.dump({"hip_vs_f64": errs, "oracle_f32_vs_f64": noise, "precision": gt.get_precision()}, f, indent=1)
+        json.dump({"hip_vs_f64": errs, "oracle_f32_vs_f64": noise, "hip_vs_oracle_f32": vs32,
+                   "precision": gt.get_precision()}, f, indent=1)
 
     def tol(k):
         if k == "out":
             return TOL
-        if scaler_act == "relu" and k.startswith("downscaler."):
-            return 2e-3
-        if mode == "off" and k.startswith("encoder_layers.") and gt.get_precision() != "f32":
-            return 1e-3
         return max(2e-5, 12.0 * noise.get(k, 0.0))
 
     bad = {k: (v, tol(k)) for k, v in errs.items() if not v < tol(k)}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12]
+    # where float32 itself sits far from float64 (the interpolation coordinates of the down-scaler), the float32 oracle is
+    # the closer statement of the reference: the HIP gradients must agree with IT to the plain bar
+    bad32 = {k: v for k, v in vs32.items() if noise.get(k, 0.0) > 1e-5 and k.startswith("downscaler.") and not v < 2e-5}
+    assert not bad32, bad32
     assert len(errs) == 1 + len(ref_dp) == 1 + sum(1 for _ in model.parameters())
     print(json.dumps({"mode": mode, "scaler_act": scaler_act, "worst": max(errs.values()),
                       "worst_outside_downscaler": max(v for k, v in errs.items() if not k.startswith("downscaler.")),

@@ -1256,8 +1256,10 @@ def test_scaler_conv_chain_matches_conv2d(H, gpu_device, p_drop):
     cur, refs = xr, []
     for i in range(3):
         pre = torch.nn.functional.conv2d(cur.permute(0, 3, 1, 2), wr[i], padding=1).permute(0, 2, 3, 1)
-        keep = ((got[i].double() > 0) | (pre <= 0)).double() if p_drop > 0 else torch.ones_like(pre)
-        cur = torch.relu(pre) * keep * scale
+        # the run's own decisions (output > 0 <=> kept by the dropout and positive) are replayed: among ~1e6 ReLUs some
+        # pre-activation lies within fp32 rounding of zero, and ONE differing decision moves a gradient by ~1e-3
+        assert int(((got[i] > 0) & (pre < -1e-5)).sum()) == 0 and (p_drop > 0 or int(((got[i] <= 0) & (pre > 1e-5)).sum()) == 0)
+        cur = pre * (got[i] > 0).double() * scale
         refs.append(cur)
         if p_drop > 0:
             pos = pre > 1e-6
@@ -1304,8 +1306,8 @@ def test_scaler_chain_with_masked_segment_resize_matches_reference(H, gpu_device
     cur, refs = xr, []
     for i in range(3):
         pre = torch.nn.functional.conv2d(cur.permute(0, 3, 1, 2), wr[i], padding=1).permute(0, 2, 3, 1)
-        keep = ((got[i].double() > 0) | (pre <= 0)).double() if p_drop > 0 else torch.ones_like(pre)
-        cur = torch.relu(pre) * keep * scale
+        assert int(((got[i] > 0) & (pre < -1e-5)).sum()) == 0 and (p_drop > 0 or int(((got[i] <= 0) & (pre > 1e-5)).sum()) == 0)
+        cur = pre * (got[i] > 0).double() * scale              # the run's own ReLU / dropout decisions, replayed
         refs.append(cur)
     rcat = torch.cat(refs, -1).permute(0, 3, 1, 2)
     ry = torch.relu(torch.nn.functional.interpolate(rcat, size=(Ho, Wo), mode="bilinear", align_corners=True)).permute(0, 2, 3, 1)
@@ -1354,3 +1356,52 @@ def test_conv3x3_resize_channels_last_output(H, gpu_device):
         res.append((y.permute(0, 3, 1, 2) if nhwc else y, w.grad))
     assert torch.equal(res[0][0], res[1][0])
     assert rel_l2(res[1][1], res[0][1]) < 1e-6
+
+
+@pytest.mark.parametrize("B,Hh,Ww,Cin,ldx,ldg,alpha", [
+    (3, 78, 78, 128, 128, 144, 1.0),        # conv1 of the down-scaler: dense 128-channel input, gy = a segment of [.., 144]
+    (2, 78, 78, 48, 144, 96, 1.0 / 0.9),    # conv2 / conv3: both operands column segments (pitches 144 / 96), dropout scale
+    (5, 9, 80, 16, 16, 48, 1.0),            # one input tile, the widest row the LDS rows hold, few image rows
+    (2, 20, 37, 32, 36, 48, -2.0),          # odd width, pitch > channels
+    (1, 3, 5, 48, 48, 48, 1.0),             # tiny image: every row and column touches the zero padding
+])
+def test_conv3x3_wgrad_nhwc_matches_conv2d(H, gpu_device, B, Hh, Ww, Cin, ldx, ldg, alpha):
+    """gt_conv3x3_wgrad_nhwc (gt_convw.hip: operands split once per block into LDS planes, pixel-interleaved k, nine taps
+    co-resident, sign-alternating accumulation) against the weight gradient of torch's conv2d in fp64 -- the reference's
+    autograd path for Interp2dEncoder's conv1 / conv2 / conv3 (libs/layers.py:463-482, 88-150).  Operands are read in place
+    out of wider channels-last buffers (pixel pitches ldx / ldg); columns beyond the used ones hold NaN-free garbage that
+    must not enter."""
+    dev = gpu_device
+    Cout, T = 48, B * Hh * Ww
+    xbuf = rnd(T, ldx, dev=dev, seed=611)
+    gbuf = rnd(T, ldg, dev=dev, seed=612)
+    off_x, off_g = (ldx - Cin) // 4 * 4, (ldg - Cout) // 4 * 4      # 16-byte aligned column offsets inside the buffers
+    xv, gv = xbuf[:, off_x:off_x + Cin], gbuf[:, off_g:off_g + Cout]
+    dw = H.conv3x3_wgrad_nhwc(gv, ldg, xv, ldx, B, Hh, Ww, Cin, Cout, alpha=alpha)
+    torch.cuda.synchronize()
+    xr = xv.double().reshape(B, Hh, Ww, Cin).permute(0, 3, 1, 2).contiguous()
+    gr = gv.double().reshape(B, Hh, Ww, Cout).permute(0, 3, 1, 2).contiguous()
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, device=dev, requires_grad=True)
+    torch.nn.functional.conv2d(xr, w, padding=1).backward(gr)
+    ref = alpha * w.grad
+    assert dw.shape == ref.shape
+    assert rel_l2(dw, ref) < KTOL, rel_l2(dw, ref)
+    # every tap on its own (a transposed / mirrored tap order would pass a norm over all taps only by accident)
+    for ky in range(3):
+        for kx in range(3):
+            assert rel_l2(dw[:, :, ky, kx], ref[:, :, ky, kx]) < 2 * KTOL, (ky, kx)
+    # deterministic
+    dw2 = H.conv3x3_wgrad_nhwc(gv, ldg, xv, ldx, B, Hh, Ww, Cin, Cout, alpha=alpha)
+    assert torch.equal(dw, dw2)
+
+
+def test_conv3x3_wgrad_nhwc_rejects_what_it_does_not_cover(H, gpu_device):
+    dev = gpu_device
+    x, g = rnd(2 * 8 * 8, 16, dev=dev, seed=621), rnd(2 * 8 * 8, 48, dev=dev, seed=622)
+    with pytest.raises(H.GtNotSupported):
+        H.conv3x3_wgrad_nhwc(g[:, :32], 48, x, 16, 2, 8, 8, 16, 32)          # Cout != 48
+    with pytest.raises(H.GtNotSupported):
+        H.conv3x3_wgrad_nhwc(g, 48, x[:, :8], 16, 2, 8, 8, 8, 48)            # Cin % 16
+    xw, gw = rnd(1 * 2 * 96, 16, dev=dev, seed=623), rnd(1 * 2 * 96, 48, dev=dev, seed=624)
+    with pytest.raises(H.GtNotSupported):
+        H.conv3x3_wgrad_nhwc(gw, 48, xw, 16, 1, 2, 96, 16, 48)               # W > 80
