@@ -19,8 +19,10 @@
 //  * One wave per dy.  Wave w accumulates the three taps (dy = w - 1, dx = -1, 0, 1) for all CI x Cout of the block: its x
 //    fragments (row y + dy) serve three taps, the gy fragments serve CI/16 tiles.  3 x (CI/16) x (Cout/16) accumulator tiles
 //    per wave.
-//  * Rows y + 2 / y + 1 of the next iteration are fetched into registers before the MFMAs of row y and written (split) to LDS
-//    behind them; with CI = 32 two blocks share a CU and one computes while the other stages.
+//  * A fourth wave is the loader, on the SIMD the three MFMA waves leave free: while they work on row y it fetches, splits and
+//    writes x row y + 2 (into the free slot of a ring of four) and gy row y + 1 (second buffer); one barrier per row.  (Staged
+//    by the MFMA waves between their phases the 48-channel launch took 307 us; four loader waves sharing the MFMA waves' SIMDs
+//    280 us -- worse than one.)
 //  * Sign-alternating accumulation (gt_gemm_x3.hip: GT_X3_ALT): channels at odd LDS positions enter negated on both sides,
 //    the accumulators are un-flipped when the block writes its partial result.
 //
@@ -28,6 +30,7 @@
 // also transposes to the reference's [co][ci][3][3] and applies alpha: deterministic, no atomics.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gt_common.h"
 
@@ -36,8 +39,16 @@ namespace gt {
 typedef __bf16 cw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 cw_bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t cw_u32x4 __attribute__((ext_vector_type(4)));
+// pointers into device memory as such (inside the non-inlined role functions the compiler no longer sees where they came from
+// and would fall back to flat loads / stores)
+typedef __attribute__((address_space(1))) f32x4 cw_gf32x4;
+typedef __attribute__((address_space(1))) float cw_gf32;
 
-constexpr int CW_THREADS = 192;        // three waves: dy = -1, 0, 1
+#ifndef GT_CW_LOADER_WAVES
+#define GT_CW_LOADER_WAVES 1
+#endif
+constexpr int CW_LOADERS = 64 * GT_CW_LOADER_WAVES;   // loader threads (they also stage the prologue)
+constexpr int CW_THREADS = 192 + CW_LOADERS;          // waves 0..2: dy = -1, 0, 1 (MFMA); waves 3..: the loaders
 constexpr int CW_NQ = 10;              // pixel groups (units) per row and channel: 80 pixels
 constexpr int CW_MAXW = 8 * CW_NQ;
 
@@ -62,88 +73,139 @@ __device__ __forceinline__ void cw_split3(float a, float b, uint32_t (&out)[3]) 
     }
 }
 
-// One staged row of one operand: NITEM float4 pairs per thread.  Item idx = (g, m, q), g fastest: dword m of unit q of the four
-// channels 4g .. 4g+3, i.e. the pixels  q + QOFF + 20 m  and  + 10  (QOFF = -1 for gy: its units run q = -1 .. 10).  A wave's
-// loads walk the contiguous channel groups of a pixel; its ds_write_b32 (positions c * C/4 + g) spread over the banks.
-template <int C, int NQ, int QOFF>
+__device__ __attribute__((aligned(16))) float cw_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+// One staged row of one operand: NITEM float4 quadruples per thread.  Item idx = (g, mm, q), g fastest: dwords 2 mm, 2 mm + 1 of
+// unit q of the four channels 4g .. 4g+3, i.e. the pixels  q + QOFF + 40 mm + {0, 10, 20, 30}  (QOFF = -1 for gy: its units run
+// q = -1 .. 10).  A wave's loads walk the contiguous channel groups of a pixel; its ds_write_b64 (unit positions c * C/4 + g)
+// spread over the banks.  Everything that does not change from row to row (element offsets of the sixteen pixels, the LDS
+// offset, the sign) is worked out once by init(); a pixel outside the row reads the zero line instead of sitting under a branch.
+template <int C, int NQ, int QOFF, int NT>              // NT: threads that share the row
 struct CwStage {
     static constexpr int G4 = C / 4;
-    static constexpr int ITEMS = 4 * G4 * NQ;
-    static constexpr int NITEM = (ITEMS + CW_THREADS - 1) / CW_THREADS;
-    f32x4 v[NITEM][2];
+    static constexpr int ITEMS = 2 * G4 * NQ;
+    static constexpr int NITEM = (ITEMS + NT - 1) / NT;
+    f32x4 v[NITEM][4];
+    int off0[NITEM];                                       // element offset of the item's first pixel from the row's first pixel
+    int vm[NITEM];                                         // bit e: pixel e of the item exists
+    int lds[NITEM];                                        // byte offset of (unit q, position g, dword pair mm) in plane 0, or -1
+    int stride10;
 
-    // rowp: first pixel of the image row (channel offset applied), or nullptr for a row outside the image
-    __device__ __forceinline__ void load(const float* __restrict__ rowp, int64_t ld, int W, int tid) {
+    __device__ __forceinline__ void init(int64_t ld, int W, int tid) {
+        stride10 = (int)(10 * ld);
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
-            const int idx = tid + it * CW_THREADS;
-            const int g = idx % G4, m = (idx / G4) & 3, q = idx / (4 * G4);
-            const int px0 = q + QOFF + 20 * m, px1 = px0 + 10;
-            const bool ok = rowp != nullptr && idx < ITEMS;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            v[it][0] = (ok && px0 >= 0 && px0 < W) ? *reinterpret_cast<const f32x4*>(rowp + (int64_t)px0 * ld + 4 * g) : z;
-            v[it][1] = (ok && px1 < W) ? *reinterpret_cast<const f32x4*>(rowp + (int64_t)px1 * ld + 4 * g) : z;
+            const int idx = tid + it * NT;
+            const int g = idx % G4, mm = (idx / G4) & 1, q = idx / (2 * G4);
+            const int px0 = q + QOFF + 40 * mm;
+            off0[it] = px0 * (int)ld + 4 * g;
+            int m = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m |= (idx < ITEMS && px0 + 10 * e >= 0 && px0 + 10 * e < W) ? (1 << e) : 0;
+            vm[it] = m;
+            lds[it] = idx < ITEMS ? ((q * C + g) << 4) + 8 * mm : -1;
         }
     }
+    // rowp: first pixel of the image row (channel offset applied), or nullptr (wave-uniform) for a row outside the image
+    __device__ __forceinline__ void load(const float* __restrict__ rowp) {
+        if (rowp == nullptr) {
+#pragma unroll
+            for (int it = 0; it < NITEM; ++it)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[it][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* src = ((vm[it] >> e) & 1) ? rowp + (off0[it] + e * stride10) : cw_zero;
+                v[it][e] = *(const cw_gf32x4*)src;
+            }
+    }
     // planes: [3][NQ][C] units of 16 bytes
-    __device__ __forceinline__ void store(char* __restrict__ planes, int tid) const {
+    __device__ __forceinline__ void store(char* __restrict__ planes) const {
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
-            const int idx = tid + it * CW_THREADS;
-            if (idx >= ITEMS) continue;
-            const int g = idx % G4, m = (idx / G4) & 3, q = idx / (4 * G4);
-            const float sg = (g & 1) ? -1.f : 1.f;                 // position parity = g parity (C / 4 is even)
+            if (lds[it] < 0) continue;
+            char* base = planes + lds[it];
+            const float sg = (lds[it] & 16) ? -1.f : 1.f;          // position parity = g parity (C / 4 is even)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                uint32_t h[3];
-                cw_split3(sg * v[it][0][c], sg * v[it][1][c], h);
-                const int pos = c * G4 + g;
+                uint32_t h0[3], h1[3];
+                cw_split3(sg * v[it][0][c], sg * v[it][1][c], h0);
+                cw_split3(sg * v[it][2][c], sg * v[it][3][c], h1);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    *reinterpret_cast<uint32_t*>(planes + (((pl * NQ + q) * C + pos) << 4) + 4 * m) = h[pl];
+                    *reinterpret_cast<uint2*>(base + ((pl * NQ * C + c * G4) << 4)) = uint2{h0[pl], h1[pl]};
             }
         }
     }
 };
 
 template <int CIT, int COT>
-__global__ __launch_bounds__(CW_THREADS, (CIT == 3 ? 1 : 2)) void convw_kernel(const ConvWP p) {
-    constexpr int CI = 16 * CIT, CO = 16 * COT;
-    constexpr int XSLOT = 3 * CW_NQ * CI * 16;            // bytes of one x row (three planes)
-    constexpr int YBUF = 3 * (CW_NQ + 2) * CO * 16;       // the gy row with its two halo units
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xs = smem;                                       // [3 slots][3 planes][NQ][CI] units
-    char* ys = smem + 3 * XSLOT;                           // [3 planes][NQ + 2][CO] units
-    char* zs = ys + YBUF;                                  // 16 zero bytes: the operands of pixel groups past the row
+struct CwGeom {
+    static constexpr int CI = 16 * CIT, CO = 16 * COT;
+    static constexpr int XSLOT = 3 * CW_NQ * CI * 16;     // bytes of one x row (three planes)
+    static constexpr int YBUF = 3 * (CW_NQ + 2) * CO * 16;   // one gy row with its two halo units
+    // LDS: [4 slots][3 planes][NQ][CI] units of x (row r in slot (r + 4) & 3), [2][3 planes][NQ + 2][CO] units of gy (row r in
+    // buffer r & 1), 16 zero bytes
+    static constexpr int XS = 0, YS = 4 * XSLOT, ZS = YS + 2 * YBUF, BYTES = ZS + 16;
+};
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int ci0 = blockIdx.y * CI;
-    const int bc = blockIdx.x, b = bc / p.chunks, chunk = bc - b * p.chunks;
-    const int y0 = chunk * p.rows_per_chunk, y1 = min(p.H, y0 + p.rows_per_chunk);
-    const int dy = wave - 1;
+extern __shared__ __attribute__((aligned(16))) char cw_smem[];
 
-    for (int i = tid; i < (3 * XSLOT + YBUF + 16) / 16; i += CW_THREADS)
-        reinterpret_cast<cw_u32x4*>(smem)[i] = cw_u32x4{0u, 0u, 0u, 0u};
+// The two roles are separate (non-inlined) functions so that each gets a register allocation of its own: inlined into one
+// kernel body the loader's prefetched rows were parked in accumulator registers behind a wait on every single load (one
+// memory latency per load: 2.4 ms for the 128 -> 48 launch).
 
-    auto xrow = [&](int y) -> const float* {
-        return (y >= 0 && y < p.H) ? p.x + ((int64_t)(b * p.H + y) * p.W) * p.ldx + ci0 : nullptr;
-    };
-    auto grow = [&](int y) -> const float* {
-        return (y >= 0 && y < p.H) ? p.gy + ((int64_t)(b * p.H + y) * p.W) * p.ldg : nullptr;
-    };
-    CwStage<CI, CW_NQ, 0> sx;
-    CwStage<CO, CW_NQ + 2, -1> sy;
-    __syncthreads();
-    // prologue: x rows y0 - 1, y0, y0 + 1 and gy row y0
-    for (int r = -1; r <= 1; ++r) {
-        sx.load(xrow(y0 + r), p.ldx, p.W, tid);
-        sx.store(xs + ((y0 + r + 3) % 3) * XSLOT, tid);
+// ---- the loader wave: the prologue rows, then during the MFMAs of row y it writes x row y + 2 and gy row y + 1; what it writes
+// in one iteration was requested from memory an iteration earlier
+template <int CIT, int COT>
+__device__ __noinline__ void cw_loader(const float* xb, int64_t ldx, const float* gb, int64_t ldg, int H, int W, int y0, int y1,
+                                       int lt) {
+    using G = CwGeom<CIT, COT>;
+    char* xs = cw_smem + G::XS;
+    char* ys = cw_smem + G::YS;
+    // xb / gb: pixel (0, 0) of the block's image (x: channel block offset applied)
+    auto xrow = [&](int y) -> const float* { return (y >= 0 && y < H) ? xb + (int64_t)y * W * ldx : nullptr; };
+    auto grow = [&](int y) -> const float* { return (y >= 0 && y < H) ? gb + (int64_t)y * W * ldg : nullptr; };
+    CwStage<G::CI, CW_NQ, 0, CW_LOADERS> sx;
+    CwStage<G::CO, CW_NQ + 2, -1, CW_LOADERS> sy;
+    sx.init(ldx, W, lt);
+    sy.init(ldg, W, lt);
+    for (int r = -1; r <= 1; ++r) {                        // prologue: x rows y0 - 1, y0, y0 + 1 and gy row y0
+        sx.load(xrow(y0 + r));
+        sx.store(xs + ((y0 + r + 4) & 3) * G::XSLOT);
     }
-    sy.load(grow(y0), p.ldg, p.W, tid);
-    sy.store(ys, tid);
+    sy.load(grow(y0));
+    sy.store(ys + (y0 & 1) * G::YBUF);
+    if (y0 + 1 < y1) {                                     // what the first iteration writes
+        sx.load(xrow(y0 + 2));
+        sy.load(grow(y0 + 1));
+    }
     __syncthreads();
+    for (int y = y0; y < y1; ++y) {
+        if (y + 1 < y1) {
+            sx.store(xs + ((y + 2 + 4) & 3) * G::XSLOT);
+            sy.store(ys + ((y + 1) & 1) * G::YBUF);
+            if (y + 2 < y1) {
+                sx.load(xrow(y + 3));
+                sy.load(grow(y + 2));
+            }
+        }
+        __syncthreads();
+    }
+}
 
+// ---- an MFMA wave: the three taps (dy, dx = -1, 0, 1) for all CI x CO of the block
+template <int CIT, int COT>
+__device__ __noinline__ void cw_mfma(float* slab, int Cin, int Cout, int ci0, int co0, int y0, int y1, int dy, int lane) {
+    using G = CwGeom<CIT, COT>;
+    constexpr int CI = G::CI, CO = G::CO;
+    const char* xs = cw_smem + G::XS;
+    const char* ys = cw_smem + G::YS;
+    const int li = lane & 15, kq = lane >> 4;
     f32x4 acc[3][CIT][COT];
 #pragma unroll
     for (int d = 0; d < 3; ++d)
@@ -152,58 +214,62 @@ __global__ __launch_bounds__(CW_THREADS, (CIT == 3 ? 1 : 2)) void convw_kernel(c
 #pragma unroll
             for (int j = 0; j < COT; ++j) acc[d][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int y = y0; y < y1; ++y) {
-        const bool more = y + 1 < y1;
-        if (more) {                                        // block-uniform: next iteration's rows on their way
-            sx.load(xrow(y + 2), p.ldx, p.W, tid);
-            sy.load(grow(y + 1), p.ldg, p.W, tid);
-        }
-        const char* xr = xs + ((y + dy + 3) % 3) * XSLOT;
-#pragma unroll 1
-        for (int ks = 0; ks < 3; ++ks) {
-            const int q = 4 * ks + kq;
-            const bool valid = q < CW_NQ;
-            cw_bf16x8 a[CIT][3];
+    // One k-step = four pixel groups (the lane groups kq) of row y.  Ten groups per row: the third step has two; its lanes
+    // kq >= 2 re-read group 9 and get zero x fragments instead (the ds_read addresses then are base + immediate throughout).
+    // The gy fragments of tap column d + 1 are requested before the MFMAs of column d.
+    auto kstep = [&](const char* xr, const char* yr, int q, auto last) {
+        constexpr bool LAST = decltype(last)::value;
+        const int qq = LAST ? min(q, CW_NQ - 1) : q;
+        const char* abase = xr + ((qq * CI + li) << 4);
+        const char* bbase = yr + (((qq + 2) * CO + li) << 4);
+        cw_bf16x8 a[CIT][3], bq[2][COT][3];
+#pragma unroll
+        for (int i = 0; i < CIT; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                a[i][pl] = *reinterpret_cast<const cw_bf16x8*>(abase + pl * (CW_NQ * CI * 16) + i * 256);
+        auto loadb = [&](int d, cw_bf16x8 (&dst)[COT][3]) {   // dx = d - 1: gy unit q - dx, stored at unit index q + 2 - d
+#pragma unroll
+            for (int j = 0; j < COT; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    dst[j][pl] = *reinterpret_cast<const cw_bf16x8*>(bbase + pl * ((CW_NQ + 2) * CO * 16) - d * (CO * 16) + j * 256);
+        };
+        loadb(0, bq[0]);
+        if (LAST && q >= CW_NQ) {
 #pragma unroll
             for (int i = 0; i < CIT; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const char* ap = valid ? xr + (((pl * CW_NQ + q) * CI + 16 * i + li) << 4) : zs;
-                    a[i][pl] = *reinterpret_cast<const cw_bf16x8*>(ap);
-                }
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {                  // dx = d - 1: gy unit q - dx, stored at unit index q - dx + 1
-#pragma unroll
-                for (int j = 0; j < COT; ++j) {
-                    cw_bf16x8 bq[3];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        const char* bp = valid ? ys + (((pl * (CW_NQ + 2) + (q + 2 - d)) * CO + 16 * j + li) << 4) : zs;
-                        bq[pl] = *reinterpret_cast<const cw_bf16x8*>(bp);
-                    }
-#pragma unroll
-                    for (int s = 2; s >= 0; --s)           // plane pairs, smallest terms first (gt_gemm_x3.hip)
-#pragma unroll
-                        for (int pa = 0; pa < 3; ++pa) {
-                            const int pb = s - pa;
-                            if (pb < 0 || pb > 2) continue;
-#pragma unroll
-                            for (int i = 0; i < CIT; ++i)
-                                acc[d][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pa], bq[pb], acc[d][i][j], 0, 0, 0);
-                        }
-                }
-            }
+                for (int pl = 0; pl < 3; ++pl) a[i][pl] = __builtin_bit_cast(cw_bf16x8, cw_u32x4{0u, 0u, 0u, 0u});
         }
-        __syncthreads();                                   // every wave is done with row y's operands
-        if (more) {
-            sx.store(xs + ((y + 2) % 3) * XSLOT, tid);     // over row y - 1
-            sy.store(ys, tid);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (d < 2) loadb(d + 1, bq[(d + 1) & 1]);
+#pragma unroll
+            for (int s = 2; s >= 0; --s)                   // plane pairs, smallest terms first (gt_gemm_x3.hip)
+#pragma unroll
+                for (int pa = 0; pa < 3; ++pa) {
+                    const int pb = s - pa;
+                    if (pb < 0 || pb > 2) continue;
+#pragma unroll
+                    for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                        for (int j = 0; j < COT; ++j)
+                            acc[d][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pa], bq[d & 1][j][pb], acc[d][i][j], 0, 0, 0);
+                }
         }
-        __syncthreads();
+    };
+    __syncthreads();                                       // the loader's prologue rows are in place
+    for (int y = y0; y < y1; ++y) {
+        const char* xr = xs + ((y + dy + 4) & 3) * G::XSLOT;
+        const char* yr = ys + (y & 1) * G::YBUF;
+        kstep(xr, yr, kq, std::false_type{});
+        kstep(xr, yr, 4 + kq, std::false_type{});
+        kstep(xr, yr, 8 + kq, std::true_type{});
+        __syncthreads();                                   // row y is done with; the loader has published rows y + 2 / y + 1
     }
 
     // partial result: accumulator register r of lane (li, kq) = (x position 16 i + 4 kq + r, gy position 16 j + li)
-    float* slab = p.slabs + (int64_t)bc * 9 * p.Cin * p.Cout;
 #pragma unroll
     for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -213,11 +279,28 @@ __global__ __launch_bounds__(CW_THREADS, (CIT == 3 ? 1 : 2)) void convw_kernel(c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int pa = 16 * i + 4 * kq + r, pb = 16 * j + li;
-                    const int ci = ci0 + cw_chan_of_pos(pa, CI), co = cw_chan_of_pos(pb, CO);
+                    const int ci = ci0 + cw_chan_of_pos(pa, CI), co = co0 + cw_chan_of_pos(pb, CO);
                     const float sg = ((r + li) & 1) ? -1.f : 1.f;      // position parities (16 i + 4 kq and 16 j are even)
-                    if (ci < p.Cin && co < p.Cout)
-                        slab[((int64_t)((dy + 1) * 3 + d) * p.Cin + ci) * p.Cout + co] = sg * acc[d][i][j][r];
+                    if (ci < Cin && co < Cout)
+                        ((cw_gf32*)slab)[((int64_t)((dy + 1) * 3 + d) * Cin + ci) * Cout + co] = sg * acc[d][i][j][r];
                 }
+}
+
+template <int CIT, int COT>
+__global__ __launch_bounds__(CW_THREADS, 1) void convw_kernel(const ConvWP p) {
+    using G = CwGeom<CIT, COT>;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci0 = blockIdx.y * G::CI, co0 = blockIdx.z * G::CO;
+    const int bc = blockIdx.x, b = bc / p.chunks, chunk = bc - b * p.chunks;
+    const int y0 = chunk * p.rows_per_chunk, y1 = min(p.H, y0 + p.rows_per_chunk);
+    for (int i = tid; i < G::BYTES / 16; i += CW_THREADS)
+        reinterpret_cast<cw_u32x4*>(cw_smem)[i] = cw_u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (wave >= 3)
+        cw_loader<CIT, COT>(p.x + (int64_t)b * p.H * p.W * p.ldx + ci0, p.ldx, p.gy + (int64_t)b * p.H * p.W * p.ldg + co0, p.ldg,
+                            p.H, p.W, y0, y1, tid - 192);
+    else
+        cw_mfma<CIT, COT>(p.slabs + (int64_t)bc * 9 * p.Cin * p.Cout, p.Cin, p.Cout, ci0, co0, y0, y1, wave - 1, tid & 63);
 }
 
 // dw[co][ci][tap] = alpha * sum_s slabs[s][tap][ci][co]
@@ -238,19 +321,30 @@ __global__ __launch_bounds__(256) void convw_reduce_kernel(const float* __restri
     dw[((int64_t)co * Cin + ci) * 9 + tap] = alpha * ((s0 + s1) + (s2 + s3));
 }
 
-struct CwPlan { int cit, ciblocks, chunks, rows; size_t lds; };
+struct CwPlan { int cit, cot, ciblocks, coblocks, chunks, rows; size_t lds; };
 
+// Channel blocks of one thread block: outputs of 48 channels (the down-scaler's narrow convolutions, padded) in one piece with
+// the widest input block that divides Cin; wide outputs (the up-scaler's 128 -> 128 convolution) in blocks of 64 x 32.  One
+// block per CU (ring of four x rows + two gy rows in LDS).
 static bool cw_plan(int B, int H, int W, int Cin, int Cout, CwPlan* pl) {
-    if (B <= 0 || H <= 0 || W <= 0 || W > CW_MAXW || Cin <= 0 || Cout <= 0 || (Cin & 15) || Cout != 48) return false;
-    // CI = 32: two blocks per CU (one stages while the other multiplies); 48-channel inputs run as one block of three tiles
-    pl->cit = (Cin % 32 == 0) ? 2 : (Cin % 48 == 0) ? 3 : 1;
+    if (B <= 0 || H <= 0 || W <= 0 || W > CW_MAXW || Cin <= 0 || Cout <= 0 || (Cin & 15)) return false;
+    if (Cout == 48) {
+        pl->cot = 3;
+        pl->cit = (Cin % 48 == 0) ? 3 : (Cin % 32 == 0) ? 2 : 1;
+    } else if (Cout % 64 == 0 && Cin % 32 == 0) {
+        pl->cot = 4;
+        pl->cit = 2;
+    } else {
+        return false;
+    }
     pl->ciblocks = Cin / (16 * pl->cit);
-    const int per_cu = pl->cit == 3 ? 1 : 2, want = 256 * per_cu;
-    int chunks = std::max(1, (want + B * pl->ciblocks - 1) / (B * pl->ciblocks));
+    pl->coblocks = Cout / (16 * pl->cot);
+    const int per_row = B * pl->ciblocks * pl->coblocks;
+    int chunks = std::max(1, (256 + per_row - 1) / per_row);
     chunks = std::min(chunks, std::max(1, H / 8));          // at least eight rows per block: the three-row prologue is paid once
     pl->rows = (H + chunks - 1) / chunks;
     pl->chunks = (H + pl->rows - 1) / pl->rows;
-    pl->lds = (size_t)3 * 3 * CW_NQ * 16 * pl->cit * 16 + (size_t)3 * (CW_NQ + 2) * Cout * 16 + 16;
+    pl->lds = (size_t)4 * 3 * CW_NQ * 16 * pl->cit * 16 + (size_t)2 * 3 * (CW_NQ + 2) * 16 * pl->cot * 16 + 16;
     return true;
 }
 
@@ -272,12 +366,12 @@ extern "C" int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* 
     if (!cw_plan(B, H, W, Cin, Cout, &pl)) return GT_ENOTSUP;
     if (((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(x)) & 15) || (ldg & 3) || (ldx & 3)) return GT_EALIGN;
     if (!ws || ws_bytes < gt_conv3x3_wgrad_nhwc_ws_bytes(B, H, W, Cin, Cout)) return GT_EWS;
-    if ((int64_t)B * pl.chunks > 65535LL * 32768) return GT_EINVAL;
+    if ((int64_t)B * pl.chunks > 0x7fffffffLL) return GT_EINVAL;
     ConvWP p{gy, ldg, x, ldx, reinterpret_cast<float*>(ws), B, H, W, Cin, Cout, pl.chunks, pl.rows};
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)(B * pl.chunks), (unsigned)pl.ciblocks);
+    const dim3 grid((unsigned)(B * pl.chunks), (unsigned)pl.ciblocks, (unsigned)pl.coblocks);
     // more than 64 KB of LDS per block: the limit is raised once per kernel instance
-    static bool raised[4] = {false, false, false, false};
+    static bool raised[5] = {false, false, false, false, false};
     auto launch = [&](auto kern, int idx) -> int {
         if (!raised[idx]) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -289,7 +383,8 @@ extern "C" int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* 
         return 0;
     };
     int rc;
-    if (pl.cit == 1) rc = launch(convw_kernel<1, 3>, 1);
+    if (pl.cot == 4) rc = launch(convw_kernel<2, 4>, 4);
+    else if (pl.cit == 1) rc = launch(convw_kernel<1, 3>, 1);
     else if (pl.cit == 2) rc = launch(convw_kernel<2, 3>, 2);
     else rc = launch(convw_kernel<3, 3>, 3);
     if (rc) return rc;

@@ -319,6 +319,8 @@ _conv_implicit = [os.environ.get("GT_CONV_IMPLICIT", "1") != "0"]        # A/B s
 # the default because its solver choice is not ours: at B = 4 MIOpen has been seen to answer this layout with
 # naive_conv_ab_nonpacked_wrw_nhwc (34 ms per call, profiles/README.md).
 _conv_wgrad = [os.environ.get("GT_CONV_WGRAD", "hip") != "miopen"]
+_conv_wgrad_planes = [os.environ.get("GT_CONV_WGRAD_PLANES", "1") != "0"]   # gt_conv3x3_wgrad_nhwc where it applies (A/B switch)
+
 
 
 def _conv_k_order(w):
@@ -376,8 +378,15 @@ class Conv3x3NhwcFn(Function):
                         [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).contiguous()
         if ctx.needs_input_grad[1]:
             # dw[co][ci][tap] = sum_pix gy[pix][co] x[pix + shift(tap)][ci]
+            dw = None
             hip_wgrad = Ww >= 16 and _conv_wgrad[0]
-            if hip_wgrad:       # nine [Cout, Cin] products over the pixels, K chunks x taps on one launch
+            if hip_wgrad and ctx.prec == "bf16x3" and _conv_wgrad_planes[0]:
+                # operands split once per block into LDS planes, nine taps co-resident (gt_convw.hip): images up to 80 wide
+                try:
+                    dw = H.conv3x3_wgrad_nhwc(g.reshape(-1, Cout), Cout, xc.reshape(-1, Cin), Cin, B, Hh, Ww, Cin, Cout)
+                except H.GtNotSupported:
+                    dw = None
+            if hip_wgrad and dw is None:       # nine [Cout, Cin] products over the pixels, K chunks x taps on one launch
                                 # + a fixed-order reduce (gt_hip.h: cv_wgrad)
                 dw9 = torch.empty(9, Cout, Cin, dtype=torch.float32, device=g.device)
                 try:
@@ -387,7 +396,7 @@ class Conv3x3NhwcFn(Function):
                     dw = dw9.view(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
                 except H.GtNotSupported:
                     hip_wgrad = False
-            if not hip_wgrad:   # the library's channels-last wrw kernel on the same buffers
+            if dw is None:      # the library's channels-last wrw kernel on the same buffers
                 dw = torch.ops.aten.convolution_backward(
                     g.permute(0, 3, 1, 2), xc.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last),
                     None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].contiguous()

@@ -472,7 +472,8 @@ int gt_conv3x3_resize_bwd_nhwc(const float* g, const float* y, const float* x, c
  * gy / x: channels-last images with pixel pitches ldg >= Cout / ldx >= Cin (a column segment of a wider buffer is read in
  * place), 16-byte aligned, pitches multiples of 4.  dw: [Cout][Cin][3][3], the reference's layout.  Arithmetic: the three-plane
  * split-operand products of gt_gemm (GT_PREC_BF16X3), each operand value split once per block (gt_convw.hip).
- * GT_ENOTSUP unless Cout == 48, Cin % 16 == 0, W <= 80.  Deterministic: partial results per (image, row chunk) in ws
+ * GT_ENOTSUP unless W <= 80 and (Cout == 48, Cin % 16 == 0: the down-scaler's padded narrow convolutions) or (Cout % 64 == 0,
+ * Cin % 32 == 0: the up-scaler's 128 -> 128 convolution).  Deterministic: partial results per (image, row chunk) in ws
  * (>= gt_conv3x3_wgrad_nhwc_ws_bytes), summed in a fixed order.
  * ------------------------------------------------------------------------------------------- */
 int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* x, int64_t ldx, float* dw, int32_t B, int32_t H,

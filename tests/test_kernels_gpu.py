@@ -1359,6 +1359,7 @@ def test_conv3x3_resize_channels_last_output(H, gpu_device):
 
 
 @pytest.mark.parametrize("B,Hh,Ww,Cin,ldx,ldg,alpha", [
+    (2, 77, 77, 128, 128, -128, 1.0),       # the up-scaler's 128 -> 128 convolution (Cout = 128: blocks of 64 x 32 channels)
     (3, 78, 78, 128, 128, 144, 1.0),        # conv1 of the down-scaler: dense 128-channel input, gy = a segment of [.., 144]
     (2, 78, 78, 48, 144, 96, 1.0 / 0.9),    # conv2 / conv3: both operands column segments (pitches 144 / 96), dropout scale
     (5, 9, 80, 16, 16, 48, 1.0),            # one input tile, the widest row the LDS rows hold, few image rows
@@ -1372,7 +1373,8 @@ def test_conv3x3_wgrad_nhwc_matches_conv2d(H, gpu_device, B, Hh, Ww, Cin, ldx, l
     out of wider channels-last buffers (pixel pitches ldx / ldg); columns beyond the used ones hold NaN-free garbage that
     must not enter."""
     dev = gpu_device
-    Cout, T = 48, B * Hh * Ww
+    Cout, T = (48, B * Hh * Ww) if ldg > 0 else (-ldg, B * Hh * Ww)
+    ldg = abs(ldg)
     xbuf = rnd(T, ldx, dev=dev, seed=611)
     gbuf = rnd(T, ldg, dev=dev, seed=612)
     off_x, off_g = (ldx - Cin) // 4 * 4, (ldg - Cout) // 4 * 4      # 16-byte aligned column offsets inside the buffers
