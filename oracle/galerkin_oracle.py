@@ -385,7 +385,8 @@ def simple_transformer_1d(sd: Mapping[str, Tensor], cfg: Mapping, node: Tensor, 
 
 def fourier_transformer_2d_lite(sd: Mapping[str, Tensor], cfg: Mapping, node: Tensor, pos: Tensor,
                                 grid: Tensor, *,
-                                attn_drops: Optional[Sequence[AttnDrop]] = None) -> Tensor:
+                                attn_drops: Optional[Sequence[AttnDrop]] = None,
+                                relu_masks: Optional[Sequence[Tensor]] = None) -> Tensor:
     """FourierTransformer2DLite.forward (model.py:1197-1226)."""
     B = node.shape[0]
     ng = grid.shape[1]
@@ -394,7 +395,8 @@ def fourier_transformer_2d_lite(sd: Mapping[str, Tensor], cfg: Mapping, node: Te
     ek = _enc_kwargs(cfg)
     for li in range(cfg["num_encoder_layers"]):
         ad = None if attn_drops is None else attn_drops[li]
-        x = encoder_layer(_sub(sd, f"encoder_layers.{li}."), x, pos, attn_drop=ad, **ek)
+        x = encoder_layer(_sub(sd, f"encoder_layers.{li}."), x, pos, attn_drop=ad,
+                          relu_mask=None if relu_masks is None else relu_masks[li], **ek)
     x = x.reshape(B, ng, ng, -1)
     return spectral_regressor(_sub(sd, "regressor."), x, grid, modes=cfg["fourier_modes"],
                               num_spectral_layers=cfg["num_regressor_layers"],
