@@ -35,7 +35,7 @@ N_FINE, N_COARSE = 141, 43          # 421 grid subsampled by 3 / by 10 (ex2_darc
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBS = 8000.0
-PLANE_PRODUCTS = {"bf16x3": 6, "bf16x2": 3, "bf16": 1}
+PLANE_PRODUCTS = {"bf16x3": 6, "bf16x2": 3, "bf16": 1, "f16x2": 3}
 
 
 # name -> (config.yml section, fine subsample, coarse subsample, config overrides, where the target lives)
@@ -412,18 +412,8 @@ def roofline_leg(trainer, precision):
     except (OSError, ValueError):
         pmc = {}
     legs = {}
-    for label, key, sym in (("qkv_proj+headnorm_fwd", "gemm_x3p_kernel<0, 32, 0, 128>", "gt::gemm_x3p_kernel<0, 32, 0, 128>"),
-                            ("headnorm_fwd", "gt_headnorm_fwd", "gt::headnorm_fwd_v2_kernel"),
-                            ("headnorm_bwd", "gt_headnorm_bwd", "gt::headnorm_bwd_v2_kernel"),
-                            ("galerkin_ktv", "gt_galerkin_ktv", "gt::galerkin_ktv_kernel<2>"),
-                            ("galerkin_dkv", "gt_galerkin_dkv", "gt::galerkin_dkv_kernel<2>"),
-                            ("galerkin_dkv+headnorm_bwd", "gt_galerkin_dkv_ln", "gt::galerkin_dkv_ln_kernel<2, true>"),
-                            ("galerkin_qp(Q'.P with fc folded)", "gemm_x3r_kernel<0, 1, 3, 3, 0, 0>", "gt::gemm_x3r_kernel<0, 1, 3, 3, 0, 0>"),
-                            ("token_gemms(packed B)", "gemm_x3p_kernel<0, 0, 0, 128>", "gt::gemm_x3p_kernel<0, 0, 0, 128>"),
-                            ("conv3x3_implicit", "gemm_x3p_kernel<0, 0, 1, 128>", "gt::gemm_x3p_kernel<0, 0, 1, 128>"),
-                            ("conv3x3_implicit_narrow(down-scaler)", "gemm_x3p_kernel<0, 0, 1, 64>", "gt::gemm_x3p_kernel<0, 0, 1, 64>"),
-                            ("conv3x3_wgrad", "gemm_x3r_kernel<1, 1, 3, 3, 0, 2>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 2>"),
-                            ("weight_gradients", "gemm_x3r_kernel<1, 1, 3, 3, 0, 0>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 0>")):
+    pk = "gemm_x3h_kernel" if precision == "f16x2" else "gemm_x3p_kernel"     # the packed-B instances of the arithmetic
+    for label, key, sym in ((l, k.replace("gemm_x3p_kernel", pk), s_.replace("gemm_x3p_kernel", pk)) for l, k, s_ in LEGS):
         t = table.get(key) or table.get(key.replace("+splitk", ""))
         if not t or t["ms"] <= 0:
             continue
@@ -441,6 +431,22 @@ def roofline_leg(trainer, precision):
         legs[label] = leg
     roof["legs"] = legs
     return roof, table
+
+
+# roofline legs: label, key of the HIP-event table (_hip.Profile), kernel symbol in profiles/pmc_step.json
+# (tests/test_host_cpu.py checks that every symbol named here exists in that file)
+LEGS = (("qkv_proj+headnorm_fwd", "gemm_x3p_kernel<0, 32, 0, 128>", "gt::gemm_x3p_kernel<0, 32, 0, 128>"),
+        ("headnorm_fwd", "gt_headnorm_fwd", "gt::headnorm_fwd_v2_kernel"),
+        ("headnorm_bwd", "gt_headnorm_bwd", "gt::headnorm_bwd_v2_kernel"),
+        ("galerkin_ktv", "gt_galerkin_ktv", "gt::galerkin_ktv_lds_kernel<2>"),
+        ("galerkin_dkv", "gt_galerkin_dkv", "gt::galerkin_dkv_kernel<2>"),
+        ("galerkin_dkv+headnorm_bwd", "gt_galerkin_dkv_ln", "gt::galerkin_dkv_ln_kernel<2, true>"),
+        ("galerkin_qp(Q'.P with fc folded)", "gemm_x3r_kernel<0, 1, 3, 3, 0, 0>", "gt::gemm_x3r_kernel<0, 1, 3, 3, 0, 0>"),
+        ("token_gemms(packed B)", "gemm_x3p_kernel<0, 0, 0, 128>", "gt::gemm_x3p_kernel<0, 0, 0, 128>"),
+        ("conv3x3_implicit", "gemm_x3p_kernel<0, 0, 1, 128>", "gt::gemm_x3p_kernel<0, 0, 1, 128>"),
+        ("conv3x3_implicit_narrow(down-scaler)", "gemm_x3p_kernel<0, 0, 1, 64>", "gt::gemm_x3p_kernel<0, 0, 1, 64>"),
+        ("conv3x3_wgrad(LDS planes)", "gt_conv3x3_wgrad_nhwc", "gt::convw_kernel<2, 4>"),
+        ("weight_gradients", "gemm_x3r_kernel<1, 1, 3, 3, 0, 0>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 0>"))
 
 
 def x3_name(key: str) -> bool:
@@ -554,6 +560,9 @@ DTYPE_TEXT = {
     "f32": "f32",
     "bf16x3": "f32 (operands split exactly into 3 bf16 terms, 6 plane products on the bf16 MFMA pipe, f32 accumulate; "
               "fp32-class results: the 1e-5 parity gate is tested in this mode)",
+    "f16x2": "f32 (operands split into 2 fp16 terms under a running per-row / per-tile power-of-two scale, 3 products on the "
+             "f16 MFMA pipe, f32 accumulate; fp32-class results: the 1e-5 parity suite passes in this mode; launches outside the "
+             "packed-B kernels run bf16x3)",
     "bf16x2": "f32 storage / bf16x2 split MFMA (~2^-16 relative; throughput mode, own gate)",
     "bf16": "f32 storage / bf16-rounded MFMA operands, f32 accumulate (throughput mode, own 3e-3 gate)",
 }
@@ -570,7 +579,7 @@ def main():
     ap.add_argument("--workload", default="ex2_darcy141", choices=sorted(WORKLOADS),
                     help="ex2_darcy141 is the headline metric; the others are informational")
     ap.add_argument("--loss", default="mse", choices=["mse", "weighted_l2"])
-    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16x2", "bf16"],
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16x2", "bf16", "f16x2"],
                     help="arithmetic of the contractions (default: the library default, bf16x3)")
     ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"])
     ap.add_argument("--no-graph", action="store_true")

@@ -501,15 +501,16 @@ static bool has_epilogue(const gt_gemm_desc* d) {
 
 // number of bf16 planes the split-operand kernel (gt_gemm_x3.hip) would use for d, 0 = fp32 MFMA kernels
 static int x3_planes(const gt_gemm_desc* d) {
-    const int planes = d->precision == GT_PREC_BF16X3 ? 3 : d->precision == GT_PREC_BF16X2 ? 2
-                       : d->precision == GT_PREC_BF16 ? 1 : 0;
+    // GT_PREC_F16X2: the packed-B kernels run the two-term fp16 arithmetic, every other split-operand launch bf16x3
+    const int planes = (d->precision == GT_PREC_BF16X3 || d->precision == GT_PREC_F16X2) ? 3
+                       : d->precision == GT_PREC_BF16X2 ? 2 : d->precision == GT_PREC_BF16 ? 1 : 0;
     if (!planes || !x3_shape_ok(d) || (d->a_colsum && d->layout_a != 1)) return 0;
     return planes;
 }
 
 static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     if (d->M <= 0 || d->N <= 0 || d->K < 0 || d->batch0 <= 0 || d->batch1 <= 0) return GT_EINVAL;
-    if (d->precision < GT_PREC_F32 || d->precision > GT_PREC_BF16) return GT_EINVAL;
+    if (d->precision < GT_PREC_F32 || d->precision > GT_PREC_F16X2) return GT_EINVAL;
     const int64_t batch = (int64_t)d->batch0 * d->batch1;
     if (batch > 65535) return GT_EINVAL;
     pl->x3 = x3_planes(d);
@@ -631,7 +632,7 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
         GemmP q;
         memset(&q, 0, sizeof(q));
         q.M = d->M; q.N = d->N; q.K = d->K; q.K2 = d->K2; q.cv_C = d->cv_c; q.cv_wgrad = d->cv_wgrad != 0;
-        if (x3_packed_ok(d, pl.x3, pl.split)) q.Bp = d->B;
+        if (x3_packed_ok(d, pl.x3, pl.split)) { q.Bp = d->B; q.bp_f16 = d->precision == GT_PREC_F16X2; }
         q.a_vec = al16(d->A) && m4(d->lda) && m4(d->a_bs0) && m4(d->a_bs1);
         q.b_vec = al16(d->B) && m4(d->ldb) && m4(d->b_bs0) && m4(d->b_bs1);
         snprintf(buf, n, "%s", x3_kernel_name(q, d->layout_a, d->layout_b, pl.x3,

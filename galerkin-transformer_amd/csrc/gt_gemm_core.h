@@ -31,7 +31,7 @@ struct GemmP {
     const float* hn_gamma; const float* hn_beta; const float* hn_pos; float* hn_out; float* hn_stats;
     int hn_h, hn_dk, hn_p, hn_DP, hn_mask, hn_skip_raw, hn_plain; float hn_eps;
     int cv_H, cv_W, cv_C, cv_wgrad;  // implicit 3x3 convolution (gt_hip.h: cv_*), cv_C = 0: plain GEMM
-    const void* Bp; int bp_NT, bp_KS;        // packed-B kernel (gt_gemm_x3.hip): bf16 planes of B in fragment order
+    const void* Bp; int bp_NT, bp_KS, bp_f16; // packed-B kernel (gt_gemm_x3.hip): bf16 (fp16: bp_f16) planes of B in fragment order
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------

@@ -140,6 +140,41 @@ __device__ __forceinline__ void x3_alt_undo(f32x16 (&acc)[NI][NJ], float rsgn) {
 #endif
 }
 
+// ---- two-term fp16 arithmetic (GT_PREC_F16X2) --------------------------------------------------------------------------
+// fp32-class results from THREE products per stage instead of six: every operand value x is split as
+//     h0 = f16_rne(x s),  h1 = f16_rne(x s - h0)          (s a power of two; 11 + 11 significand bits, both steps exact)
+// and the products h1 g0 + h0 g1 + h0 g0 are accumulated in fp32 by v_mfma_f32_32x32x16_f16 (dropped: h1 g1 <= 2^-22).
+// fp16 has five exponent bits, so the scale s must track the data; no tensor statistics are passed in for that:
+//   * N side (the packed weight): x3_pack_b16_kernel takes the amax of each 32-column fragment tile when it packs it and
+//     stores the tile's exponent behind the planes -- a wave-uniform factor of one accumulator column block;
+//   * M side (activation rows, split in registers): a lane holds ONE row of its 32-row tile (and with the N-side tile as
+//     the MFMA's first operand all sixteen accumulator registers of that lane belong to that row), so the scale is a
+//     PER-ROW running exponent kept in the lane: before a stage's eight values are split the lane pair of the row takes
+//     their amax; if amax 2^e would reach 2^15 the exponent is lowered to put it at 2^13 and the lane's accumulators are
+//     multiplied by the same power of two (exact) -- the online-rescaling of a streaming softmax, applied to a dot
+//     product.  Nothing can overflow (the check precedes the split), a row whose early stages are its largest simply
+//     resolves the later ones relative to that maximum, like any fp32 accumulation does.
+// The accumulators are un-scaled together with the GT_X3_ALT sign, before the epilogue.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int X3H_E0 = 120;                       // start exponent: any non-zero first stage sets the real one
+constexpr int X3H_TARGET = 13, X3H_LIMIT = 15;    // scaled row amax is put in [2^13, 2^14) and kept below 2^15
+
+__device__ __forceinline__ float x3h_pow2(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }   // -126 <= e <= 127
+
+// two scaled fp32 -> two packed fp16 pairs
+__device__ __forceinline__ void x3h_split_pair(float a, float b, float s, uint32_t (&out)[2]) {
+    const f32x2 r = f32x2{a, b} * s;
+    const f16x2 h0 = __builtin_convertvector(r, f16x2);           // v_cvt_pk_f16_f32 (RNE)
+    const f16x2 h1 = __builtin_convertvector(r - __builtin_convertvector(h0, f32x2), f16x2);
+    out[0] = __builtin_bit_cast(uint32_t, h0);
+    out[1] = __builtin_bit_cast(uint32_t, h1);
+}
+
+__device__ __forceinline__ f32x16 mfma32h(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 // Epilogue shared by both kernels.  Result registers of the 32x32 MFMA with the N-side tile as its A operand: lane
 // (lr = lane & 31, lh = lane >> 5) holds output row  mrow + 32 i  of accumulator (i, j) and the four 4-column groups
 // ncol + 32 j + 8 g .. + 3  (ncol already includes 4 * lh).
@@ -919,6 +954,42 @@ __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict_
         out[(((int64_t)pl * NT + nt) * KS + ks) * 64 + lane] = u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
 }
 
+// GT_PREC_F16X2: the two fp16 planes of B in the same fragment order, one block per 32-column tile: pass 1 takes the tile's
+// amax (its exponent e: amax 2^e in [2^13, 2^14)), pass 2 splits the scaled values.  The exponents follow the planes as NT ints.
+__global__ __launch_bounds__(256) void x3_pack_b16_kernel(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K,
+                                                          int NT, int KS, u32x4* __restrict__ out) {
+    __shared__ float red[4];
+    const int nt = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = nt * 32 + (lane & 31);
+    auto val = [&](int k) -> float {
+        return (n < N && k < K) ? (layout_b == 0 ? B[(int64_t)n * ldb + k] : B[(int64_t)k * ldb + n]) : 0.f;
+    };
+    float amax = 0.f;
+    for (int ks = tid >> 6; ks < KS; ks += 4)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(val(ks * 16 + 8 * (lane >> 5) + e)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
+    const int e = ex == 0 ? 0 : X3H_TARGET + 127 - ex;            // amax 2^e in [2^13, 2^14); an all-zero tile keeps 1
+    const float sc = x3h_pow2(e) * x3_alt_sign(n);                // GT_X3_ALT: odd rows of the N-side operand enter negated
+    for (int ks = tid >> 6; ks < KS; ks += 4) {
+        uint32_t q[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = ks * 16 + 8 * (lane >> 5) + 2 * i;
+            x3h_split_pair(val(k), val(k + 1), sc, q[i]);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+            out[(((int64_t)pl * NT + nt) * KS + ks) * 64 + lane] = u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
+    }
+    if (tid == 0) reinterpret_cast<int*>(out + (int64_t)2 * NT * KS * 64)[nt] = e;
+}
+
 #ifndef GT_X3P_BLOCKS                              // resident blocks per CU the general instances are compiled for
 #define GT_X3P_BLOCKS 3
 #endif
@@ -1159,6 +1230,308 @@ __global__ __launch_bounds__(256, ((HN > 0 || LA == 1 || CV == 1) ? 3 : GT_X3P_B
 #endif
 }
 
+// The GT_PREC_F16X2 twin of gemm_x3p_kernel (two fp16 planes, three products, see above).  It is a SEPARATE body on purpose:
+// folding both arithmetics into one templated body changed hipcc's code for the bf16 instances enough to make the head-norm
+// launch return different bits from run to run (16 rows of one head, one launch in four; tools: 40 repeated launches) while
+// the instruction stream around its counted waits looked the same -- the bf16 kernel above is therefore textually the one
+// that has passed every suite, and this one is gated by its own repeat-launch test.  F16 is always 1 here.
+template <int LA, int HN, int CV, int BN, int F16>     // CV: 0 plain, 1 implicit 3x3 convolution on A
+__device__ __forceinline__ void x3p_body(const GemmP& p) {
+    constexpr int MI = BN == 64 ? 1 : 2;           // 32-row tiles of A per wave
+    static_assert(BN == 128 || (BN == 64 && HN == 0 && LA == 0), "the narrow tile serves plain / convolution launches");
+    constexpr int R = X3P_R, PLANES = F16 ? 2 : 3;
+    constexpr int STG = (HN > 0 ? X3_HN_STG : X3_EP_STG) * 4 * 4;       // bytes of epilogue staging, four waves
+    constexpr int SMEM = R * X3R_OP > STG ? R * X3R_OP : STG;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+    X3P_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = BN == 64 ? wave : wave >> 1, wn = BN == 64 ? 0 : wave & 1;
+    const int wrow = BN == 64 ? wm * 32 : wm * 64; // first tile row of this wave
+    const int lr = lane & 31, lh = lane >> 5;
+    int tile;
+    {
+        const int tiles = gridDim.x, q = tiles >> 3, r = tiles & 7;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * X3_BM, n0 = tn * BN;
+    const int kend = p.K;
+    const float* A = p.A;
+    const uint32_t akey = drop_key_dev(p.a_drop);
+
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};         // the plain epilogue's bias, fetched under the K loop
+    if (HN == 0) x3_bias4(p, n0 + wn * 64, lane, bias4);
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (kend + X3_BK - 1) / X3_BK;
+    int ea[MI];                                    // F16: running exponent of this lane's row in tile i (see x3h_* above)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) ea[i] = X3H_E0;
+    // GT_X3_ALT in this kernel (no register to spare for a per-lane sign): the M-side sign alternates per 32-ROW TILE -- a
+    // compile-time constant of the unrolled tile loop for the 64-row wave tile (a source modifier of the split's first
+    // instructions), the wave's parity (a scalar) for the 32-row one -- the N-side per column (x3_pack_b_kernel)
+    const float tsgn = x3_alt_sign(BN == 64 ? __builtin_amdgcn_readfirstlane(wm) : 0);
+    const float* cv_row[2] = {A, A};
+    int cv_ok[2] = {0, 0}, cv_none[2] = {0, 0}, cv_tap = 0, cv_c0 = 0;      // cv_none: a stage past the end of K reads zeros
+    const int cv_cb = (p.cv_C & 31) ? 16 : 32;
+    if (CV == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + 16 * (wave * 2 + i) + (lane >> 2);
+            if (m < p.M) {
+                const int pix = m % (p.cv_H * p.cv_W), y = pix / p.cv_W, x = pix - y * p.cv_W;
+                int ok = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    ok |= (((unsigned)(y + t / 3 - 1) < (unsigned)p.cv_H) && ((unsigned)(x + t % 3 - 1) < (unsigned)p.cv_W)) << t;
+                cv_ok[i] = ok;
+                cv_row[i] = A + (int64_t)m * p.lda;
+            }
+        }
+    }
+    auto issue = [&](int s) {                      // A stage s -> slot s % R : 2 load instructions per wave
+        char* st = smem + (s % R) * X3R_OP;
+        if (CV == 1) {
+            x3r_issue_conv(cv_row, s < nk ? cv_ok : cv_none, cv_tap, cv_c0, p.cv_W, p.lda, st, wave, lane);
+            cv_c0 += X3_BK;                        // channel block first, taps second, channel blocks last (gt_hip.h)
+            if ((cv_c0 & (cv_cb - 1)) == 0) {
+                cv_c0 -= cv_cb;
+                if (++cv_tap == 9) { cv_tap = 0; cv_c0 += cv_cb; }
+            }
+        } else {
+            x3r_issue<LA>(A, p.lda, m0, p.M, s * X3_BK, kend, st, wave, lane);
+        }
+    };
+    // this wave's two 32-column B fragments of stage ks: plane pl, fragment j at bbase + pl * bplane + (j * KS + ks) KiB
+    // (wave-uniform address in SGPRs + the lane's 16-byte slot).  The loads are inline asm on purpose: hipcc's own
+    // scoreboard answers a register load inside this loop with s_waitcnt vmcnt(0) before the MFMAs, which also drains
+    // the A stage requested a moment earlier (measured in the ISA); here the wait is the counted one below.
+    const int wn_u = __builtin_amdgcn_readfirstlane(wn);
+    const char* bbase = reinterpret_cast<const char*>(p.Bp) + (int64_t)((n0 + wn_u * 64) >> 5) * p.bp_KS * 1024;
+    const int64_t bplane = (int64_t)p.bp_NT * p.bp_KS * 1024;
+    const uint32_t voff = lane * 16;
+    // Two register sets for B, one stage apart: B(kt + 1) is requested at the TOP of iteration kt, before the A stage of that
+    // iteration, and is consumed one iteration later.  Vector-memory loads retire in order, so a wait for B also waits for
+    // every A stage requested before it: with ONE set the loads of B(kt + 1) can only go out behind the MFMAs of B(kt), and
+    // their latency (plus that of the A stage requested one iteration earlier) stands in front of every stage's MFMAs --
+    // load, matrix and store time of a launch add up instead of overlapping (tools/ablate_x3.sh: 37 + 15 + 30 = 82 us).
+    using frag_t = std::conditional_t<F16 != 0, f16x8, bf16x8>;    // the MFMA's own operand type: no conversion (= no copy of a
+                                                                   // register the load has not filled yet) between load and use
+    frag_t bn0[2][PLANES], bn1[2][PLANES];
+    auto loadb = [&](int ks, frag_t (&bn)[2][PLANES]) {
+#ifdef GT_ABL_X3_NOLOADB         // ablation: the B fragments are fetched for the first two stages only (timing; wrong results)
+        if (ks > 1) return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) {
+#ifdef GT_ABL_X3_NOSPLIT_B       // ablation: every stage reads the same (cache-resident) fragment
+                const char* sp = bbase + pl * bplane + (int64_t)j * p.bp_KS * 1024;
+#else
+                const char* sp = bbase + pl * bplane + ((int64_t)j * p.bp_KS + ks) * 1024;
+#endif
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bn[j][pl]) : "v"(voff), "s"(sp));
+            }
+    };
+    // one 32-row tile of A at a time: its fragment is split and goes through its twelve MFMAs before the next one is read
+    // (the three planes of ONE tile are live, not of both: the second B set has to fit under 168 registers)
+    auto stage = [&](int kt, frag_t (&bn)[2][PLANES]) {
+        const char* sa = smem + (kt % R) * X3R_OP;
+        const int kbase = kt * X3_BK + 8 * lh;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float v[8];
+            const int row = wrow + 32 * i + lr;
+            x3r_frag<LA>(sa, row, lh, v);
+            if (p.a_drop.thresh) x3_mask8<LA>(p.a_drop, akey, p.a_drop_ld, 0, m0 + row, kbase, v);
+            if constexpr (F16) {
+                // the row's amax of this stage (both k-halves); lower the row's exponent -- and rescale what the lane has
+                // accumulated for it -- before anything could overflow
+                float amax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                                   fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                const int ex = (int)(__float_as_uint(amax) >> 23);
+                const bool need = ex + ea[i] - 127 >= X3H_LIMIT;
+                if (__any(need)) {                        // wave-uniform
+                    const int enew = need ? X3H_TARGET + 127 - ex : ea[i];
+                    const int d = enew - ea[i];           // <= 0
+                    const float f = d < -126 ? 0.f : x3h_pow2(d);   // 2^-127 of a value is below fp32 resolution of the new ones
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] *= f;
+                    ea[i] = enew;
+                }
+                const float sv = x3h_pow2(ea[i]) * (MI == 1 ? tsgn : ((GT_X3_ALT && (i & 1)) ? -1.f : 1.f));
+                uint32_t q[4][2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x3h_split_pair(v[2 * t], v[2 * t + 1], sv, q[t]);
+                f16x8 am[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) am[pl] = __builtin_bit_cast(f16x8, u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]});
+#pragma unroll
+                for (int s = 1; s >= 0; --s)             // h1 g0 + h0 g1, then h0 g0
+#pragma unroll
+                    for (int pa = 0; pa < 2; ++pa) {
+                        const int pb = s - pa;
+                        if (pb < 0 || pb > 1) continue;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = mfma32h(bn[j][pb], am[pa], acc[i][j]);
+                    }
+                continue;
+            }
+            bf16x8 am[3];
+            if (GT_X3_ALT && (MI == 1 || (i & 1))) {   // M-side: the sign alternates per 32-row tile (see below)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = MI == 1 ? v[q] * tsgn : -v[q];
+            }
+#ifdef GT_ABL_X3_NOSPLIT_A       // ablation builds (tools/ablate_x3.sh): timing only, results are wrong
+            for (int pl = 0; pl < PLANES; ++pl) am[pl] = __builtin_bit_cast(bf16x8, u32x4{__float_as_uint(v[0]), __float_as_uint(v[2]), __float_as_uint(v[4]), __float_as_uint(v[6])});
+#else
+            x3r_split<3>(v, am);
+#endif
+            if constexpr (!F16) {
+#pragma unroll
+                for (int s = 2; s >= 0; --s) {             // plane pairs (pa, pb) with pa + pb = s, smallest terms first
+#pragma unroll
+                    for (int pa = 0; pa < 3; ++pa) {
+                        const int pb = s - pa;
+                        if (pb < 0 || pb >= 3) continue;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = mfma32(bn[j][pb], am[pa], acc[i][j]);
+                    }
+                }
+            }
+        }
+    };
+    // Request order of a wave:  B(0) A(0) .. A(R-2) | B(1) A(R-1) | B(2) A(R) | ...   (A = 2 loads, B = 6).
+    // Top of iteration kt >= 1: A(kt) and B(kt) must have landed; the only request behind B(kt) is A(kt+R-2): vmcnt(2).
+    // The barrier makes every wave's pieces of A(kt) visible and frees slot (kt-1) % R for the request of A(kt+R-1).
+    // Tying the set to the statement keeps its MFMAs behind the wait.  Every iteration issues the same requests -- past
+    // the end of K the A loader reads the zero line into a free slot and B re-reads its last stage -- so the counts hold
+    // to the last stage and no load sits under a branch: a conditional asm load makes hipcc allocate fresh registers for
+    // it and COPY them into the set at the join, before the data has arrived (seen in the ISA of a first version).
+#define X3P_WAIT_AB_(N, bn)                                                                                            \
+    do {                                                                                                               \
+        if constexpr (PLANES == 3)                                                                                     \
+            asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier"                                                        \
+                         : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[0][PLANES - 1]), "+v"(bn[1][0]), "+v"(bn[1][1]),    \
+                           "+v"(bn[1][PLANES - 1])                                                                     \
+                         :                                                                                             \
+                         : "memory");                                                                                  \
+        else                                                                                                           \
+            asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier"                                                        \
+                         : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1])                              \
+                         :                                                                                             \
+                         : "memory");                                                                                  \
+    } while (0)
+#ifdef GT_X3P_PROF                                 // time spent in the waits of the K loop (wave 0)
+    unsigned long long tw_sum = 0;
+#define X3P_WAIT_AB(N, bn)                                                                                             \
+    do {                                                                                                               \
+        const unsigned long long w0_ = __builtin_amdgcn_s_memrealtime();                                              \
+        X3P_WAIT_AB_(N, bn);                                                                                           \
+        tw_sum += __builtin_amdgcn_s_memrealtime() - w0_;                                                              \
+    } while (0)
+#else
+#define X3P_WAIT_AB(N, bn) X3P_WAIT_AB_(N, bn)
+#endif
+    const int klast = nk - 1;
+    loadb(0, bn0);
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s) issue(s);
+    if (R == 3) X3P_WAIT_AB(2, bn0);               // iteration 0: behind A(0) are the R - 2 other stages of the prologue
+    else if (R == 4) X3P_WAIT_AB(4, bn0);
+    else if (R == 5) X3P_WAIT_AB(6, bn0);
+    else X3P_WAIT_AB(8, bn0);
+    X3P_STAMP(1);
+    loadb(klast < 1 ? klast : 1, bn1);
+    issue(R - 1);
+    stage(0, bn0);
+    int kt = 1;
+    for (; kt + 1 < nk; kt += 2) {
+        X3P_WAIT_AB(2, bn1);
+        loadb(kt + 1, bn0);
+        issue(kt + R - 1);
+        stage(kt, bn1);
+        X3P_WAIT_AB(2, bn0);
+        loadb(kt + 2 < klast ? kt + 2 : klast, bn1);
+        issue(kt + R);
+        stage(kt + 1, bn0);
+    }
+    if (kt < nk) {                                 // odd stage out (nk even): nothing left to request
+        X3P_WAIT_AB(2, bn1);
+        stage(kt, bn1);
+    }
+    X3P_STAMP(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero stages requested past the end of K: the ring becomes staging
+#undef X3P_WAIT_AB
+#undef X3P_WAIT_AB_
+#ifdef GT_ABL_X3_NOSTORE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+
+    if constexpr (F16) {           // un-scale (row exponent of the lane, tile exponent of the packed columns) with the ALT sign
+        const int* ebp = reinterpret_cast<const int*>(reinterpret_cast<const char*>(p.Bp) + 2 * bplane) + ((n0 + wn_u * 64) >> 5);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int et = -(ea[i] + ebp[j]);
+                const float sg = x3h_pow2(et < -126 ? -126 : (et > 126 ? 126 : et)) * (MI == 1 ? tsgn : ((GT_X3_ALT && (i & 1)) ? -1.f : 1.f));
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= (GT_X3_ALT && (e & 1)) ? -sg : sg;
+            }
+    } else {
+#if GT_X3_ALT
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float sg = MI == 1 ? tsgn : ((i & 1) ? -1.f : 1.f);
+                    acc[i][j][e] *= (e & 1) ? -sg : sg;
+                }
+#endif
+    }
+    __syncthreads();                               // every wave is done with the ring: its first slots become staging
+    if constexpr (HN > 0)
+        x3_epilogue_hn<(HN > 0 ? HN : 32), 2>(p, acc, m0 + wm * 64 + lr, n0 + wn * 64 + 4 * lh, lane,
+                                               reinterpret_cast<float*>(smem) + wave * X3_HN_STG);
+    else
+        x3_epilogue<MI>(p, acc, m0 + wrow, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * X3_EP_STG, 0, 0, 0, 0,
+                        bias4);
+#ifdef GT_X3P_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the block's stores have left
+    X3P_STAMP(3);
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned long long* o = x3p_prof + 8 * blockIdx.x;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID: cu / sh / se
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // XCC_ID
+        o[6] = tile;
+        o[7] = tw_sum;
+    }
+#endif
+}
+
+template <int LA, int HN, int CV, int BN = 128>        // the GT_PREC_F16X2 instances
+__global__ __launch_bounds__(256, 3) void gemm_x3h_kernel(const GemmP p) {
+    x3p_body<LA, HN, CV, BN, 1>(p);
+}
+
 // operands the ring kernel's direct loads can take (see its header comment)
 static bool x3r_ok(const GemmP& p, int layout_a, int layout_b) {
     if (p.K2 > 0 || !p.a_vec || !p.b_vec) return false;
@@ -1230,8 +1603,21 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
             GemmP q = p;
             q.tiles_n = (p.N + 63) / 64;
             const dim3 gn((unsigned)(p.tiles_m * q.tiles_n));
-            if (p.cv_C > 0) hipLaunchKernelGGL((gemm_x3p_kernel<0, 0, 1, 64>), gn, dim3(256), 0, st, q);
+            if (p.bp_f16) {
+                if (p.cv_C > 0) hipLaunchKernelGGL((gemm_x3h_kernel<0, 0, 1, 64>), gn, dim3(256), 0, st, q);
+                else hipLaunchKernelGGL((gemm_x3h_kernel<0, 0, 0, 64>), gn, dim3(256), 0, st, q);
+            } else if (p.cv_C > 0) hipLaunchKernelGGL((gemm_x3p_kernel<0, 0, 1, 64>), gn, dim3(256), 0, st, q);
             else hipLaunchKernelGGL((gemm_x3p_kernel<0, 0, 0, 64>), gn, dim3(256), 0, st, q);
+            GT_LAUNCH_CHECK();
+            return 0;
+        }
+        if (p.bp_f16) {
+            if (p.cv_C > 0) hipLaunchKernelGGL((gemm_x3h_kernel<0, 0, 1>), grid, dim3(256), 0, st, p);
+            else if (hn == 16) hipLaunchKernelGGL((gemm_x3h_kernel<0, 16, 0>), grid, dim3(256), 0, st, p);
+            else if (hn == 32) hipLaunchKernelGGL((gemm_x3h_kernel<0, 32, 0>), grid, dim3(256), 0, st, p);
+            else if (hn == 64) hipLaunchKernelGGL((gemm_x3h_kernel<0, 64, 0>), grid, dim3(256), 0, st, p);
+            else if (layout_a == 0) hipLaunchKernelGGL((gemm_x3h_kernel<0, 0, 0>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_x3h_kernel<1, 0, 0>), grid, dim3(256), 0, st, p);
             GT_LAUNCH_CHECK();
             return 0;
         }
@@ -1306,8 +1692,13 @@ int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipSt
     if (!ws || ws_bytes < x3_packed_bytes(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) return GT_EWS;
     const int NT = x3p_nt(d->N), KS = x3p_ks(d->K);
     const int threads = NT * KS * 64;
-    hipLaunchKernelGGL(x3_pack_b_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, d->B, d->layout_b, d->ldb, d->N,
-                       d->K, NT, KS, reinterpret_cast<u32x4*>(ws));
+    p.bp_f16 = d->precision == GT_PREC_F16X2;
+    if (p.bp_f16)              // two planes + NT tile exponents: fits the three-plane buffer
+        hipLaunchKernelGGL(x3_pack_b16_kernel, dim3(NT), dim3(256), 0, st, d->B, d->layout_b, d->ldb, d->N, d->K, NT, KS,
+                           reinterpret_cast<u32x4*>(ws));
+    else
+        hipLaunchKernelGGL(x3_pack_b_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, d->B, d->layout_b, d->ldb, d->N,
+                           d->K, NT, KS, reinterpret_cast<u32x4*>(ws));
     GT_LAUNCH_CHECK();
     p.Bp = ws; p.bp_NT = NT; p.bp_KS = KS;
     return 0;
@@ -1316,7 +1707,7 @@ int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipSt
 const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int planes, int hn_dk) {
     static thread_local char buf[112];
     if (p.Bp) {
-        snprintf(buf, sizeof(buf), "void gt::gemm_x3p_kernel<%d, %d, %d, %d>(gt::GemmP)", p.cv_C > 0 ? 0 : layout_a, hn_dk,
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3%c_kernel<%d, %d, %d, %d>(gt::GemmP)", p.bp_f16 ? 'h' : 'p', p.cv_C > 0 ? 0 : layout_a, hn_dk,
                  p.cv_C > 0 ? 1 : 0, (p.N <= 64 && !hn_dk && layout_a == 0) ? 64 : 128);
         return buf;
     }

@@ -380,7 +380,7 @@ class Conv3x3NhwcFn(Function):
             # dw[co][ci][tap] = sum_pix gy[pix][co] x[pix + shift(tap)][ci]
             dw = None
             hip_wgrad = Ww >= 16 and _conv_wgrad[0]
-            if hip_wgrad and ctx.prec == "bf16x3" and _conv_wgrad_planes[0]:
+            if hip_wgrad and ctx.prec in H.SPLIT_EXACT and _conv_wgrad_planes[0]:
                 # operands split once per block into LDS planes, nine taps co-resident (gt_convw.hip): images up to 80 wide
                 try:
                     dw = H.conv3x3_wgrad_nhwc(g.reshape(-1, Cout), Cout, xc.reshape(-1, Cin), Cin, B, Hh, Ww, Cin, Cout)
@@ -422,7 +422,7 @@ def scaler_chain_ok(convs, act_name: str) -> bool:
     conv -> dropout -> ReLU, outputs concatenated) can run as ``scaler_conv_chain``: plain 3x3 / stride 1 / zero padding 1 /
     bias-free, chained channel counts, the first input a multiple of 16 channels, ReLU (it commutes with the dropout
     scale, so both ride on the product's epilogue), the split-operand arithmetic."""
-    if not (_scaler_chain[0] and act_name == "relu" and H.get_precision() == "bf16x3" and len(convs) == 3):
+    if not (_scaler_chain[0] and act_name == "relu" and H.get_precision() in H.SPLIT_EXACT and len(convs) == 3):
         return False
     for c in convs:
         if not (isinstance(c, torch.nn.Conv2d) and tuple(c.kernel_size) == (3, 3) and tuple(c.stride) == (1, 1)
@@ -467,12 +467,13 @@ class ScalerConvChainFn(Function):
         cat = torch.empty(T, 3 * CP, dtype=torch.float32, device=dev)
         salt = _next_salt(3)
         cin = (C0, CP, CP)
+        ctx.prec = H.get_precision()             # bf16x3 or f16x2 (scaler_chain_ok); the backward runs in the same arithmetic
         for i, w in enumerate(ws):
             wf = _conv_k_order(_pad_filter(w, CP, cin[i]))                            # [CP, 9 cin] in k order
             A = x0c.reshape(T, C0) if i == 0 else cat[:, (i - 1) * CP:i * CP]
             H.gemm(A, wf, cat[:, i * CP:(i + 1) * CP], T, CP, 9 * cin[i], lda=(C0 if i == 0 else 3 * CP), ldb=9 * cin[i],
                    ldc=3 * CP, conv=(Hh, Ww, cin[i]), act=H.ACT_RELU,
-                   drop=H.dropout_desc(p_drop, salt + i, dev) if p_drop > 0 else None, precision="bf16x3")
+                   drop=H.dropout_desc(p_drop, salt + i, dev) if p_drop > 0 else None, precision=ctx.prec)
         if _scaler_mask_sink[0] is not None:
             c4 = cat.view(B, Hh, Ww, 3 * CP)
             _scaler_mask_sink[0].append([c4[..., i * CP:i * CP + w.shape[0]] > 0 for i, w in enumerate(ws)])
@@ -484,6 +485,7 @@ class ScalerConvChainFn(Function):
     def backward(ctx, g):
         x0c, w1, w2, w3, cat = ctx.saved_tensors
         p_drop, CP, grad_masked = ctx.cfg
+        prec = ctx.prec
         B, Hh, Ww, C0 = x0c.shape
         T = B * Hh * Ww
         dev = g.device
@@ -511,11 +513,11 @@ class ScalerConvChainFn(Function):
                 if i == 0:
                     dx0 = torch.empty(T, C0, dtype=torch.float32, device=dev)
                     H.gemm(seg, wd, dx0, T, C0, 9 * CP, lda=ldseg, ldb=9 * CP, ldc=C0, conv=(Hh, Ww, CP), alpha=scale,
-                           precision="bf16x3")
+                           precision=prec)
                 else:       # + the segment's own masked gradient (res), through its ReLU / dropout mask (aux)
                     H.gemm(seg, wd, acc[:, (i - 1) * CP:i * CP], T, CP, 9 * CP, lda=ldseg, ldb=9 * CP, ldc=2 * CP,
                            conv=(Hh, Ww, CP), alpha=scale, aux_op=H.AUX_GT0, aux=cat[:, (i - 1) * CP:i * CP], ldaux=3 * CP,
-                           res=gsrc[:, (i - 1) * CP:i * CP], ldr=3 * CP, precision="bf16x3")
+                           res=gsrc[:, (i - 1) * CP:i * CP], ldr=3 * CP, precision=prec)
             H.join_side(dev)        # the next weight gradient reads the segment this data gradient has just completed
         return (None if dx0 is None else dx0.view(B, Hh, Ww, C0)), dws[0], dws[1], dws[2], None, None
 
@@ -829,7 +831,7 @@ class SimpleAttentionFn(Function):
         # tiles, and the raw projection has no reader left: it is neither written nor allocated (gt_hip.h: hn_plain)
         plain = (_plain_tiles[0] and kind == "galerkin" and _dkv_ln_fused[0] and H.galerkin_dkv_ln_supported(dk, p, norm_mask)
                  and H.galerkin_ktv_supported(dk, p))
-        if _qkvnorm_fused[0] and dk in (16, 32, 64) and bqkv is not None and H.get_precision() == "bf16x3":
+        if _qkvnorm_fused[0] and dk in (16, 32, 64) and bqkv is not None and H.get_precision() in H.SPLIT_EXACT:
             # head norm on the projection's epilogue (GT_EP_HEADNORM): one pass less over [T, 3d], one launch less
             out3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
             stats = torch.empty(2, T, h, 2, dtype=torch.float32, device=dev)

@@ -171,7 +171,13 @@ typedef struct gt_gemm_desc {
      *                  v_mfma_f32_32x32x16_bf16 in fp32: same rounding class as GT_PREC_F32 (the 1e-5 parity gate
      *                  holds), 16/6 of its matrix rate;
      *   GT_PREC_BF16X2 two terms / three products (~2^-16 relative);
-     *   GT_PREC_BF16   operands rounded to bf16, one product: throughput mode with its own (3e-3) gate.
+     *   GT_PREC_BF16   operands rounded to bf16, one product: throughput mode with its own (3e-3) gate;
+     *   GT_PREC_F16X2  every operand value is split into TWO fp16 terms (11 + 11 significand bits) after scaling by a
+     *                  power of two that tracks the data (weights: per 32-column tile when they are packed; activation rows:
+     *                  a running per-row exponent inside the kernel, the accumulator rescaled when it has to drop), three
+     *                  products on v_mfma_f32_32x32x16_f16: fp32-class results at half the matrix work of GT_PREC_BF16X3.
+     *                  Implemented by the packed-B kernels (a weight against >= 16384 token rows, the implicit
+     *                  convolutions); every other launch of this mode runs GT_PREC_BF16X3.
      * The split kernel serves the plain-epilogue products with M, N >= 96 (whole 128 x 128 tiles); everything else
      * (fused heads, head-norm epilogue, narrow or tiny problems, the tall-skinny path) stays on the fp32 pipe in
      * every mode. */
@@ -215,6 +221,7 @@ typedef struct gt_gemm_desc {
 #define GT_PREC_BF16X3 1
 #define GT_PREC_BF16X2 2
 #define GT_PREC_BF16   3
+#define GT_PREC_F16X2  4
 
 #define GT_EP_NORMAL  0
 #define GT_EP_ROWDOT  1

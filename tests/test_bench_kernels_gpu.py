@@ -141,8 +141,10 @@ def test_encoder_layer_bench_kernel_instances(gpu_device, name, mode):
         gt.set_attention_dropout("reference")
     bad = {k: v for k, v in errs.items() if not v < TOL}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
-    if gt.get_precision() == "bf16x3":                     # the kernel selection of the default arithmetic
+    if gt.get_precision() in _hip.SPLIT_EXACT:             # the kernel selection of the fp32-class split-operand modes
+        pk = "gemm_x3h_kernel" if gt.get_precision() == "f16x2" else "gemm_x3p_kernel"
         for k in c["expect"]:
+            k = k.replace("gemm_x3p_kernel", pk)
             assert k in kernels, (k, sorted(set(kernels)))
         assert spy.dkv_plain == [c["plain"]] and spy.ktv_affine == [c["plain"]]
         if _hip._dual_stream[0]:
@@ -268,11 +270,14 @@ def test_whole_model_darcy141_vs_oracle(gpu_device, mode, scaler_act):
     print(json.dumps({"mode": mode, "scaler_act": scaler_act, "worst": max(errs.values()),
                       "worst_outside_downscaler": max(v for k, v in errs.items() if not k.startswith("downscaler.")),
                       "oracle_f32_worst": max(noise.values()) if noise else None}))
-    if gt.get_precision() == "bf16x3":
-        want = ["gemm_x3p_kernel<0, 32, 0, 128>", "gemm_x3p_kernel<0, 0, 0, 128>", "gemm_x3p_kernel<0, 0, 1, 128>", "gt_galerkin_dkv_ln"]
+    if gt.get_precision() in _hip.SPLIT_EXACT:
+        pk = "gemm_x3h_kernel" if gt.get_precision() == "f16x2" else "gemm_x3p_kernel"
+        want = ["gemm_x3p_kernel<0, 32, 0, 128>", "gemm_x3p_kernel<0, 0, 0, 128>", "gemm_x3p_kernel<0, 0, 1, 128>", "gt_galerkin_dkv_ln",
+                "gt_conv3x3_wgrad_nhwc"]
         if scaler_act == "relu":               # the down-scaler's narrow convolutions on the 128 x 64 tile
             want += ["gemm_x3p_kernel<0, 0, 1, 64>", "gt_bilinear2d_seg_fwd"]
         for k in want:
+            k = k.replace("gemm_x3p_kernel", pk)
             assert k in kernels, (k, sorted(kernels))
 
 

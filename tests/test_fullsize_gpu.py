@@ -105,7 +105,10 @@ def test_galerkin_attention_equivariances_at_bench_batch(gpu_device):
     finally:
         gt.set_attention_dropout("reference")
     assert torch.isfinite(y).all()
-    assert torch.equal(yb, y[bp])                      # same kernels, same per-sample arithmetic: bitwise
+    # same kernels, same per-sample arithmetic -- up to the sign-alternating accumulation (gt_gemm_x3.hip: GT_X3_ALT), whose
+    # sign follows a row's position in its 128-row tile: a permuted sample can see the matrix pipe's chop from the other side,
+    # a last-bit difference (bitwise equality held until round 4, with the coherent offset it removes)
+    assert rel_l2(yb, y[bp]) < 2e-7
     assert rel_l2(yt, y[:, tp]) < TOL                  # summation order over tokens changes: fp32 noise only
 
 

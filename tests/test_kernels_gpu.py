@@ -1407,3 +1407,106 @@ def test_conv3x3_wgrad_nhwc_rejects_what_it_does_not_cover(H, gpu_device):
     xw, gw = rnd(1 * 2 * 96, 16, dev=dev, seed=623), rnd(1 * 2 * 96, 48, dev=dev, seed=624)
     with pytest.raises(H.GtNotSupported):
         H.conv3x3_wgrad_nhwc(gw, 48, xw, 16, 1, 2, 96, 16, 48)               # W > 80
+
+
+@pytest.mark.parametrize("N,K", [(128, 128), (256, 128), (128, 384), (384, 128)])
+def test_gemm_f16x2_dynamic_row_scaling(H, gpu_device, N, K):
+    """GT_PREC_F16X2 on the packed-B kernel (two fp16 terms per operand, three products, per-row running exponent on the
+    activation side, per-tile exponent on the packed weight): rows spanning ten decades of magnitude, rows that grow or shrink
+    a thousandfold along K (the accumulator is rescaled in flight), zero rows and a zero stage -- every ROW of the product must
+    be fp32-class accurate relative to its own scale, and identical inputs give identical bits."""
+    dev = gpu_device
+    M = 20000                                  # >= 16384: the packed-B kernel
+    g = torch.Generator().manual_seed(700 + N + K)
+    A = torch.randn(M, K, generator=g)
+    A *= 10.0 ** (torch.rand(M, 1, generator=g) * 10.0 - 6.0)                  # row magnitudes 1e-6 .. 1e4
+    ramp = torch.logspace(0, 3, K).unsqueeze(0)
+    A[1000:2000] *= ramp                                                       # growing along K: exponent drops in flight
+    A[2000:3000] *= ramp.flip(1)                                               # shrinking along K
+    A[3000:3100] = 0.0
+    A[3100:3200, :16] = 0.0                                                    # an all-zero first stage
+    A[3200:3300, 32:] = 0.0                                                    # nothing after the second stage
+    B = torch.randn(N, K, generator=g) * 0.05
+    B[:32] *= 1e-4                                                             # one fragment tile of tiny weights
+    B[32:64] *= 1e3
+    Ad, Bd = A.to(dev), B.to(dev)
+    ref = A.double() @ B.double().t()
+    scale = A.double().abs() @ B.double().abs().t()                           # the un-cancelled magnitude of every output
+    C = torch.empty(M, N, device=dev)
+    H.gemm(Ad, Bd, C, M, N, K, lda=K, ldb=K, ldc=N, precision="f16x2")
+    torch.cuda.synchronize()
+    assert "gemm_x3h_kernel" in H.gemm_kernel_name(Ad, Bd, M, N, K, lda=K, ldb=K, ldc=N, precision="f16x2")
+    err = (C.double().cpu() - ref).abs() / scale.clamp_min(1e-300)
+    err[scale == 0] = (C.double().cpu()[scale == 0]).abs()
+    assert float(err.max()) < 2e-6, float(err.max())                          # every element, relative to sum |a||b|
+    assert float(err.pow(2).mean().sqrt()) < 1e-7
+    row_err = (C.double().cpu() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300)
+    assert float(row_err[ref.norm(dim=1) > 0].max()) < 2e-6
+    assert torch.equal(C[3000:3100], torch.zeros_like(C[3000:3100]))
+    C2 = torch.empty(M, N, device=dev)
+    H.gemm(Ad, Bd, C2, M, N, K, lda=K, ldb=K, ldc=N, precision="f16x2")
+    assert torch.equal(C, C2)
+    # the same product in the default arithmetic, for scale
+    C3 = torch.empty(M, N, device=dev)
+    H.gemm(Ad, Bd, C3, M, N, K, lda=K, ldb=K, ldc=N, precision="bf16x3")
+    err3 = (C3.double().cpu() - ref).abs() / scale.clamp_min(1e-300)
+    print("f16x2 rms %.2e max %.2e | bf16x3 rms %.2e max %.2e" % (float(err.pow(2).mean().sqrt()), float(err.max()),
+                                                                    float(err3.pow(2).mean().sqrt()), float(err3.max())))
+
+
+def test_conv3x3_f16x2_matches_conv2d(H, gpu_device):
+    """The implicit 3x3 convolution (forward and data gradient) in GT_PREC_F16X2 against torch's conv2d in fp64."""
+    from galerkin_transformer import ops
+    dev = gpu_device
+    old = H.set_precision("f16x2")
+    try:
+        x = rnd(4, 77, 77, 128, dev=dev, seed=801).requires_grad_(True)
+        w = rnd(128, 128, 3, 3, dev=dev, seed=802, scale=0.05).requires_grad_(True)
+        y = ops.conv3x3_nhwc(x, w)
+        cot = rnd(*y.shape, dev=dev, seed=803)
+        y.backward(cot)
+        torch.cuda.synchronize()
+    finally:
+        H.set_precision(old)
+    xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1)
+    yr.backward(cot.double())
+    assert rel_l2(y, yr) < KTOL and rel_l2(x.grad, xr.grad) < KTOL and rel_l2(w.grad, wr.grad) < KTOL
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x2"])
+def test_packed_gemm_repeat_launch_bitwise(H, gpu_device, prec):
+    """The packed-B kernels order their loads with COUNTED waits (inline-asm fragment loads, vmcnt(N) + barrier): a miscount
+    shows up as a few rows of one launch in several differing from run to run, not as a wrong mean.  Forty back-to-back
+    launches of the three hot instances -- QKV + head-norm epilogue on plain tiles, a plain token product, the implicit 3x3
+    convolution -- must all return the bits of the first one.  (Round 4: a refactoring of the kernel body made exactly the
+    head-norm launch flicker, 16 rows of one head in one launch out of four, with an unchanged instruction stream around
+    the waits; this test is what keeps that from coming back unnoticed.)"""
+    dev = gpu_device
+    B, n, d, h, p = 18, 1849, 128, 4, 2
+    T, dk = B * n, d // h
+    DP = H.round4(dk + p)
+    x, pos = rnd(T, d, dev=dev, seed=901), rnd(T, p, dev=dev, seed=902)
+    wq, bq = rnd(3 * d, d, dev=dev, seed=903, scale=0.1), rnd(3 * d, dev=dev, seed=904, scale=0.1)
+    gamma, beta = torch.ones(2, h, dk, device=dev), torch.zeros(2, h, dk, device=dev)
+    w2 = rnd(256, d, dev=dev, seed=905, scale=0.1)
+    img, wc = rnd(6, 77, 77, 128, dev=dev, seed=906), rnd(128, 9 * 128, dev=dev, seed=907, scale=0.05)
+
+    def launch():
+        out3 = torch.empty(3, T, h, DP, device=dev)
+        stats = torch.empty(2, T, h, 2, device=dev)
+        H.gemm(x, wq, None, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bq, precision=prec,
+               hn=dict(gamma=gamma, beta=beta, pos=pos, out=out3, stats=stats, h=h, dk=dk, p=p, norm_mask=6, eps=1e-7,
+                       skip_raw=7, plain=True))
+        y = torch.empty(T, 256, device=dev)
+        H.gemm(x, w2, y, T, 256, d, lda=d, ldb=d, ldc=256, precision=prec)
+        c = torch.empty(6 * 77 * 77, 128, device=dev)
+        H.gemm(img.reshape(-1, 128), wc, c, 6 * 77 * 77, 128, 9 * 128, lda=128, ldb=9 * 128, ldc=128, conv=(77, 77, 128),
+               precision=prec)
+        return out3, stats, y, c
+
+    first = launch()
+    for _ in range(40):
+        again = launch()
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)

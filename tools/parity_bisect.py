@@ -75,8 +75,11 @@ def summarize(out, grads):
             "worst": [(k, float("%.3g" % v)) for k, v in worst]}
 
 
-def run(classes=None, base="bf16x3", fused_qkv=True, conv_implicit=True):
-    old = gt.set_precision(base)
+DEFAULT = os.environ.get("GT_PRECISION", "bf16x3")
+
+
+def run(classes=None, base=None, fused_qkv=True, conv_implicit=True):
+    old = gt.set_precision(base or DEFAULT)
     H.set_precision_classes(classes)
     ops._qkvnorm_fused[0] = fused_qkv
     ops._conv_implicit[0] = conv_implicit
@@ -98,7 +101,7 @@ def run(classes=None, base="bf16x3", fused_qkv=True, conv_implicit=True):
 res = {"B": B, "ffn_activation": FFN_ACT, "oracle_seconds": t_oracle,
        "oracle_f32": summarize(y32, dp32), "runs": {}}
 R = res["runs"]
-R["bf16x3 (default)"] = run()
+R[f"{DEFAULT} (default)"] = run()
 R["f32 everywhere"] = run(base="f32")
 CLS = ("conv",) if os.environ.get("BISECT_QUICK") else ("tok", "batched", "wgrad", "hn", "conv")
 for c in CLS:
@@ -106,7 +109,7 @@ for c in CLS:
         R["bf16x3, QKV projection unfused"] = run(fused_qkv=False)
         continue
     if c == "conv":     # implicit convolutions exist on the split engine only: the library's fp32 convolutions instead
-        R["bf16x3, convolutions -> library fp32"] = run(conv_implicit=False)
+        R[f"{DEFAULT}, convolutions -> library fp32"] = run(conv_implicit=False)
         continue
     R[f"bf16x3, {c} -> f32"] = run(classes={c: "f32"})
 if not os.environ.get("BISECT_QUICK"):
