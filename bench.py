@@ -502,29 +502,37 @@ def cpu_baseline_leg(model_cpu_sd, cfg, budget_s=20.0):
                 sample=f"{n} steps of batch {B} (fwd+MSE+bwd+clip+Adam, {src}), {dt:.1f} s of CPU time")
 
 
-def accuracy_leg(precision, seeds=(1, 2, 3)):
+def accuracy_leg(precision, n_seeds=10, first_seed=1000):
     """Second half of the metric: validation rel-L2 after the short synthetic-Darcy training run of
-    tools/accuracy_leg.py on this GPU, next to the reference's own CPU runs of the same recipe, data, initial weights
-    and dropout seeds (profiles/accuracy_reference_cpu.json, recorded in the build container where /root/reference
-    exists).  The 128-step run peaks at lr 1e-3 and is noise-sensitive (individual runs land between 0.08 and 0.29 for
-    BOTH implementations), so several dropout seeds are run and the spread is reported, not one number."""
+    tools/accuracy_leg.py on this GPU, over `n_seeds` dropout seeds, next to the reference's own CPU runs of the same
+    recipe, data, initial weights and dropout seeds (profiles/accuracy_reference_cpu_seeds.json: twelve seeds recorded in
+    the build container, where /root/reference exists).  The 128-step run peaks at lr 1e-3 and is noise-sensitive --
+    individual runs land between 0.08 and 0.26 for BOTH implementations -- so the two samples are compared as
+    distributions: mean +- standard error and Welch's two-sample t-test."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import accuracy_leg as AL
+    import accuracy_seeds as AS
+    seeds = [first_seed + i for i in range(n_seeds)]
     runs = [AL.run("hip", dropout_seed=sd) for sd in seeds]
-    vals = [r["val_rel_l2"] for r in runs]
+    hs = AS.summarize([r["val_rel_l2"] for r in runs])
     out = {"metric": "validation relative L2 error after %d epochs (%d steps of batch %d) on the synthetic Darcy set"
                      % (runs[0]["epochs"], runs[0]["steps"], runs[0]["batch"]),
-           "hip": {"val_rel_l2_mean": round(sum(vals) / len(vals), 5), "val_rel_l2_runs": [round(v, 5) for v in vals],
-                   "dropout_seeds": list(seeds), "seconds_per_run": runs[0]["seconds"], "precision": precision},
-           "reference_cpu": None, "data": runs[0]["data"]}
+           "hip": {"val_rel_l2_mean": round(hs["mean"], 5), "val_rel_l2_sem": round(hs["sem"], 5),
+                   "val_rel_l2_std": round(hs["std"], 5), "val_rel_l2_runs": [round(v, 5) for v in hs["values"]],
+                   "dropout_seeds": seeds, "seconds_per_run": runs[0]["seconds"], "precision": precision},
+           "reference_cpu": None, "welch_t_test": None, "data": runs[0]["data"]}
     try:
-        with open(os.path.join(ROOT, "profiles", "accuracy_reference_cpu.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "accuracy_reference_cpu_seeds.json")) as f:
             ref = json.load(f)
-        rv = [r["val_rel_l2"] for r in ref["runs"]]
-        out["reference_cpu"] = {"val_rel_l2_mean": round(sum(rv) / len(rv), 5), "val_rel_l2_runs": [round(v, 5) for v in rv],
+        rs = AS.summarize([r["val_rel_l2"] for r in ref["runs"]])
+        out["reference_cpu"] = {"val_rel_l2_mean": round(rs["mean"], 5), "val_rel_l2_sem": round(rs["sem"], 5),
+                                "val_rel_l2_std": round(rs["std"], 5), "val_rel_l2_runs": [round(v, 5) for v in rs["values"]],
                                 "dropout_seeds": [r["dropout_seed"] for r in ref["runs"]],
                                 "seconds_per_run": ref["runs"][0]["seconds"],
-                                "source": "profiles/accuracy_reference_cpu.json (tools/accuracy_leg.py --impl reference)"}
+                                "source": "profiles/accuracy_reference_cpu_seeds.json (tools/accuracy_seeds.py --impl reference)"}
+        w = AS.welch(hs, rs)
+        out["welch_t_test"] = {"t": round(w["t"], 3), "df": round(w["df"], 1), "p_two_sided": round(w["p_two_sided"], 4),
+                               "reading": "p > 0.05: the two error distributions are statistically indistinguishable"}
     except (OSError, ValueError, KeyError):
         pass
     return out

@@ -956,36 +956,66 @@ __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict_
 
 // GT_PREC_F16X2: the two fp16 planes of B in the same fragment order, one block per 32-column tile: pass 1 takes the tile's
 // amax (its exponent e: amax 2^e in [2^13, 2^14)), pass 2 splits the scaled values.  The exponents follow the planes as NT ints.
-__global__ __launch_bounds__(256) void x3_pack_b16_kernel(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K,
-                                                          int NT, int KS, u32x4* __restrict__ out) {
-    __shared__ float red[4];
-    const int nt = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+__global__ __launch_bounds__(1024) void x3_pack_b16_kernel(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K,
+                                                           int NT, int KS, u32x4* __restrict__ out) {
+    __shared__ float red[16];
+    const int nt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = nt * 32 + (lane & 31);
-    auto val = [&](int k) -> float {
-        return (n < N && k < K) ? (layout_b == 0 ? B[(int64_t)n * ldb + k] : B[(int64_t)k * ldb + n]) : 0.f;
-    };
-    float amax = 0.f;
-    for (int ks = tid >> 6; ks < KS; ks += 4)
+    auto load8 = [&](int ks, float (&v)[8]) {        // this lane's eight k of stage ks (one row n, k contiguous or strided)
+        const int k0 = ks * 16 + 8 * (lane >> 5);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(val(ks * 16 + 8 * (lane >> 5) + e)));
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            v[e] = (n < N && k < K) ? (layout_b == 0 ? B[(int64_t)n * ldb + k] : B[(int64_t)k * ldb + n]) : 0.f;
+        }
+    };
+    // sixteen waves, a stage each per trip; a wave's stages stay in registers between the two passes when there are at most
+    // four of them (K <= 1024), so the weight is read once
+    constexpr int KEEP = 4;
+    float keep[KEEP][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        const int ks = w + 16 * i;
+        if (ks < KS) {
+            load8(ks, keep[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(keep[i][e]));
+        }
+    }
+    for (int ks = w + 16 * KEEP; ks < KS; ks += 16) {
+        float v[8];
+        load8(ks, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if (lane == 0) red[tid >> 6] = amax;
+    if (lane == 0) red[w] = amax;
     __syncthreads();
-    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, red[i]);
     const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
     const int e = ex == 0 ? 0 : X3H_TARGET + 127 - ex;            // amax 2^e in [2^13, 2^14); an all-zero tile keeps 1
     const float sc = x3h_pow2(e) * x3_alt_sign(n);                // GT_X3_ALT: odd rows of the N-side operand enter negated
-    for (int ks = tid >> 6; ks < KS; ks += 4) {
+    auto store = [&](int ks, const float (&v)[8]) {
         uint32_t q[4][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = ks * 16 + 8 * (lane >> 5) + 2 * i;
-            x3h_split_pair(val(k), val(k + 1), sc, q[i]);
-        }
+        for (int i = 0; i < 4; ++i) x3h_split_pair(v[2 * i], v[2 * i + 1], sc, q[i]);
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
             out[(((int64_t)pl * NT + nt) * KS + ks) * 64 + lane] = u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
+    };
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        const int ks = w + 16 * i;
+        if (ks < KS) store(ks, keep[i]);
+    }
+    for (int ks = w + 16 * KEEP; ks < KS; ks += 16) {
+        float v[8];
+        load8(ks, v);
+        store(ks, v);
     }
     if (tid == 0) reinterpret_cast<int*>(out + (int64_t)2 * NT * KS * 64)[nt] = e;
 }
@@ -1694,7 +1724,7 @@ int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipSt
     const int threads = NT * KS * 64;
     p.bp_f16 = d->precision == GT_PREC_F16X2;
     if (p.bp_f16)              // two planes + NT tile exponents: fits the three-plane buffer
-        hipLaunchKernelGGL(x3_pack_b16_kernel, dim3(NT), dim3(256), 0, st, d->B, d->layout_b, d->ldb, d->N, d->K, NT, KS,
+        hipLaunchKernelGGL(x3_pack_b16_kernel, dim3(NT), dim3(1024), 0, st, d->B, d->layout_b, d->ldb, d->N, d->K, NT, KS,
                            reinterpret_cast<u32x4*>(ws));
     else
         hipLaunchKernelGGL(x3_pack_b_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, d->B, d->layout_b, d->ldb, d->N,
