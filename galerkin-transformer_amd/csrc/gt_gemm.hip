@@ -633,6 +633,7 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
         memset(&q, 0, sizeof(q));
         q.M = d->M; q.N = d->N; q.K = d->K; q.K2 = d->K2; q.cv_C = d->cv_c; q.cv_wgrad = d->cv_wgrad != 0;
         if (x3_packed_ok(d, pl.x3, pl.split)) { q.Bp = d->B; q.bp_f16 = d->precision == GT_PREC_F16X2; }
+        q.wg_f16 = x3w_ok(d, pl.split);
         q.a_vec = al16(d->A) && m4(d->lda) && m4(d->a_bs0) && m4(d->a_bs1);
         q.b_vec = al16(d->B) && m4(d->ldb) && m4(d->b_bs0) && m4(d->b_bs1);
         snprintf(buf, n, "%s", x3_kernel_name(q, d->layout_a, d->layout_b, pl.x3,
@@ -822,6 +823,7 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
             int rcp = x3_pack_b(d, p, ws, ws_bytes, st);
             if (rcp) return rcp;
         }
+        p.wg_f16 = x3w_ok(d, pl.split);
         int rcx = x3_launch(p, d->layout_a, d->layout_b, pl.x3, (unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split,
                             (unsigned)batch, st);
         if (rcx) return rcx;

@@ -32,6 +32,7 @@ struct GemmP {
     int hn_h, hn_dk, hn_p, hn_DP, hn_mask, hn_skip_raw, hn_plain; float hn_eps;
     int cv_H, cv_W, cv_C, cv_wgrad;  // implicit 3x3 convolution (gt_hip.h: cv_*), cv_C = 0: plain GEMM
     const void* Bp; int bp_NT, bp_KS, bp_f16; // packed-B kernel (gt_gemm_x3.hip): bf16 (fp16: bp_f16) planes of B in fragment order
+    int wg_f16;                              // gemm_x3w_kernel: the GT_PREC_F16X2 token-contracted weight gradient
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------
@@ -389,5 +390,6 @@ const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int plane
 bool x3_packed_ok(const gt_gemm_desc* d, int planes, int split);
 int64_t x3_packed_bytes(const gt_gemm_desc* d);
 int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipStream_t st);
+bool x3w_ok(const gt_gemm_desc* d, int split);
 
 }  // namespace gt

@@ -1562,6 +1562,169 @@ __global__ __launch_bounds__(256, 3) void gemm_x3h_kernel(const GemmP p) {
     x3p_body<LA, HN, CV, BN, 1>(p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Token-contracted weight gradients in GT_PREC_F16X2:  C[M][N] = sum_k A[k][M] B[k][N]  (both operands x-contiguous
+// activations, K = tokens, M / N multiples of 128), split-K slabs like the ring kernel's.  gemm_x3r_kernel<1, 1> splits both
+// operands again in every wave that multiplies them (each value is split twice per block, ~10 VALU instructions per MFMA:
+// 121 / 181 us for 363 / 484 MB of operands); here a stage of 32 tokens is split ONCE, by the thread that fetched it, into
+// two fp16 planes in LDS ([plane][k-group of 8 tokens][row]: a fragment is one aligned ds_read_b128, consecutive rows in
+// consecutive 16-byte slots), and the four waves read their fragments from there: 24 MFMAs per wave and stage against ~180
+// VALU instructions per thread.  The scale is one running exponent per operand and BLOCK: every stage the block takes the
+// amax of the two tiles it is about to split (wave reduce + four floats through LDS, the barrier is there anyway), lowers the
+// exponent -- rescaling its accumulators -- when the scaled amax would reach 2^15, and otherwise keeps it, so nothing can
+// overflow and values are resolved to 2^-22 of the largest magnitude the block has seen (the weight gradient is a sum over
+// all tokens: the tensor's scale is the relevant one).  GT_X3_ALT as everywhere: odd rows of both operands enter negated.
+constexpr int X3W_KG = 4;                            // k-groups (8 tokens) per stage
+constexpr int X3W_PLANE = X3W_KG * 128 * 16;         // bytes of one plane of one operand tile: 8 KB
+
+__global__ __launch_bounds__(256, 3) void gemm_x3w_kernel(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * X3W_PLANE];      // A planes 0 / 1, B planes 0 / 1
+    __shared__ float red[1][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    int tile;
+    {
+        const int tiles = gridDim.x, q = tiles >> 3, r = tiles & 7;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int by = blockIdx.y, kbeg = by * p.k_chunk, kend = min(p.K, kbeg + p.k_chunk);
+    const bool do_acs = p.acs != nullptr && tn == 0;
+
+    // staging role: waves 0, 1 stage the A tile, waves 2, 3 the B tile; a thread owns rows 4 r4 .. 4 r4 + 3 of its tile and the
+    // eight tokens of k-group kg: eight 16-byte loads (a wave instruction covers 512 contiguous bytes of two token rows), four
+    // 8-token units to split and store
+    const bool isB = wave >= 2;                        // wave-uniform
+    const int st = tid & 127, r4 = st & 31, kg = st >> 5;
+    const float* Op = isB ? p.B + n0 + 4 * r4 : p.A + m0 + 4 * r4;
+    const int64_t ldo = isB ? p.ldb : p.lda;
+    f32x4 v[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + 8 * kg + e;
+            v[e] = *reinterpret_cast<const f32x4*>(k < kend ? Op + (int64_t)k * ldo : x3_zero);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int ea = X3H_E0, eb = X3H_E0;                      // block-uniform running exponents of the two operands
+    float asum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        // amax of the stage (the values are in registers), per operand over its two waves
+        float mx = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[e][0]), fabsf(v[e][1])), fmaxf(fabsf(v[e][2]), fabsf(v[e][3]))));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) red[0][wave] = mx;
+        __syncthreads();                               // also: every wave is done reading the previous stage's planes
+        const float ma = fmaxf(red[0][0], red[0][1]), mb = fmaxf(red[0][2], red[0][3]);
+        const int xa = (int)(__float_as_uint(ma) >> 23), xb = (int)(__float_as_uint(mb) >> 23);
+        int d = 0;
+        if (xa + ea - 127 >= X3H_LIMIT) { d += X3H_TARGET + 127 - xa - ea; ea = X3H_TARGET + 127 - xa; }
+        if (xb + eb - 127 >= X3H_LIMIT) { d += X3H_TARGET + 127 - xb - eb; eb = X3H_TARGET + 127 - xb; }
+        if (d != 0) {                                  // block-uniform
+            const float f = d < -126 ? 0.f : x3h_pow2(d);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] *= f;
+        }
+        const float sc = x3h_pow2(isB ? eb : ea);
+        char* planes = smem + (isB ? 2 * X3W_PLANE : 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                  // row 4 r4 + c: its eight tokens -> one unit per plane
+            if (do_acs && !isB)
+                asum[c] += ((v[0][c] + v[1][c]) + (v[2][c] + v[3][c])) + ((v[4][c] + v[5][c]) + (v[6][c] + v[7][c]));
+            const float sv = (GT_X3_ALT && (c & 1)) ? -sc : sc;          // odd rows enter negated
+            uint32_t q[4][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x3h_split_pair(v[2 * t][c], v[2 * t + 1][c], sv, q[t]);
+            const int off = (kg * 128 + 4 * r4 + c) << 4;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                *reinterpret_cast<u32x4*>(planes + pl * X3W_PLANE + off) = u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
+        }
+        if (k0 + 32 < kend) fetch(k0 + 32);           // the next stage's values travel under this stage's MFMAs
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {               // two MFMA k-steps of 16 tokens
+            f16x8 am[2][2], bn[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const int kq = 2 * ks + lh;
+                    am[i][pl] = *reinterpret_cast<const f16x8*>(smem + pl * X3W_PLANE + ((kq * 128 + wm * 64 + 32 * i + lr) << 4));
+                    bn[i][pl] = *reinterpret_cast<const f16x8*>(smem + (2 + pl) * X3W_PLANE + ((kq * 128 + wn * 64 + 32 * i + lr) << 4));
+                }
+#pragma unroll
+            for (int s = 1; s >= 0; --s)
+#pragma unroll
+                for (int pa = 0; pa < 2; ++pa) {
+                    const int pb = s - pa;
+                    if (pb < 0 || pb > 1) continue;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32h(bn[j][pb], am[i][pa], acc[i][j]);
+                }
+        }
+    }
+
+    if (do_acs) {                                      // row sums of A: the four k-group threads of a row
+        __syncthreads();
+        float* part = reinterpret_cast<float*>(smem);
+        if (!isB) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[kg * 128 + 4 * r4 + c] = asum[c];
+        }
+        __syncthreads();
+        if (tid < 128 && m0 + tid < p.M)
+            p.acs[(int64_t)by * p.M + m0 + tid] = (part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid]);
+    }
+    // un-scale, undo the sign, store the slab tile: lane (lr, lh) holds row m = .. + 32 i + lr and columns .. + 32 j + 8 g + 4 lh + t
+    const int et = -(ea + eb);
+    const float us = x3h_pow2(et < -126 ? -126 : (et > 126 ? 126 : et)) * x3_alt_sign(lr);
+    float* C = p.C + (int64_t)by * p.c_split;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + 32 * i + lr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + 32 * j + 8 * g + 4 * lh;
+                if (m < p.M && n < p.N)
+                    *reinterpret_cast<f32x4*>(C + (int64_t)m * p.ldc + n) =
+                        f32x4{acc[i][j][4 * g] * us, -acc[i][j][4 * g + 1] * us, acc[i][j][4 * g + 2] * us, -acc[i][j][4 * g + 3] * us};
+            }
+    }
+}
+
+// the launches gemm_x3w_kernel takes: GT_PREC_F16X2, both operands x-contiguous and 16-byte aligned, whole 128 x 128 tiles,
+// a long token contraction cut into split-K slabs (raw epilogue), no batching / dropout / second product
+bool x3w_ok(const gt_gemm_desc* d, int split) {
+    static const int on = [] { const char* e = getenv("GT_X3W"); return e ? atoi(e) : 1; }();
+    return on && d->precision == GT_PREC_F16X2 && d->layout_a == 1 && d->layout_b == 1 && split > 1 && d->K >= 16384 &&
+           (d->M & 127) == 0 && (d->N & 127) == 0 && d->batch0 * d->batch1 == 1 && d->K2 == 0 && d->cv_c == 0 &&
+           !(d->a_drop.p > 0.f) && ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B)) & 15) == 0 &&
+           (d->lda & 3) == 0 && (d->ldb & 3) == 0;
+}
+
 // operands the ring kernel's direct loads can take (see its header comment)
 static bool x3r_ok(const GemmP& p, int layout_a, int layout_b) {
     if (p.K2 > 0 || !p.a_vec || !p.b_vec) return false;
@@ -1691,6 +1854,11 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
         GT_LAUNCH_CHECK();
         return 0;
     }
+    if (p.wg_f16) {                                // GT_PREC_F16X2 weight gradient (x3w_ok said yes)
+        hipLaunchKernelGGL(gemm_x3w_kernel, grid, dim3(256), 0, st, p);
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
     if (lay == 0) x3_launch_planes<0, 0>(p, planes, ring, grid, st);
     else if (lay == 1) x3_launch_planes<0, 1>(p, planes, ring, grid, st);
     else if (lay == 2) x3_launch_planes<1, 0>(p, planes, ring, grid, st);
@@ -1743,6 +1911,10 @@ const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int plane
     }
     if (hn_dk > 0) {
         snprintf(buf, sizeof(buf), "void gt::gemm_x3r_kernel<0, 0, 3, %d, %d, 0>(gt::GemmP)", x3_ring_depth(), hn_dk);
+        return buf;
+    }
+    if (p.wg_f16) {
+        snprintf(buf, sizeof(buf), "gt::gemm_x3w_kernel(gt::GemmP)");
         return buf;
     }
     if (p.cv_C > 0 && p.cv_wgrad)

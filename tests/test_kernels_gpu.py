@@ -1510,3 +1510,33 @@ def test_packed_gemm_repeat_launch_bitwise(H, gpu_device, prec):
         again = launch()
         for a, b in zip(first, again):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 256, 33282), (384, 128, 20000), (256, 128, 236672)])
+def test_gemm_f16x2_weight_gradient_kernel(H, gpu_device, M, N, K):
+    """gemm_x3w_kernel (GT_PREC_F16X2 token-contracted weight gradient: a stage of 32 tokens split once into fp16 planes in LDS,
+    one running exponent per operand and block with in-flight accumulator rescaling, split-K slabs + fixed-order reduce,
+    the bias gradient riding on it as column sums of A): against fp64, with magnitudes that change a thousandfold along the
+    token axis (early blocks see small values, late blocks large ones; inside a block the exponent drops as the ramp climbs)."""
+    dev = gpu_device
+    g = torch.Generator().manual_seed(1200 + M + N)
+    A = torch.randn(K, M, generator=g)
+    B = torch.randn(K, N, generator=g)
+    A *= torch.logspace(-3, 0, K).unsqueeze(1)                 # gradient-like: grows along the tokens
+    B[: K // 3] *= 50.0
+    Ad, Bd = A.to(dev), B.to(dev)
+    C = torch.empty(M, N, device=dev)
+    cs = torch.empty(M, device=dev)
+    H.gemm(Ad, Bd, C, M, N, K, layout_a=1, layout_b=1, lda=M, ldb=N, ldc=N, split_k=0, a_colsum=cs, precision="f16x2")
+    torch.cuda.synchronize()
+    assert "gemm_x3w_kernel" in H.gemm_kernel_name(Ad, Bd, M, N, K, layout_a=1, layout_b=1, lda=M, ldb=N, ldc=N, split_k=0,
+                                                   precision="f16x2")
+    ref = Ad.double().t() @ Bd.double()
+    scale = Ad.double().abs().t() @ Bd.double().abs()
+    err = ((C.double() - ref).abs() / scale)
+    assert float(err.max()) < 1e-6 and float(err.pow(2).mean().sqrt()) < 5e-8, (float(err.max()), float(err.pow(2).mean().sqrt()))
+    assert rel_l2(C, ref) < KTOL
+    assert rel_l2(cs, Ad.double().sum(0)) < KTOL
+    C2, cs2 = torch.empty(M, N, device=dev), torch.empty(M, device=dev)
+    H.gemm(Ad, Bd, C2, M, N, K, layout_a=1, layout_b=1, lda=M, ldb=N, ldc=N, split_k=0, a_colsum=cs2, precision="f16x2")
+    assert torch.equal(C, C2) and torch.equal(cs, cs2)
