@@ -579,6 +579,7 @@ constexpr int CRB_PXT = 8;
 #define GT_CRB_CG 8
 #endif
 constexpr int CRB_CG = GT_CRB_CG;
+static_assert(CRB_CG % 4 == 0 && CRB_CG >= 4, "the channels-last paths read a pixel's CRB_CG channels as float4 groups");
 #ifndef GT_CRB_WAVES                               // resident waves per SIMD the one-channel instance is compiled for
 #define GT_CRB_WAVES 2
 #endif
@@ -993,7 +994,9 @@ static int conv_resize_bwd(const float* g, const float* y, const float* x, const
                            void* stream) {
     if (int rc = check_conv_resize(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
     if (!g || !dw) return GT_EINVAL;
-    if (y_nhwc && ((Cout & 7) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(g)) & 15))) return GT_ENOTSUP;
+    // channels-last: a block walks whole channel groups of CRB_CG (a build-time constant) as aligned float4s
+    if (y_nhwc && ((Cout & 7) || (Cout % CRB_CG) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(g)) & 15)))
+        return GT_ENOTSUP;
     if (!ws || ws_bytes < gt_conv3x3_resize_bwd_ws_bytes(B, Cin, Cout, H, W)) return GT_EWS;
     ConvResizeP p{x, w, const_cast<float*>(y), g, reinterpret_cast<float*>(ws), B, Cin, Cout, H, W, Ho, Wo,
                   scale_of(H, Ho), scale_of(W, Wo), make_drop(drop), y_nhwc, 0};

@@ -209,7 +209,11 @@ class SpectralConv1dFn(Function):
 
 def spectral_conv2d(x, wlin, blin, w0, w1, modes: int, act: str = "silu", return_freq: bool = False):
     """return_freq: also the zero-padded half spectrum of the mixed modes, (B, Cout, n, n//2 + 1) complex64, as the reference
-    returns it (layers.py:1179-1197) -- assembled from the retained coefficients, detached (a diagnostic output)."""
+    returns it (layers.py:1179-1197) -- assembled from the retained coefficients, detached (a diagnostic output).
+    DEVIATION from the reference: the returned spectrum is DETACHED (marked non-differentiable).  In the reference `out_ft`
+    is part of the autograd graph (layers.py:1179-1196), so a loss or regulariser built on it reaches the weights; here it
+    would silently get zero gradient.  No script of the reference differentiates through it (it is a debug / plotting output);
+    build such a term from the module's output instead."""
     out, Y = SpectralConv2dFn.apply(x, wlin, blin, w0, w1, int(modes), H.ACT_CODE[act], bool(return_freq))
     if not return_freq:
         return out

@@ -1,0 +1,66 @@
+#!/bin/bash
+# Round-4 measurement pass (one gpurun call).  usage: bash tools/gpu_r4_final.sh <tag> <step> [<step> ...]
+#   suite   the whole -m gpu suite (default arithmetic)          full    tests/test_fullsize_models_gpu.py (C3 / C4 / C5 at full size)
+#   bench   the default bench.py line (+ per-kernel table)        prof    rocprofv3 kernel stats of the steady step, one stream, by grid
+#   pmc     FETCH_SIZE / WRITE_SIZE / SQ passes -> pmc_step.json   sweep   batch sweep        work   the informational workloads
+#   mode:<p> short bench in arithmetic <p>
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r05}; shift
+O=$R/gpurun_out/$TAG; mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+BENCH_FAST="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-accuracy"
+for step in "$@"; do
+  name=${step%%:*}; arg=""; [[ "$step" == *:* ]] && arg=${step#*:}
+  echo "=== $step"
+  case $name in
+    suite) ( time timeout 2400 python -m pytest tests -m gpu -q --deselect tests/test_fullsize_models_gpu.py ) > $O/suite.log 2>&1; grep -E "passed|failed|^FAILED" $O/suite.log | cut -c1-250 | tail -8
+           cp gpurun_out/parity_*.json $O/ 2>/dev/null;;
+    full) ( time timeout 2400 python -m pytest tests/test_fullsize_models_gpu.py -q ) > $O/full.log 2>&1; grep -E "passed|failed|^FAILED" $O/full.log | cut -c1-250 | tail -4
+          cp gpurun_out/parity_whole_model_full_*.json $O/ 2>/dev/null;;
+    bench) ( time timeout 1500 python bench.py --table $O/bench_table.json 2>$O/bench.err | tail -1 ) > $O/bench.json 2>$O/bench.time
+           python -c "import json;r=json.loads(open('$O/bench.json').read().strip().splitlines()[0]);print('bench',r['value'],r['ms_per_step'],'roofline',r['roofline']['kernel'],r['roofline']['avg_launch_us'],r['roofline']['frac'],'cpu',r['cpu_baseline']['value'],'acc',r['accuracy']['hip']['val_rel_l2_mean'],r['accuracy']['welch_t_test'])";;
+    mode) ( timeout 400 python bench.py $BENCH_FAST --precision $arg 2>$O/bench_$arg.err | tail -1 ) > $O/bench_prec_$arg.json
+          python -c "import json;r=json.load(open('$O/bench_prec_$arg.json'));print('precision $arg',r['value'],r['ms_per_step'])";;
+    prof)
+      cd /tmp
+      GT_DUAL_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o trace --output-format csv -- \
+          python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-f32-leg --no-accuracy > $O/prof.log 2>&1
+      cd $R
+      MS=$(grep '^{"metric' $O/prof.log | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step']*10)")
+      python tools/prof_csv_summary.py $O/prof 90 --last-ms $MS --by-grid > $O/kernel_stats_steady.txt 2>&1
+      rm -rf $O/prof
+      head -30 $O/kernel_stats_steady.txt | cut -c1-150;;
+    pmc)
+      cd /tmp
+      for C in FETCH_SIZE WRITE_SIZE; do
+        timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmc/$C -o pmc --output-format csv -- \
+            python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-f32-leg --no-accuracy > $O/pmc_$C.log 2>&1
+      done
+      timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $O/pmc/SQ -o pmc --output-format csv -- \
+          python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-f32-leg --no-accuracy > $O/pmc_SQ.log 2>&1
+      cd $R
+      python tools/pmc_to_json.py $O/pmc $O/pmc_step.json
+      python tools/pmc_summary.py $O/pmc 60 > $O/pmc_summary.txt 2>&1
+      rm -rf $O/pmc
+      head -24 $O/pmc_summary.txt | cut -c1-170;;
+    sweep)
+      echo "[" > $O/sweep.json
+      for B in 4 16 64 128 256; do
+        timeout 300 python bench.py --batch $B --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-accuracy --no-f32-leg 2>/dev/null | tail -1 >> $O/sweep.json
+        echo "," >> $O/sweep.json
+      done
+      timeout 300 python bench.py --batch 4 --no-graph --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-accuracy --no-f32-leg 2>/dev/null | tail -1 >> $O/sweep.json
+      echo "]" >> $O/sweep.json
+      python -c "
+import json
+for r in json.load(open('$O/sweep.json')): print('B', r['config']['per_gpu_batch'], 'graph' if r['config']['hip_graph'] else 'eager', r['value'], r['ms_per_step'])";;
+    work)
+      for W in ex3_darcy_inv ex2_darcy211_fourier ex4_ns ex1_burgers; do
+        timeout 400 python bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-accuracy --no-f32-leg 2>$O/work_$W.err | tail -1 > $O/bench_$W.json
+        python -c "import json;r=json.load(open('$O/bench_$W.json'));print('$W',r['value'],r['ms_per_step'],r['config']['per_gpu_batch'])"
+      done
+      timeout 400 python bench.py --loss weighted_l2 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-accuracy --no-f32-leg 2>/dev/null | tail -1 > $O/bench_weighted_l2.json
+      python -c "import json;r=json.load(open('$O/bench_weighted_l2.json'));print('weighted_l2',r['value'],r['ms_per_step'])";;
+  esac
+done
