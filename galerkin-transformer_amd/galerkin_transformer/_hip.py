@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 15          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 16          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -144,7 +144,7 @@ _PROTOS = {
                                                                                C.c_void_p]),
     "gt_debug_conv0_mask": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gt_conv3x3_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 5 +
-                              [C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+                              [C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "gt_conv3x3_wgrad_nhwc_ws_bytes": (C.c_int64, [C.c_int32] * 5),
     "gt_bilinear2d_seg_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p]),
     "gt_bilinear2d_seg_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p, C.c_void_p]),
@@ -832,20 +832,21 @@ def conv3x3_resize_fwd(x: torch.Tensor, w: torch.Tensor, size, drop: Optional[Gt
 
 
 def conv3x3_wgrad_nhwc(gy: torch.Tensor, ldg: int, x: torch.Tensor, ldx: int, B: int, Hh: int, Ww: int, Cin: int,
-                       Cout: int, alpha: float = 1.0) -> torch.Tensor:
+                       Cout: int, alpha: float = 1.0, precision: Optional[str] = None) -> torch.Tensor:
     """dw [Cout, Cin, 3, 3] of a narrow channels-last 3x3 convolution (gt_hip.h: gt_conv3x3_wgrad_nhwc).  gy / x: 2-D views
     [B*H*W, >= Cout / Cin] whose row pitch is ldg / ldx (column segments of wider buffers are read in place).  Raises
     GtNotSupported for shapes the kernel does not take (the caller owns the fallback)."""
     need_f32_cuda(gy, x)
     L = lib()
+    prec = _precision[0] if precision is None else PREC_CODE[precision]
     need = L.gt_conv3x3_wgrad_nhwc_ws_bytes(B, Hh, Ww, Cin, Cout)
-    if need <= 0:
+    if need <= 0 or prec not in (PREC_BF16X3, PREC_F16X2):
         raise GtNotSupported("gt_conv3x3_wgrad_nhwc: " + _ERR[-4])
     ws = workspace(gy.device, need)
     dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=gy.device)
     check(_timed("gt_conv3x3_wgrad_nhwc", 18.0 * B * Hh * Ww * Cin * Cout, 4.0 * B * Hh * Ww * (Cin + Cout),
                  lambda: L.gt_conv3x3_wgrad_nhwc(gy.data_ptr(), ldg, x.data_ptr(), ldx, dw.data_ptr(), B, Hh, Ww, Cin, Cout,
-                                                 float(alpha), ws.data_ptr(), ws.numel(), stream_ptr()),
+                                                 float(alpha), prec, ws.data_ptr(), ws.numel(), stream_ptr()),
                  shape=(B, Hh, Ww, Cin, Cout)), "gt_conv3x3_wgrad_nhwc")
     return dw
 

@@ -383,7 +383,8 @@ class Conv3x3NhwcFn(Function):
             if hip_wgrad and ctx.prec in H.SPLIT_EXACT and _conv_wgrad_planes[0]:
                 # operands split once per block into LDS planes, nine taps co-resident (gt_convw.hip): images up to 80 wide
                 try:
-                    dw = H.conv3x3_wgrad_nhwc(g.reshape(-1, Cout), Cout, xc.reshape(-1, Cin), Cin, B, Hh, Ww, Cin, Cout)
+                    dw = H.conv3x3_wgrad_nhwc(g.reshape(-1, Cout), Cout, xc.reshape(-1, Cin), Cin, B, Hh, Ww, Cin, Cout,
+                                              precision=ctx.prec)
                 except H.GtNotSupported:
                     dw = None
             if hip_wgrad and dw is None:       # nine [Cout, Cin] products over the pixels, K chunks x taps on one launch
@@ -506,7 +507,7 @@ class ScalerConvChainFn(Function):
             xin, ldx = (x0c.reshape(T, C0), C0) if i == 0 else (cat[:, (i - 1) * CP:i * CP], 3 * CP)
             if ctx.needs_input_grad[1 + i]:
                 with H.side_branch(dev, T):
-                    dws[i] = _scaler_wgrad(seg, ldseg, xin, ldx, ws[i], B, Hh, Ww, CP, cin[i], scale)
+                    dws[i] = _scaler_wgrad(seg, ldseg, xin, ldx, ws[i], B, Hh, Ww, CP, cin[i], scale, prec)
             # dx[pix][ci] = scale * sum_tap sum_co dpre[pix - shift(tap)][co] W[co][ci][tap]: tap' = 8 - tap
             if i > 0 or ctx.needs_input_grad[0]:
                 wd = _conv_k_order(_pad_filter(ws[i].flip(2, 3).transpose(0, 1), cin[i], CP))   # [cin, 9 CP] in k order
@@ -525,7 +526,7 @@ class ScalerConvChainFn(Function):
 _scaler_wgrad_hip = [os.environ.get("GT_SCALER_WGRAD", "hip") != "miopen"]     # A/B switch (tools / tests)
 
 
-def _scaler_wgrad(dseg, ldg, xin, ldx, w, B, Hh, Ww, CP, cin, scale):
+def _scaler_wgrad(dseg, ldg, xin, ldx, w, B, Hh, Ww, CP, cin, scale, prec=None):
     """dW[co][ci][tap] = scale * sum_pix dseg[pix][co] xin[pix + shift(tap)][ci] for one narrow convolution: both operands are
     activations (column segments read in place through their row pitches), one side is <= 48 wide, nine taps share them:
     gt_conv3x3_wgrad_nhwc (gt_convw.hip) -- operands split once per block into LDS planes, all nine taps co-resident.
@@ -534,7 +535,7 @@ def _scaler_wgrad(dseg, ldg, xin, ldx, w, B, Hh, Ww, CP, cin, scale):
     co, ci = w.shape[0], w.shape[1]
     if _scaler_wgrad_hip[0]:
         try:
-            return H.conv3x3_wgrad_nhwc(dseg, ldg, xin, ldx, B, Hh, Ww, cin, CP, alpha=scale)[:co, :ci].contiguous()
+            return H.conv3x3_wgrad_nhwc(dseg, ldg, xin, ldx, B, Hh, Ww, cin, CP, alpha=scale, precision=prec)[:co, :ci].contiguous()
         except H.GtNotSupported:
             pass
     gd = dseg.contiguous().view(B, Hh, Ww, CP).permute(0, 3, 1, 2)                      # dense channels-last

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 15
+#define GT_ABI_VERSION 16
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -477,14 +477,16 @@ int gt_conv3x3_resize_bwd_nhwc(const float* g, const float* y, const float* x, c
  * layers.py:88-150), whose weight gradients autograd would compute with cudnn/MIOpen's conv2d weight backward:
  *     dw[co][ci][ky][kx] = alpha * sum_{b,y,x} gy[(b H + y) W + x][co] * x[(b H + y + ky - 1) W + x + kx - 1][ci]
  * gy / x: channels-last images with pixel pitches ldg >= Cout / ldx >= Cin (a column segment of a wider buffer is read in
- * place), 16-byte aligned, pitches multiples of 4.  dw: [Cout][Cin][3][3], the reference's layout.  Arithmetic: the three-plane
- * split-operand products of gt_gemm (GT_PREC_BF16X3), each operand value split once per block (gt_convw.hip).
+ * place), 16-byte aligned, pitches multiples of 4.  dw: [Cout][Cin][3][3], the reference's layout.  precision: GT_PREC_BF16X3
+ * (three bf16 planes, six products) or GT_PREC_F16X2 (two fp16 planes under one running power-of-two scale per operand and
+ * block, three products); each operand value is split once per block (gt_convw.hip).
  * GT_ENOTSUP unless W <= 80 and (Cout == 48, Cin % 16 == 0: the down-scaler's padded narrow convolutions) or (Cout % 64 == 0,
  * Cin % 32 == 0: the up-scaler's 128 -> 128 convolution).  Deterministic: partial results per (image, row chunk) in ws
  * (>= gt_conv3x3_wgrad_nhwc_ws_bytes), summed in a fixed order.
  * ------------------------------------------------------------------------------------------- */
 int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* x, int64_t ldx, float* dw, int32_t B, int32_t H,
-                          int32_t W, int32_t Cin, int32_t Cout, float alpha, void* ws, int64_t ws_bytes, void* stream);
+                          int32_t W, int32_t Cin, int32_t Cout, float alpha, int32_t precision, void* ws, int64_t ws_bytes,
+                          void* stream);
 int64_t gt_conv3x3_wgrad_nhwc_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 
 /* Parity hook for the fused convolution's ReLU (reference: Conv2dResBlock's activation, layers.py:139-149, which the fused

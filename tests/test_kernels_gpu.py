@@ -1366,7 +1366,8 @@ def test_conv3x3_resize_channels_last_output(H, gpu_device):
     (2, 20, 37, 32, 36, 48, -2.0),          # odd width, pitch > channels
     (1, 3, 5, 48, 48, 48, 1.0),             # tiny image: every row and column touches the zero padding
 ])
-def test_conv3x3_wgrad_nhwc_matches_conv2d(H, gpu_device, B, Hh, Ww, Cin, ldx, ldg, alpha):
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x2"])
+def test_conv3x3_wgrad_nhwc_matches_conv2d(H, gpu_device, B, Hh, Ww, Cin, ldx, ldg, alpha, prec):
     """gt_conv3x3_wgrad_nhwc (gt_convw.hip: operands split once per block into LDS planes, pixel-interleaved k, nine taps
     co-resident, sign-alternating accumulation) against the weight gradient of torch's conv2d in fp64 -- the reference's
     autograd path for Interp2dEncoder's conv1 / conv2 / conv3 (libs/layers.py:463-482, 88-150).  Operands are read in place
@@ -1379,7 +1380,11 @@ def test_conv3x3_wgrad_nhwc_matches_conv2d(H, gpu_device, B, Hh, Ww, Cin, ldx, l
     gbuf = rnd(T, ldg, dev=dev, seed=612)
     off_x, off_g = (ldx - Cin) // 4 * 4, (ldg - Cout) // 4 * 4      # 16-byte aligned column offsets inside the buffers
     xv, gv = xbuf[:, off_x:off_x + Cin], gbuf[:, off_g:off_g + Cout]
-    dw = H.conv3x3_wgrad_nhwc(gv, ldg, xv, ldx, B, Hh, Ww, Cin, Cout, alpha=alpha)
+    # (the fp16 arithmetic keeps one running exponent per operand and block: a tenfold ramp over the image rows moves it)
+    ramp = torch.logspace(0, 1, Hh, device=dev).repeat_interleave(Ww).repeat(B).unsqueeze(1)
+    xbuf, gbuf = xbuf * ramp, gbuf * ramp.flip(0)
+    xv, gv = xbuf[:, off_x:off_x + Cin], gbuf[:, off_g:off_g + Cout]
+    dw = H.conv3x3_wgrad_nhwc(gv, ldg, xv, ldx, B, Hh, Ww, Cin, Cout, alpha=alpha, precision=prec)
     torch.cuda.synchronize()
     xr = xv.double().reshape(B, Hh, Ww, Cin).permute(0, 3, 1, 2).contiguous()
     gr = gv.double().reshape(B, Hh, Ww, Cout).permute(0, 3, 1, 2).contiguous()
@@ -1393,7 +1398,7 @@ def test_conv3x3_wgrad_nhwc_matches_conv2d(H, gpu_device, B, Hh, Ww, Cin, ldx, l
         for kx in range(3):
             assert rel_l2(dw[:, :, ky, kx], ref[:, :, ky, kx]) < 2 * KTOL, (ky, kx)
     # deterministic
-    dw2 = H.conv3x3_wgrad_nhwc(gv, ldg, xv, ldx, B, Hh, Ww, Cin, Cout, alpha=alpha)
+    dw2 = H.conv3x3_wgrad_nhwc(gv, ldg, xv, ldx, B, Hh, Ww, Cin, Cout, alpha=alpha, precision=prec)
     assert torch.equal(dw, dw2)
 
 
