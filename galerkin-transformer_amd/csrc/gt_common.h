@@ -72,6 +72,13 @@ __device__ inline void silu_both(float x, float& a, float& da) {   // value and 
     da = s * (1.f + x * (1.f - s));
 }
 
+// erf GELU (torch.nn.GELU's default, reference layers.py:968): value Phi(x) x and derivative Phi(x) + x phi(x)
+__device__ inline void gelu_both(float x, float& a, float& da) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    a = x * cdf;
+    da = cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -511,6 +511,7 @@ static int x3_planes(const gt_gemm_desc* d) {
 static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     if (d->M <= 0 || d->N <= 0 || d->K < 0 || d->batch0 <= 0 || d->batch1 <= 0) return GT_EINVAL;
     if (d->precision < GT_PREC_F32 || d->precision > GT_PREC_F16X2) return GT_EINVAL;
+    if (d->act < GT_ACT_NONE || d->act > GT_ACT_SILU) return GT_EINVAL;      // GT_ACT_GELU: elementwise entry points only
     const int64_t batch = (int64_t)d->batch0 * d->batch1;
     if (batch > 65535) return GT_EINVAL;
     pl->x3 = x3_planes(d);

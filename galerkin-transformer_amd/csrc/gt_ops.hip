@@ -30,6 +30,7 @@ __global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restr
 __device__ __forceinline__ void act_pair(int act, float v, float& a, float& da) {
     if (act == GT_ACT_SILU) silu_both(v, a, da);
     else if (act == GT_ACT_RELU) { a = fmaxf(v, 0.f); da = v > 0.f ? 1.f : 0.f; }
+    else if (act == GT_ACT_GELU) gelu_both(v, a, da);
     else { a = v; da = 1.f; }
 }
 template <bool BWD>
@@ -1341,7 +1342,7 @@ static int dropact_launch(bool bwd, const float* x, const float* gy, float* out,
                           int32_t act1, const gt_dropout* d2, int32_t act2, void* stream) {
     if (!x || !out || n < 0 || (bwd && !gy)) return GT_EINVAL;
     if ((d1 && d1->p > 0.f && !d1->seed) || (d2 && d2->p > 0.f && !d2->seed)) return GT_EINVAL;
-    if (act1 < GT_ACT_NONE || act1 > GT_ACT_SILU || act2 < GT_ACT_NONE || act2 > GT_ACT_SILU) return GT_EINVAL;
+    if (act1 < GT_ACT_NONE || act1 > GT_ACT_GELU || act2 < GT_ACT_NONE || act2 > GT_ACT_GELU) return GT_EINVAL;
     if (n == 0) return 0;
     const int vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     const int grid = grid_for((n + 3) / 4, 256, 8192);

@@ -16,14 +16,15 @@ _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
 ABI_VERSION = 16          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
-ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3, PREC_BF16X2, PREC_BF16 = 0, 1, 2, 3
 PREC_F16X2 = 4
 PREC_CODE = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x2": PREC_BF16X2, "bf16": PREC_BF16, "f16x2": PREC_F16X2}
 SPLIT_EXACT = ("bf16x3", "f16x2")      # the fp32-class split-operand modes: same kernel selection, same fused paths
-ACT_CODE = {None: ACT_NONE, "none": ACT_NONE, "identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
+ACT_CODE = {None: ACT_NONE, "none": ACT_NONE, "identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU,
+            "gelu": ACT_GELU}      # gelu: drop_act only (the GEMM epilogues reject it)
 
 
 class GtDropout(C.Structure):

@@ -39,6 +39,8 @@ def _act_name(module) -> str:
         return "silu"
     if isinstance(module, nn.ReLU):
         return "relu"
+    if isinstance(module, nn.GELU) and getattr(module, "approximate", "none") == "none":
+        return "gelu"
     if isinstance(module, (nn.Identity, Identity)):
         return "none"
     raise NotImplementedError(f"activation {type(module).__name__} has no HIP path")
@@ -431,6 +433,13 @@ class FeedForward(nn.Module):
         if self.batch_norm:
             raise NotImplementedError("batch_norm=True is outside the HIP hot path (False in every config)")
         p_h = self.dropout.p if self.training else 0.0
+        if isinstance(self.activation, nn.GELU):
+            # activation='gelu' (reference layers.py:968; no config selects it): the two GEMMs with the erf GELU and its
+            # dropout as one elementwise pass between them -- the GEMM epilogues carry relu / silu only
+            hid = ops.drop_act(ops.linear(x, self.lr1.weight, self.lr1.bias), 0.0, _act_name(self.activation),
+                               training=True, p2=p_h)
+            y = ops.linear(hid, self.lr2.weight, self.lr2.bias, p_drop=p_out)
+            return y if residual is None else residual + y
         return ops.feed_forward(x, self.lr1.weight, self.lr1.bias, self.lr2.weight, self.lr2.bias,
                                 res=residual, act=_act_name(self.activation), p_h=p_h, p_out=p_out)
 

@@ -36,6 +36,7 @@ extern "C" {
 #define GT_ACT_NONE 0
 #define GT_ACT_RELU 1
 #define GT_ACT_SILU 2
+#define GT_ACT_GELU 3   /* erf GELU; gt_dropact_fwd / gt_dropact_bwd only (every other entry point: GT_EINVAL) */
 
 /* gt_gemm_desc.aux_op: multiply the result by a function of aux[m][n] */
 #define GT_AUX_NONE      0

@@ -4,6 +4,7 @@ same machinery as make_golden.py, separate generator so the existing fixtures st
 
   corner_enc_galerkin_nopos   SimpleTransformerEncoderLayer.forward(x, pos=None): no coordinate columns, no `fc`
                               (reference layers.py:869-874, 894-897)
+  corner_enc_galerkin_gelu    the same layer with coordinates and FeedForward(activation='gelu')   (layers.py:968-969)
   corner_sconv2d_freq         SpectralConv2d(return_freq=True) -> (out, out_ft)   (layers.py:1190-1197)
   corner_sconv1d_freq         SpectralConv1d(return_freq=True)                    (layers.py:1102-1106)
   corner_sconv2d_dropmask     SpectralConv2d with dropout on the FFT branch input only (layers.py:1173), the Bernoulli
@@ -50,6 +51,20 @@ def main():
     mask = (torch.rand(2, 4, 16, 16, generator=g) >= 0.5).float() * 2.0
     meta = dict(kind="encoder_layer", B=2, n=140, nopos=True, **kw)
     record("corner_enc_galerkin_nopos", layer, dict(x=x), lambda m, x: m(x, None), meta, ctl, masks=[mask])
+
+    # encoder layer whose FeedForward runs the erf GELU (activation_type='gelu', reference layers.py:968-969): appended
+    # draws from its own generator so the fixtures above stay byte-identical
+    g2 = torch.Generator().manual_seed(20260927)
+    torch.manual_seed(6)
+    kwg = dict(d_model=64, pos_dim=2, n_head=4, dim_feedforward=128, attention_type="galerkin", layer_norm=False,
+               attn_norm=True, norm_eps=1e-7, activation_type="gelu")
+    layer = M.SimpleTransformerEncoderLayer(dropout=0.0, ffn_dropout=0.0, **kwg)
+    perturb(layer, g2)
+    xg = torch.randn(2, 140, 64, generator=g2)
+    pg = torch.rand(2, 140, 2, generator=g2)
+    maskg = (torch.rand(2, 4, 18, 18, generator=g2) >= 0.5).float() * 2.0
+    record("corner_enc_galerkin_gelu", layer, dict(x=xg, pos=pg), lambda m, x, pos: m(x, pos),
+           dict(kind="encoder_layer", B=2, n=140, **kwg), ctl, masks=[maskg])
 
     def cat_freq(out, ft):
         ft = ft.detach()

@@ -696,16 +696,34 @@ def test_gemm_tall_skinny_wgrad_into_column_slice(H, gpu_device):
     assert rel_l2(cs, A.double().sum(0)) < KTOL
 
 
+def test_gelu_is_elementwise_only(H, gpu_device):
+    """GT_ACT_GELU (erf GELU, reference layers.py:968-969) lives in gt_dropact_* -- value and derivative against float64 --
+    and every GEMM epilogue refuses it instead of silently running the identity."""
+    from galerkin_transformer import ops
+    dev = gpu_device
+    x = (3.0 * rnd(50001, dev=dev, seed=5)).requires_grad_(True)
+    cot = rnd(50001, dev=dev, seed=6)
+    y = ops.drop_act(x, 0.0, "gelu")
+    y.backward(cot)
+    xd = x.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.gelu(xd)
+    yd.backward(cot.double())
+    assert rel_l2(y, yd) < 1e-6 and rel_l2(x.grad, xd.grad) < 1e-6
+    A, W, C = rnd(64, 32, dev=dev, seed=7), rnd(48, 32, dev=dev, seed=8), torch.empty(64, 48, device=dev)
+    with pytest.raises(Exception):
+        H.gemm(A, W, C, 64, 48, 32, lda=32, ldb=32, ldc=48, act=H.ACT_GELU)
+
+
 @pytest.mark.parametrize("n", [4096 * 3 + 1, 64 * 77 * 77])
 @pytest.mark.parametrize("p1,a1,p2,a2", [(0.1, "relu", 0.0, "none"), (0.05, "silu", 0.05, "silu"), (0.0, "silu", 0.3, "relu"),
-                                         (0.0, "none", 0.0, "silu")])
+                                         (0.0, "none", 0.0, "silu"), (0.0, "gelu", 0.2, "none")])
 def test_drop_act_fused_equals_chain(H, gpu_device, n, p1, a1, p2, a2):
     """ops.drop_act == activation(dropout(activation(dropout(x)))) built from the separate operators with the same
     seed and salts (identical masks), forward and backward; also in eval mode."""
     from galerkin_transformer import ops
     import torch.nn.functional as F
     dev = gpu_device
-    act = {"relu": torch.relu, "silu": F.silu, "none": lambda v: v}
+    act = {"relu": torch.relu, "silu": F.silu, "gelu": F.gelu, "none": lambda v: v}
     x0 = rnd(n, dev=dev, seed=90)
     cot = rnd(n, dev=dev, seed=91)
     for training in (True, False):

@@ -10,7 +10,7 @@ ORACLE_TOL = 2e-6     # fp32 round-off between two orderings of the same math
 
 
 def _enc_kwargs(meta):
-    keys = ("n_head", "attention_type", "layer_norm", "attn_norm", "norm_eps", "residual_type")
+    keys = ("n_head", "attention_type", "layer_norm", "attn_norm", "norm_eps", "residual_type", "activation_type")
     kw = {k: meta[k] for k in keys if k in meta and meta[k] is not None}
     return kw
 
