@@ -351,6 +351,19 @@ def roofline_leg(trainer, precision):
     # stream): operands come from wherever the producing kernel left them (L2 / Infinity Cache / HBM), as in the timed
     # region.  The same launch replayed back-to-back on a cold 0.6 GB working set is reported next to it.
     dur_s = by_shape[top_shape] / n_shape[top_shape] * 1e-3
+    # the launches of one output shape differ in their epilogue operands (FFN1 forward: A, B, C; the hidden-gradient launch
+    # of the same shape also reads the saved activation as `aux`): time AND algorithmic bytes are averaged over the same
+    # launches, and the kinds are listed (the counter passes average over the same set)
+    same = [r for r in recs if r[6] == top_shape]
+    mean_flops = sum(r[1] for r in same) / len(same)
+    mean_bytes = sum(r[2] for r in same) / len(same)
+    kinds = {}
+    for r in same:
+        k = kinds.setdefault(int(r[2]), [0, 0.0])
+        k[0] += 1
+        k[1] += r[3].elapsed_time(r[4])
+    launch_kinds = [dict(algorithmic_bytes=b, launches=n, avg_launch_us=round(ms / n * 1e3, 2),
+                         hbm_gbs=round(b / (ms / n * 1e-3) / 1e9, 1)) for b, (n, ms) in sorted(kinds.items())]
     call, _keep = best[5]
     reps = 50
     for _ in range(3):
@@ -365,9 +378,9 @@ def roofline_leg(trainer, precision):
     x3 = "x3" in dom
     products = PLANE_PRODUCTS.get(precision, 1) if x3 else 1
     peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
-    useful = best[1] / dur_s / 1e12                      # 2 M N K per launch: what the caller asked for
+    useful = mean_flops / dur_s / 1e12                   # 2 M N K per launch: what the caller asked for
     executed = useful * products                         # flops the matrix pipe actually retires
-    hbm = best[2] / dur_s / 1e9
+    hbm = mean_bytes / dur_s / 1e9
     # which roofline bounds this launch: the larger of (executed flops / MFMA peak, bytes / HBM peak)
     bound = "mfma" if executed / peak >= hbm / PEAK_HBM_GBS else "hbm"
     # HBM traffic of this kernel + launch shape from the rocprofv3 --pmc passes (tools/gpu_pmc.sh), when a
@@ -401,8 +414,9 @@ def roofline_leg(trainer, precision):
                       "useful_vs_f32_mfma_peak": round(useful / PEAK_F32_MFMA_TFLOPS, 4)},
                 hbm={"algorithmic_gbs": round(hbm, 1), "peak_gbs": PEAK_HBM_GBS, "frac": round(hbm / PEAK_HBM_GBS, 4)},
                 traffic=traffic, traffic_source=tsrc, traffic_recorded_at=(_profiles_commit() if traffic else None),
-                traffic_ratio=(round(traffic / best[2], 3) if traffic else None),
-                algorithmic_flops_per_launch=best[1], algorithmic_bytes_per_launch=best[2])
+                traffic_ratio=(round(traffic / mean_bytes, 3) if traffic else None),
+                algorithmic_flops_per_launch=mean_flops, algorithmic_bytes_per_launch=mean_bytes,
+                launch_kinds=launch_kinds)
     # legs the north star names: live per-launch HIP-event time of this step + the HBM bytes / matrix-pipe busy cycles
     # of the same kernel symbol from the rocprofv3 --pmc passes on file (profiles/pmc_step.json: FETCH_SIZE doubled
     # for gfx950, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES in separate passes -- tools/gpu_measure.sh, tools/pmc_to_json.py)

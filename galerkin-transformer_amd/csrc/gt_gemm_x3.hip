@@ -1582,15 +1582,18 @@ __global__ __launch_bounds__(256, 3) void gemm_x3w_kernel(const GemmP p) {
     __shared__ float red[1][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
-    int tile;
-    {
-        const int tiles = gridDim.x, q = tiles >> 3, r = tiles & 7;
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
+    // 1-D grid, 8 * ceil(n_split / 8) * tiles blocks.  Workgroups go to the eight XCDs round-robin: XCD x owns the K chunks
+    // [x spx, (x + 1) spx), and the 2 - 3 output tiles of ONE chunk are consecutive workgroups of that XCD -- they stream the
+    // same rows of the narrower operand at the same time, so its second (third) reader is served by the XCD's L2 (the
+    // follower's loads are hits, it catches up with the leader: the pair stays in step).  With tile = blockIdx.x and
+    // chunk = blockIdx.y the tiles of a chunk sat on DIFFERENT XCDs and the counters showed the operand fetched once per tile
+    // (485 MB for 363 MB of operands at [128 x 256], 727 MB for 484 MB at [384 x 128]; profiles/r05_pmc_step_summary.txt).
+    const int tiles = p.tiles_m * p.tiles_n, spx = (p.n_split + 7) >> 3;
+    const int s = blockIdx.x >> 3, by = (blockIdx.x & 7) * spx + s / tiles, tile = s % tiles;
+    if (by >= p.n_split) return;
     const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
     const int m0 = tm * 128, n0 = tn * 128;
-    const int by = blockIdx.y, kbeg = by * p.k_chunk, kend = min(p.K, kbeg + p.k_chunk);
+    const int kbeg = by * p.k_chunk, kend = min(p.K, kbeg + p.k_chunk);
     const bool do_acs = p.acs != nullptr && tn == 0;
 
     // staging role: waves 0, 1 stage the A tile, waves 2, 3 the B tile; a thread owns rows 4 r4 .. 4 r4 + 3 of its tile and the
@@ -1855,7 +1858,8 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
         return 0;
     }
     if (p.wg_f16) {                                // GT_PREC_F16X2 weight gradient (x3w_ok said yes)
-        hipLaunchKernelGGL(gemm_x3w_kernel, grid, dim3(256), 0, st, p);
+        const dim3 g1(8u * ((split + 7) / 8) * tiles);                 // chunk-major within an XCD (see the kernel)
+        hipLaunchKernelGGL(gemm_x3w_kernel, g1, dim3(256), 0, st, p);
         GT_LAUNCH_CHECK();
         return 0;
     }

@@ -63,8 +63,8 @@ def main():
     xg = torch.randn(2, 140, 64, generator=g2)
     pg = torch.rand(2, 140, 2, generator=g2)
     maskg = (torch.rand(2, 4, 18, 18, generator=g2) >= 0.5).float() * 2.0
-    record("corner_enc_galerkin_gelu", layer, dict(x=xg, pos=pg), lambda m, x, pos: m(x, pos),
-           dict(kind="encoder_layer", B=2, n=140, **kwg), ctl, masks=[maskg])
+    record("corner_enc_galerkin_gelu", layer, dict(x=xg), lambda m, x, pos: m(x, pos),
+           dict(kind="encoder_layer", B=2, n=140, **kwg), ctl, masks=[maskg], const_inputs=dict(pos=pg))
 
     def cat_freq(out, ft):
         ft = ft.detach()

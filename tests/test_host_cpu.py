@@ -284,3 +284,26 @@ def test_scaler_chain_eligibility_mirrors_the_segment_kernels_cpu():
     assert ok(128, (150, 150)) and not ok(128, (240, 240))       # 2 (no - 1)/(ni - 1) + 2 <= 6  <=>  no <= 155 from 78
     assert ok(128, 0.555) and not ok(128, 3.5)
     assert not ok(128, (43, 43), B=2)                            # below the token-row size of the narrow implicit GEMMs
+
+
+def test_roofline_legs_name_kernels_of_the_counter_passes_cpu():
+    """bench.py's `roofline.legs` look their HBM bytes up by kernel symbol in profiles/pmc_step.json: a leg whose symbol is
+    not in that file silently loses its counters (VERDICT r2 and r3 both found one).  Every leg the committed bench line
+    reports must resolve, in the arithmetic that line ran in, and must carry the counters; the dominant kernel's launch
+    geometry must be on file too (`roofline.traffic`)."""
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "pmc_step.json")) as f:
+        pmc = json.load(f)
+    with open(os.path.join(root, "profiles", "r05_bench.json")) as f:
+        line = json.loads(f.read().strip().splitlines()[0])
+    pk = "gemm_x3h_kernel" if line["config"]["precision"] == "f16x2" else "gemm_x3p_kernel"
+    sym = {label: s.replace("gemm_x3p_kernel", pk) for label, _, s in bench.LEGS}
+    legs = line["roofline"]["legs"]
+    assert len(legs) >= 8, sorted(legs)
+    for label, leg in legs.items():
+        assert label in sym, label
+        assert sym[label] in pmc, (label, sym[label])
+        assert "hbm_bytes_per_launch" in leg and leg["hbm_bytes_per_launch"] > 0, label
+    assert line["roofline"]["traffic"], "no counter record for the dominant kernel's launch geometry"
+    assert line["roofline"]["kernel"] in pmc

@@ -3,7 +3,7 @@
 #   suite   the whole -m gpu suite (default arithmetic)          full    tests/test_fullsize_models_gpu.py (C3 / C4 / C5 at full size)
 #   bench   the default bench.py line (+ per-kernel table)        prof    rocprofv3 kernel stats of the steady step, one stream, by grid
 #   pmc     FETCH_SIZE / WRITE_SIZE / SQ passes -> pmc_step.json   sweep   batch sweep        work   the informational workloads
-#   mode:<p> short bench in arithmetic <p>
+#   mode:<p> short bench in arithmetic <p>      quick:<-k expr> kernel/module tests matching      fetch   FETCH_SIZE pass only
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r05}; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O
@@ -20,6 +20,15 @@ for step in "$@"; do
           cp gpurun_out/parity_whole_model_full_*.json $O/ 2>/dev/null;;
     bench) ( time timeout 1500 python bench.py --table $O/bench_table.json 2>$O/bench.err | tail -1 ) > $O/bench.json 2>$O/bench.time
            python -c "import json;r=json.loads(open('$O/bench.json').read().strip().splitlines()[0]);print('bench',r['value'],r['ms_per_step'],'roofline',r['roofline']['kernel'],r['roofline']['avg_launch_us'],r['roofline']['frac'],'cpu',r['cpu_baseline']['value'],'acc',r['accuracy']['hip']['val_rel_l2_mean'],r['accuracy']['welch_t_test'])";;
+    quick) ( time timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_modules_gpu.py -q -k "$arg" ) > $O/quick.log 2>&1; grep -E "passed|failed|^FAILED|^E  " $O/quick.log | cut -c1-250 | tail -12;;
+    fetch)
+      cd /tmp
+      timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc/FETCH_SIZE -o pmc --output-format csv -- \
+          python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-f32-leg --no-accuracy > $O/pmc_FETCH_SIZE.log 2>&1
+      cd $R
+      python tools/pmc_summary.py $O/pmc 60 > $O/fetch_summary.txt 2>&1
+      rm -rf $O/pmc
+      grep -E "x3w|x3h|x3r" $O/fetch_summary.txt | cut -c1-170;;
     mode) ( timeout 400 python bench.py $BENCH_FAST --precision $arg 2>$O/bench_$arg.err | tail -1 ) > $O/bench_prec_$arg.json
           python -c "import json;r=json.load(open('$O/bench_prec_$arg.json'));print('precision $arg',r['value'],r['ms_per_step'])";;
     prof)
