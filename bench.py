@@ -460,7 +460,7 @@ LEGS = (("qkv_proj+headnorm_fwd", "gemm_x3p_kernel<0, 32, 0, 128>", "gt::gemm_x3
         ("conv3x3_implicit", "gemm_x3p_kernel<0, 0, 1, 128>", "gt::gemm_x3p_kernel<0, 0, 1, 128>"),
         ("conv3x3_implicit_narrow(down-scaler)", "gemm_x3p_kernel<0, 0, 1, 64>", "gt::gemm_x3p_kernel<0, 0, 1, 64>"),
         ("conv3x3_wgrad(LDS planes)", "gt_conv3x3_wgrad_nhwc", "gt::convw_kernel<4, 2, 1>"),
-        ("weight_gradients(f16x2 planes in LDS)", "gemm_x3w_kernel+splitk", "gt::gemm_x3w_kernel"),
+        ("weight_gradients(f16x2 planes in LDS)", "gemm_x3w_kernel<2>+splitk", "gt::gemm_x3w_kernel<2>"),
         ("weight_gradients(ring)", "gemm_x3r_kernel<1, 1, 3, 3, 0, 0>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 0>"))
 
 

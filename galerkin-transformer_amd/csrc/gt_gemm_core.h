@@ -33,6 +33,7 @@ struct GemmP {
     int cv_H, cv_W, cv_C, cv_wgrad;  // implicit 3x3 convolution (gt_hip.h: cv_*), cv_C = 0: plain GEMM
     const void* Bp; int bp_NT, bp_KS, bp_f16; // packed-B kernel (gt_gemm_x3.hip): bf16 (fp16: bp_f16) planes of B in fragment order
     int wg_f16;                              // gemm_x3w_kernel: the GT_PREC_F16X2 token-contracted weight gradient
+    int x3w_map;                             // gemm_x3w_kernel: 1 = 1-D grid, chunk-major inside an XCD (set by x3_launch)
 };
 
 // ---- global -> registers: 4 consecutive elements of the operand tile -----------------------

@@ -1577,20 +1577,36 @@ __global__ __launch_bounds__(256, 3) void gemm_x3h_kernel(const GemmP p) {
 constexpr int X3W_KG = 4;                            // k-groups (8 tokens) per stage
 constexpr int X3W_PLANE = X3W_KG * 128 * 16;         // bytes of one plane of one operand tile: 8 KB
 
-__global__ __launch_bounds__(256, 3) void gemm_x3w_kernel(const GemmP p) {
+// PF = stages of raw operand values a thread keeps in flight (registers).  With PF = 1 the next stage was requested after the
+// current one had been split, i.e. its latency was covered by 24 MFMAs only (~0.3 us against >= 2 us under load): every
+// stage paid most of a memory round trip, and the launch time did not move when the counters showed a quarter less traffic
+// (profiles/r05_x3w_prefetch.json).  PF = 2: the request for stage s + 2 is issued when stage s has been split, a full
+// stage of split + MFMA work earlier; 32 more registers (180: two blocks per CU instead of three, four stages per CU in
+// flight instead of three).
+template <int PF>
+__global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * X3W_PLANE];      // A planes 0 / 1, B planes 0 / 1
     __shared__ float red[1][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
-    // 1-D grid, 8 * ceil(n_split / 8) * tiles blocks.  Workgroups go to the eight XCDs round-robin: XCD x owns the K chunks
-    // [x spx, (x + 1) spx), and the 2 - 3 output tiles of ONE chunk are consecutive workgroups of that XCD -- they stream the
-    // same rows of the narrower operand at the same time, so its second (third) reader is served by the XCD's L2 (the
-    // follower's loads are hits, it catches up with the leader: the pair stays in step).  With tile = blockIdx.x and
-    // chunk = blockIdx.y the tiles of a chunk sat on DIFFERENT XCDs and the counters showed the operand fetched once per tile
-    // (485 MB for 363 MB of operands at [128 x 256], 727 MB for 484 MB at [384 x 128]; profiles/r05_pmc_step_summary.txt).
-    const int tiles = p.tiles_m * p.tiles_n, spx = (p.n_split + 7) >> 3;
-    const int s = blockIdx.x >> 3, by = (blockIdx.x & 7) * spx + s / tiles, tile = s % tiles;
-    if (by >= p.n_split) return;
+    int tile, by;
+    if (p.x3w_map) {
+        // 1-D grid, 8 * ceil(n_split / 8) * tiles blocks.  Workgroups go to the eight XCDs round-robin: XCD x owns the K
+        // chunks [x spx, (x + 1) spx), and the 2 - 3 output tiles of ONE chunk are consecutive workgroups of that XCD -- they
+        // stream the same rows of the narrower operand at the same time, so its second (third) reader is served by the XCD's
+        // L2.  With tile = blockIdx.x and chunk = blockIdx.y the tiles of a chunk sit on DIFFERENT XCDs and the counters show
+        // the operand fetched once per tile (485 -> 364 MB at [128 x 256], 727 -> 498 MB at [384 x 128]).
+        const int tiles = p.tiles_m * p.tiles_n, spx = (p.n_split + 7) >> 3;
+        const int s = blockIdx.x >> 3;
+        by = (blockIdx.x & 7) * spx + s / tiles;
+        tile = s % tiles;
+        if (by >= p.n_split) return;
+    } else {
+        const int tiles = gridDim.x, q = tiles >> 3, r = tiles & 7;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+        by = blockIdx.y;
+    }
     const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
     const int m0 = tm * 128, n0 = tn * 128;
     const int kbeg = by * p.k_chunk, kend = min(p.K, kbeg + p.k_chunk);
@@ -1603,8 +1619,7 @@ __global__ __launch_bounds__(256, 3) void gemm_x3w_kernel(const GemmP p) {
     const int st = tid & 127, r4 = st & 31, kg = st >> 5;
     const float* Op = isB ? p.B + n0 + 4 * r4 : p.A + m0 + 4 * r4;
     const int64_t ldo = isB ? p.ldb : p.lda;
-    f32x4 v[8];
-    auto fetch = [&](int k0) {
+    auto fetch = [&](f32x4 (&v)[8], int k0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + 8 * kg + e;
@@ -1621,8 +1636,8 @@ __global__ __launch_bounds__(256, 3) void gemm_x3w_kernel(const GemmP p) {
     int ea = X3H_E0, eb = X3H_E0;                      // block-uniform running exponents of the two operands
     float asum[4] = {0.f, 0.f, 0.f, 0.f};
 
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    // one stage: the 32 tokens [k0, k0 + 32) whose values are in v; afterwards v holds the stage PF x 32 tokens further on
+    auto stage = [&](f32x4 (&v)[8], int k0) {
         // amax of the stage (the values are in registers), per operand over its two waves
         float mx = 0.f;
 #pragma unroll
@@ -1661,7 +1676,7 @@ __global__ __launch_bounds__(256, 3) void gemm_x3w_kernel(const GemmP p) {
             for (int pl = 0; pl < 2; ++pl)
                 *reinterpret_cast<u32x4*>(planes + pl * X3W_PLANE + off) = u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
         }
-        if (k0 + 32 < kend) fetch(k0 + 32);           // the next stage's values travel under this stage's MFMAs
+        if (k0 + 32 * PF < kend) fetch(v, k0 + 32 * PF);   // the values of stage s + PF travel under PF stages of work
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {               // two MFMA k-steps of 16 tokens
@@ -1685,6 +1700,20 @@ __global__ __launch_bounds__(256, 3) void gemm_x3w_kernel(const GemmP p) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) acc[i][j] = mfma32h(bn[j][pb], am[i][pa], acc[i][j]);
                 }
+        }
+    };
+
+    if (PF == 1) {
+        f32x4 v[8];
+        if (kbeg < kend) fetch(v, kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += 32) stage(v, k0);
+    } else {
+        f32x4 v0[8], v1[8];
+        if (kbeg < kend) fetch(v0, kbeg);
+        if (kbeg + 32 < kend) fetch(v1, kbeg + 32);
+        for (int k0 = kbeg; k0 < kend; k0 += 64) {
+            stage(v0, k0);
+            if (k0 + 32 < kend) stage(v1, k0 + 32);    // block-uniform
         }
     }
 
@@ -1716,6 +1745,11 @@ __global__ __launch_bounds__(256, 3) void gemm_x3w_kernel(const GemmP p) {
                         f32x4{acc[i][j][4 * g] * us, -acc[i][j][4 * g + 1] * us, acc[i][j][4 * g + 2] * us, -acc[i][j][4 * g + 3] * us};
             }
     }
+}
+
+static int x3w_prefetch() {                          // GT_X3W_PF = 1: the single-stage prefetch, for A/B runs
+    static const int pf = [] { const char* e = getenv("GT_X3W_PF"); return e && atoi(e) == 1 ? 1 : 2; }();
+    return pf;
 }
 
 // the launches gemm_x3w_kernel takes: GT_PREC_F16X2, both operands x-contiguous and 16-byte aligned, whole 128 x 128 tiles,
@@ -1858,8 +1892,13 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
         return 0;
     }
     if (p.wg_f16) {                                // GT_PREC_F16X2 weight gradient (x3w_ok said yes)
-        const dim3 g1(8u * ((split + 7) / 8) * tiles);                 // chunk-major within an XCD (see the kernel)
-        hipLaunchKernelGGL(gemm_x3w_kernel, g1, dim3(256), 0, st, p);
+        const int pf = x3w_prefetch();
+        static const int map = [] { const char* e = getenv("GT_X3W_MAP"); return e ? atoi(e) : 2; }();
+        GemmP q = p;                                   // map 0: tile-major grid; 1: chunk-major within an XCD; 2: that for two tiles
+        q.x3w_map = map == 1 || (map == 2 && tiles == 2);
+        const dim3 g1 = q.x3w_map ? dim3(8u * ((split + 7) / 8) * tiles) : grid;
+        if (pf == 1) hipLaunchKernelGGL(gemm_x3w_kernel<1>, g1, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL(gemm_x3w_kernel<2>, g1, dim3(256), 0, st, q);
         GT_LAUNCH_CHECK();
         return 0;
     }
@@ -1918,7 +1957,7 @@ const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int plane
         return buf;
     }
     if (p.wg_f16) {
-        snprintf(buf, sizeof(buf), "gt::gemm_x3w_kernel(gt::GemmP)");
+        snprintf(buf, sizeof(buf), "void gt::gemm_x3w_kernel<%d>(gt::GemmP)", x3w_prefetch());
         return buf;
     }
     if (p.cv_C > 0 && p.cv_wgrad)
