@@ -73,6 +73,7 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="also build the GEMM ablation variants")
     ap.add_argument("--ablate-x3", action="store_true", help="also build the split-operand GEMM ablation variants")
+    ap.add_argument("--ablate-head", action="store_true", help="also build the head_bwd16_kernel timing ablations")
     ap.add_argument("-v", "--verbose", action="store_true")
     a = ap.parse_args()
     print(build(False, a.verbose, a.force))
@@ -83,6 +84,9 @@ if __name__ == "__main__":
                      ("_x3nosplitb", ["GT_ABL_X3_NOSPLIT_B"]), ("_x3nostore", ["GT_ABL_X3_NOSTORE"]),
                      ("_x3onlyload", ["GT_ABL_X3_NOMFMA", "GT_ABL_X3_NOSPLIT_A", "GT_ABL_X3_NOSPLIT_B", "GT_ABL_X3_NOSTORE"])):
             print(build(False, a.verbose, a.force, tag=t, defines=d, only=["gt_gemm_x3.hip"]))
+    if a.ablate_head:
+        for m in (1, 2, 3, 4, 8, 16, 31):
+            print(build(False, a.verbose, a.force, tag=f"_h16abl{m}", defines=[f"H16_ABL={m}"], only=["gt_head.hip"]))
     if a.ablate:
         for t, d in (("_nomfma", ["GT_ABL_NOMFMA"]), ("_noload", ["GT_ABL_NOLOAD"]),
                      ("_nostore", ["GT_ABL_NOSTORE"]), ("_onlymfma", ["GT_ABL_NOLOAD", "GT_ABL_NOSTORE"])):

@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 16          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 17          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -106,10 +106,10 @@ _PROTOS = {
     "gt_dropact_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(GtDropout), C.c_int32,
                                  C.POINTER(GtDropout), C.c_int32, C.c_void_p]),
     "gt_mlp_head_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 4 +
-                        [C.c_int32, C.c_void_p, C.c_void_p]),
+                        [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gt_mlp_head_bwd_ws_bytes": (C.c_int64, [C.c_int64]),
     "gt_mlp_head_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 3 +
-                        [C.c_int32] + [C.c_void_p] * 7 + [C.c_int64, C.c_void_p]),
+                        [C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_int64, C.c_void_p]),
     "gt_dft_analysis": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p]),
     "gt_dft_synthesis": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                                                      C.c_int32, C.c_void_p, C.c_void_p]),
@@ -308,7 +308,7 @@ def get_precision() -> str:
 # Classes of a gt_gemm launch:  "hn" QKV projection with the head-norm epilogue * "conv" implicit 3x3 convolution
 # (forward / data gradient) * "convw" its weight gradient * "wgrad" token-contracted weight gradients (both operands
 # x-contiguous, unbatched) * "batched" per-sample products (Q'P, dP^T, the dQ block) * "tok" every other token-row
-# product.  A class named here overrides both the module mode and a launch's own `precision=` argument.
+# product * "head" the fused regression head (gt_mlp_head_*).  A class named here overrides both the module mode and a launch's own `precision=` argument.
 # GT_PREC_CLASS="wgrad=f32,tok=f32" sets it from the environment.
 _prec_class = {}
 
@@ -318,7 +318,7 @@ def set_precision_classes(classes: Optional[dict]):
     old = dict(_prec_class)
     _prec_class.clear()
     for k, v in (classes or {}).items():
-        if k not in ("hn", "conv", "convw", "wgrad", "batched", "tok") or v not in PREC_CODE:
+        if k not in ("hn", "conv", "convw", "wgrad", "batched", "tok", "head") or v not in PREC_CODE:
             raise ValueError(f"set_precision_classes: bad entry {k}={v}")
         _prec_class[k] = v
     return old
@@ -969,26 +969,36 @@ def mlp_head_supported(K: int, N: int, n_out: int) -> bool:
     return K == 32 and N == 128 and n_out == 1
 
 
-def mlp_head_fwd(x2, w1, b1, w2, b2, act: int, out):
+def head_precision(precision: Optional[str] = None) -> int:
+    """Arithmetic code of a gt_mlp_head_* launch: the "head" class override, else `precision`, else the module mode."""
+    if "head" in _prec_class:
+        return PREC_CODE[_prec_class["head"]]
+    return _precision[0] if precision is None else PREC_CODE[precision]
+
+
+def mlp_head_fwd(x2, w1, b1, w2, b2, act: int, out, precision: Optional[str] = None):
+    """precision f16x2: the two-term fp16 kernels; anything else: the fp32-MFMA kernels (gt_hip.h)."""
     need_f32_cuda(x2, w1, b1, w2, b2, out)
     T, K = x2.shape
     N, no = w1.shape[0], w2.shape[0]
+    prec = head_precision(precision)
     check(_timed("gt_mlp_head_fwd", 2.0 * T * N * (K + no), 4.0 * T * (K + no),
                  lambda: lib().gt_mlp_head_fwd(x2.data_ptr(), T, K, N, no, w1.data_ptr(), ptr(b1), w2.data_ptr(), ptr(b2),
-                                               act, out.data_ptr(), stream_ptr()), shape=(T, K, N, no)),
+                                               act, prec, out.data_ptr(), stream_ptr()), shape=(T, K, N, no)),
           "gt_mlp_head_fwd")
     return out
 
 
-def mlp_head_bwd(x2, w1, b1, w2, act: int, g, dx, dw1, db1, dw2, db2):
+def mlp_head_bwd(x2, w1, b1, w2, act: int, g, dx, dw1, db1, dw2, db2, precision: Optional[str] = None):
     need_f32_cuda(x2, w1, b1, w2, g, dx, dw1, db1, dw2, db2)
     T, K = x2.shape
     N, no = w1.shape[0], w2.shape[0]
+    prec = head_precision(precision)
     need = lib().gt_mlp_head_bwd_ws_bytes(T)
     ws = workspace(x2.device, need)
     check(_timed("gt_mlp_head_bwd", 2.0 * T * N * (3 * K + 2 * no), 4.0 * T * (2 * K + no),
                  lambda: lib().gt_mlp_head_bwd(x2.data_ptr(), T, K, N, no, w1.data_ptr(), ptr(b1), w2.data_ptr(), act,
-                                               g.data_ptr(), ptr(dx), dw1.data_ptr(), ptr(db1), ptr(dw2), ptr(db2),
+                                               prec, g.data_ptr(), ptr(dx), dw1.data_ptr(), ptr(db1), ptr(dw2), ptr(db2),
                                                ws.data_ptr(), ws.numel(), stream_ptr()), shape=(T, K, N, no)),
           "gt_mlp_head_bwd")
 

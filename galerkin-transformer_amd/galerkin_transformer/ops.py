@@ -650,8 +650,9 @@ class MlpHeadFn(Function):
         T = x2.shape[0]
         w1c, w2c = _c(w1), _c(w2)
         out = torch.empty(T, no, dtype=torch.float32, device=x.device)
+        ctx.prec = H.get_precision()              # the backward runs in the arithmetic of the forward
         if H.mlp_head_supported(K, N, no):       # dedicated one-pass kernel (gt_mlp_head_fwd)
-            H.mlp_head_fwd(x2, w1c, b1, w2c, b2, act, out)
+            H.mlp_head_fwd(x2, w1c, b1, w2c, b2, act, out, precision=ctx.prec)
         else:
             H.gemm(x2, w1c, None, T, N, K, lda=K, ldb=K, ldc=N, bias=b1, act=act, ep_mode=H.EP_ROWDOT, w2=w2c,
                    b2=b2, out2=out)
@@ -671,7 +672,7 @@ class MlpHeadFn(Function):
             dw1, dw2 = torch.empty(N, K, **f32), torch.empty(no, N, **f32)
             db1 = torch.empty(N, **f32) if hb1 else None
             db2 = torch.empty(no, **f32) if hb2 else None
-            H.mlp_head_bwd(x2, w1c, b1, w2c, act, g, dx, dw1, db1, dw2, db2)
+            H.mlp_head_bwd(x2, w1c, b1, w2c, act, g, dx, dw1, db1, dw2, db2, precision=ctx.prec)
             return (dx.reshape(xshape) if dx is not None else None), dw1, db1, dw2, db2, None
         dh, dw2 = torch.empty(T, N, **f32), torch.empty(no, N, **f32)
         H.gemm(x2, w1c, dh, T, N, K, lda=K, ldb=K, ldc=N, bias=b1, act=act, ep_mode=H.EP_MLP_BWD, w2=w2c, g2=g,

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 16
+#define GT_ABI_VERSION 17
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -363,13 +363,16 @@ int gt_dft_synthesis(const float* F, const float* Z, float* Y, int32_t nb, int32
  *     db2 [n_out] (each may be NULL); ws >= gt_mlp_head_bwd_ws_bytes(T) bytes of scratch (deterministic
  *     fixed-order reduction).  Implemented for K = 32, N = 128, n_out = 1 (else GT_ENOTSUP: use gt_gemm's
  *     ep_mode GT_EP_ROWDOT / GT_EP_MLP_BWD path, which covers N <= 128, n_out <= 4).
+ *     precision: GT_PREC_F16X2 = two fp16 terms per operand, three products on the fp16 matrix pipe (per-row / per-tensor
+ *     / running power-of-two exponents, gt_head.hip); any other GT_PREC_* = the fp32-MFMA kernels (exact fp32 products).
  * ------------------------------------------------------------------------------------------- */
 int gt_mlp_head_fwd(const float* X, int64_t T, int32_t K, int32_t N, int32_t n_out, const float* W1,
-                    const float* b1, const float* w2, const float* b2, int32_t act, float* out, void* stream);
+                    const float* b1, const float* w2, const float* b2, int32_t act, int32_t precision, float* out,
+                    void* stream);
 int64_t gt_mlp_head_bwd_ws_bytes(int64_t T);
 int gt_mlp_head_bwd(const float* X, int64_t T, int32_t K, int32_t N, int32_t n_out, const float* W1,
-                    const float* b1, const float* w2, int32_t act, const float* g, float* dX, float* dW1,
-                    float* db1, float* dw2, float* db2, void* ws, int64_t ws_bytes, void* stream);
+                    const float* b1, const float* w2, int32_t act, int32_t precision, const float* g, float* dX,
+                    float* dW1, float* db1, float* dw2, float* db2, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row LayerNorm over the feature axis (model.py:128-129,134-135 when layer_norm=True).

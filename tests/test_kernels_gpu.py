@@ -679,6 +679,56 @@ def test_mlp_head_dedicated_kernels_without_optional_outputs(H, gpu_device):
     assert rel_l2(dw2, gw2) < 5e-6
 
 
+@pytest.mark.parametrize("act", ["silu", "relu"])
+@pytest.mark.parametrize("prec", ["f16x2", "f32"])
+def test_mlp_head_dynamic_range_and_arithmetic(H, gpu_device, act, prec):
+    """gt_mlp_head_* in both arithmetics (f16x2: two fp16 terms per operand with per-row / per-tensor / running exponents,
+    gt_head.hip; f32: the fp32-MFMA kernels) on data built to stress the fp16 exponents: row magnitudes of x spanning 1e-3 ..
+    1e3, all-zero rows, gradients of 1e-9 next to gradients of 1, rows without gradient, T not a multiple of 32.  Every
+    output against fp64; dX additionally ROW BY ROW (a per-row exponent must keep the rows with tiny gradients exact)."""
+    import torch.nn.functional as F
+    dev = gpu_device
+    T = 4099
+    g_ = torch.Generator().manual_seed(321)
+    x = torch.randn(T, 32, generator=g_) * torch.logspace(-3, 3, T).unsqueeze(1)[torch.randperm(T, generator=g_)]
+    x[100:140] = 0.0
+    w1 = torch.randn(128, 32, generator=g_) * 0.05
+    w1[7] *= 1e-4                                                   # a hidden unit far below the tensor's scale
+    b1 = torch.randn(128, generator=g_) * 0.5
+    w2 = torch.randn(1, 128, generator=g_) * 0.3
+    b2 = torch.randn(1, generator=g_)
+    cot = torch.randn(T, 1, generator=g_)
+    cot[: T // 2] *= 1e-9
+    cot[2000:2100] = 0.0
+    fn = F.silu if act == "silu" else torch.relu
+    xd, w1d, b1d, w2d, b2d = (t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2))
+    ref = F.linear(fn(F.linear(xd, w1d, b1d)), w2d, b2d)
+    grads = torch.autograd.grad(ref, (xd, w1d, b1d, w2d, b2d), cot.double())
+    xg, w1g, b1g, w2g, b2g, cg = (t.to(dev) for t in (x, w1, b1, w2, b2, cot))
+    code = H.ACT_CODE[act]
+    out = torch.full((T, 1), float("nan"), device=dev)
+    H.mlp_head_fwd(xg, w1g, b1g, w2g, b2g, code, out, precision=prec)
+    assert rel_l2(out, ref) < KTOL
+    res = []
+    for _ in range(2):
+        dx = torch.full((T, 32), float("nan"), device=dev)
+        dw1, db1 = torch.full((128, 32), float("nan"), device=dev), torch.full((128,), float("nan"), device=dev)
+        dw2, db2 = torch.full((1, 128), float("nan"), device=dev), torch.full((1,), float("nan"), device=dev)
+        H.mlp_head_bwd(xg, w1g, b1g, w2g, code, cg, dx, dw1, db1, dw2, db2, precision=prec)
+        torch.cuda.synchronize()
+        res.append((dx, dw1, db1, dw2, db2))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)                                    # fixed-order reductions: bitwise repeatable
+    for got, want, name in zip(res[0], grads, ("dx", "dw1", "db1", "dw2", "db2")):
+        assert rel_l2(got, want) < 5e-6, (name, rel_l2(got, want))
+    dxr, dxw = res[0][0].double().cpu(), grads[0]
+    nrm = dxw.norm(dim=1)
+    rows = nrm > 0
+    err = ((dxr - dxw).norm(dim=1)[rows] / nrm[rows]).max().item()
+    assert err < 2e-5, err
+    assert float(dxr[~rows].abs().max()) == 0.0
+
+
 def test_gemm_tall_skinny_wgrad_into_column_slice(H, gpu_device):
     """The tsmm path writes through ldc (the grid columns of SpectralRegressor.fc's weight gradient are a column
     slice of the [N, K + p] weight) and leaves the other columns alone."""
