@@ -462,6 +462,12 @@ struct ConvResizeP {
     DropDev drop;
     int y_nhwc;                                        // y (and g) channels-last [B, Ho, Wo, Cout] instead of channels-first
     int nstrips;                                       // bwd, channels-last: pixel strips per image (1-D grid, see kernel)
+    // channels-last only, optional: the forward's decisions, 4 bits per (output pixel, channel) -- bit t: source pixel t of
+    // the bilinear stencil was kept by the dropout AND positive; all four cleared when the resized value itself is <= 0 (its
+    // gradient is zero then).  [B][Cout / 16][Ho * Wo] 64-bit words (a wave's 64 pixels are 512 contiguous bytes for the
+    // writer and for the reader), nibble c % 16 of word c / 16.  With it the backward neither re-evaluates the convolution
+    // nor re-draws the dropout mask, and does not read y.
+    unsigned long long* bits;
 };
 
 __device__ __forceinline__ void load_patch(const float* __restrict__ xp, int H, int W, int iy, int ix,
@@ -531,10 +537,12 @@ __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP 
     }
     const uint32_t plane = (uint32_t)(p.H * p.W);
     const float w00 = ay.l0 * ax.l0, w01 = ay.l0 * ax.l1, w10 = ay.l1 * ax.l0, w11 = ay.l1 * ax.l1;
+    unsigned long long nib = 0ull;                  // p.bits: the decisions of this pixel's CR_CH = 16 channels
 #pragma unroll 1
     for (int j4 = 0; j4 < CR_CH; j4 += 4) {
         if (c0 + j4 >= p.Cout) break;
         float r4[4];
+        unsigned n16 = 0u;                          // the four channels' nibbles
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int j = j4 + jj, c = c0 + j;
@@ -556,7 +564,10 @@ __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP 
             }
             // same association as the stand-alone resize: l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
             r4[jj] = fmaxf(ay.l0 * (ax.l0 * cv[0] + ax.l1 * cv[1]) + ay.l1 * (ax.l0 * cv[2] + ax.l1 * cv[3]), 0.f);
+            const unsigned d4 = (cv[0] > 0.f ? 1u : 0u) | (cv[1] > 0.f ? 2u : 0u) | (cv[2] > 0.f ? 4u : 0u) | (cv[3] > 0.f ? 8u : 0u);
+            n16 |= (r4[jj] > 0.f ? d4 : 0u) << (4 * jj);
         }
+        nib |= (unsigned long long)n16 << (4 * j4);
         (void)w00; (void)w01; (void)w10; (void)w11;
         const int c = c0 + j4;
         if (p.y_nhwc) {                       // a pixel's four channels: one 16-byte store (Cout % 4 == 0 checked on the host)
@@ -567,7 +578,9 @@ __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP 
                 if (c + jj < p.Cout) p.y[((int64_t)b * p.Cout + c + jj) * p.Ho * p.Wo + e] = r4[jj];
         }
     }
+    if (p.bits) p.bits[((int64_t)b * (p.Cout >> 4) + bc) * (p.Ho * p.Wo) + e] = nib;   // CR_CH == 16: one word per thread
 }
+static_assert(CR_CH == 16, "conv_resize_fwd_kernel packs the decisions of its 16 channels into one 64-bit word");
 
 // Backward: weight gradient only (the fused path is used when the input needs no gradient).
 // Output-side formulation: with R the bilinear operator, G = g .* [y > 0], and D = keep .* [y0 > 0],
@@ -583,9 +596,10 @@ static_assert(CRB_CG % 4 == 0 && CRB_CG >= 4, "the channels-last paths read a pi
 #ifndef GT_CRB_WAVES                               // resident waves per SIMD the one-channel instance is compiled for
 #define GT_CRB_WAVES 2
 #endif
-template <int CIN>
+template <int CIN, bool BITS = false>
 __global__ __launch_bounds__(256, (CIN == 1 ? GT_CRB_WAVES : 1)) void conv_resize_bwd_kernel(const ConvResizeP p) {
-    __shared__ float sw[CRB_CG * CIN * 9];
+    static_assert(!BITS || CRB_CG == 8, "the recorded decisions are read as one 32-bit half word: eight channels per thread");
+    __shared__ float sw[BITS ? 1 : CRB_CG * CIN * 9];
     __shared__ float red[4][CRB_CG * CIN * 9];
     // channels-first: blockIdx = (pixel strip, channel group).  channels-last: a strip's channel groups read the same
     // 512-byte rows of g and y, 32 bytes each: they are put on ONE XCD next to each other (1-D grid, block id % 8 = XCD), so
@@ -605,11 +619,13 @@ __global__ __launch_bounds__(256, (CIN == 1 ? GT_CRB_WAVES : 1)) void conv_resiz
     }
     const int c0 = bc * CRB_CG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < CRB_CG * CIN * 9; i += 256) {
-        const int c = c0 + i / (CIN * 9);
-        sw[i] = (c < p.Cout) ? p.w[(int64_t)c * CIN * 9 + i % (CIN * 9)] : 0.f;
+    if (!BITS) {
+        for (int i = threadIdx.x; i < CRB_CG * CIN * 9; i += 256) {
+            const int c = c0 + i / (CIN * 9);
+            sw[i] = (c < p.Cout) ? p.w[(int64_t)c * CIN * 9 + i % (CIN * 9)] : 0.f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const uint32_t plane = (uint32_t)(p.H * p.W);
     const int oplane = p.Ho * p.Wo;
     const uint32_t key = drop_key_dev(p.drop);
@@ -624,53 +640,98 @@ __global__ __launch_bounds__(256, (CIN == 1 ? GT_CRB_WAVES : 1)) void conv_resiz
         const int e = (bx * CRB_PXT + it) * 256 + threadIdx.x;
         if (e >= oplane) continue;
         const int oy = e / p.Wo, ox = e - oy * p.Wo;
-        const Axis ay = axis_of(oy, p.sy, p.H), ax = axis_of(ox, p.sx, p.W);
+        Axis ay = axis_of(oy, p.sy, p.H), ax = axis_of(ox, p.sx, p.W);
         float pt[CIN][4][9];
         uint32_t toff[4];
+        if (BITS) {
+            // The four 3x3 patches are windows of ONE 4x4 neighbourhood around (i0 - 1, i0 - 1) when i1 = i0 + 1: 16 loads
+            // instead of 36.  At the last row / column i1 = i0: both taps of that axis are the same source pixel (same
+            // patch, same recorded decision), so its weight moves to tap 0 and tap 1 (which would read the window one
+            // further, i.e. something else) gets weight zero.
+            if (ay.i1 == ay.i0) { ay.l0 += ay.l1; ay.l1 = 0.f; }
+            if (ax.i1 == ax.i0) { ax.l0 += ax.l1; ax.l1 = 0.f; }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int iy = (t & 2) ? ay.i1 : ay.i0, ix = (t & 1) ? ax.i1 : ax.i0;
-            toff[t] = (uint32_t)(iy * p.W + ix);
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float* xp = p.x + ((int64_t)b * CIN + ci) * plane;
+                float nb[4][4];
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci)
-                load_patch_clamped(p.x + ((int64_t)b * CIN + ci) * plane, p.H, p.W, iy, ix, pt[ci][t]);
+                for (int r = 0; r < 4; ++r) {
+                    const int yy = ay.i0 - 1 + r, yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int xx = ax.i0 - 1 + q, xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+                        const float v = xp[yc * p.W + xc];
+                        nb[r][q] = (yy == yc && xx == xc) ? v : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) pt[ci][t][dy * 3 + dx] = nb[(t >> 1) + dy][(t & 1) + dx];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int iy = (t & 2) ? ay.i1 : ay.i0, ix = (t & 1) ? ax.i1 : ax.i0;
+                toff[t] = (uint32_t)(iy * p.W + ix);
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci)
+                    load_patch_clamped(p.x + ((int64_t)b * CIN + ci) * plane, p.H, p.W, iy, ix, pt[ci][t]);
+            }
         }
         const float wt[4] = {ay.l0 * ax.l0, ay.l0 * ax.l1, ay.l1 * ax.l0, ay.l1 * ax.l1};
         float gl[CRB_CG], yl[CRB_CG];       // channels-last: the pixel's eight channels are 32 contiguous bytes of g and y
+        uint32_t dec = 0u;                  // BITS: the forward's decisions for these eight channels, 4 bits each
         if (p.y_nhwc) {
             const int64_t o8 = ((int64_t)b * oplane + e) * p.Cout + c0;           // Cout % 8 == 0 checked on the host
 #pragma unroll
             for (int h = 0; h < CRB_CG / 4; ++h) {
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.g + o8 + 4 * h);
-                const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.y + o8 + 4 * h);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { gl[4 * h + t] = g4[t]; yl[4 * h + t] = y4[t]; }
+                for (int t = 0; t < 4; ++t) gl[4 * h + t] = g4[t];
+                if (!BITS) {
+                    const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.y + o8 + 4 * h);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) yl[4 * h + t] = y4[t];
+                }
+            }
+            if (BITS) {
+                const unsigned long long w64 = p.bits[((int64_t)b * (p.Cout >> 4) + (c0 >> 4)) * oplane + e];
+                dec = (c0 & 8) ? (uint32_t)(w64 >> 32) : (uint32_t)w64;
             }
         }
 #pragma unroll          // full unroll: acc[j][..] must be statically indexed to stay in registers
         for (int j = 0; j < CRB_CG; ++j) {
             const int c = min(c0 + j, p.Cout - 1);                 // clamped: tail channels are not stored
             float go;
-            if (p.y_nhwc) go = (yl[j] > 0.f) ? gl[j] : 0.f;
-            else {
-                const int64_t o = ((int64_t)b * p.Cout + c) * oplane + e;
-                go = (p.y[o] > 0.f) ? p.g[o] : 0.f;
-            }
-            float cv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float wv = sw[(j * CIN + ci) * 9 + k];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) cv[t] = fmaf(wv, pt[ci][t][k], cv[t]);
-                }
-            const uint32_t cbase = ((uint32_t)b * (uint32_t)p.Cout + (uint32_t)c) * plane;
             float coef[4];
+            if (BITS) {                     // decisions recorded by the forward (they include [y > 0]): no conv, no mask draw
+                go = gl[j] * p.drop.scale;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
-                coef[t] = (cv[t] * m > 0.f) ? wt[t] * m * go : 0.f;
+                for (int t = 0; t < 4; ++t) coef[t] = (dec & (1u << (4 * j + t))) ? wt[t] * go : 0.f;
+            } else {
+                if (p.y_nhwc) go = (yl[j] > 0.f) ? gl[j] : 0.f;
+                else {
+                    const int64_t o = ((int64_t)b * p.Cout + c) * oplane + e;
+                    go = (p.y[o] > 0.f) ? p.g[o] : 0.f;
+                }
+                float cv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const float wv = sw[(j * CIN + ci) * 9 + k];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) cv[t] = fmaf(wv, pt[ci][t][k], cv[t]);
+                    }
+                const uint32_t cbase = ((uint32_t)b * (uint32_t)p.Cout + (uint32_t)c) * plane;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
+                    coef[t] = (cv[t] * m > 0.f) ? wt[t] * m * go : 0.f;
+                }
             }
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci)
@@ -948,11 +1009,12 @@ static int check_conv_resize(const void* x, const void* w, const void* y, int B,
 
 static int conv_resize_fwd(const float* x, const float* w, float* y, int32_t B, int32_t Cin,
                            int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
-                           const gt_dropout* drop, int32_t act, int y_nhwc, void* stream) {
+                           const gt_dropout* drop, int32_t act, int y_nhwc, void* bits, void* stream) {
     if (int rc = check_conv_resize(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
     if (y_nhwc && ((Cout & 7) || (reinterpret_cast<uintptr_t>(y) & 15))) return GT_ENOTSUP;
+    if (bits && (!y_nhwc || (Cout & 15) || (reinterpret_cast<uintptr_t>(bits) & 7))) return GT_ENOTSUP;
     ConvResizeP p{x, w, y, nullptr, nullptr, B, Cin, Cout, H, W, Ho, Wo, scale_of(H, Ho), scale_of(W, Wo),
-                  make_drop(drop), y_nhwc, 0};
+                  make_drop(drop), y_nhwc, 0, reinterpret_cast<unsigned long long*>(bits)};
     dim3 grid((unsigned)ceil_div((int64_t)Ho * Wo, 256), (unsigned)ceil_div(Cout, CR_CH), (unsigned)B);
     if (y_nhwc) std::swap(grid.x, grid.y);
     hipStream_t st = (hipStream_t)stream;
@@ -975,12 +1037,16 @@ extern "C" int gt_debug_conv0_mask(void* mask, void* stream) {
 extern "C" int gt_conv3x3_resize_fwd(const float* x, const float* w, float* y, int32_t B, int32_t Cin,
                                      int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                                      const gt_dropout* drop, int32_t act, void* stream) {
-    return conv_resize_fwd(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act, 0, stream);
+    return conv_resize_fwd(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act, 0, nullptr, stream);
 }
 extern "C" int gt_conv3x3_resize_fwd_nhwc(const float* x, const float* w, float* y, int32_t B, int32_t Cin,
                                           int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
-                                          const gt_dropout* drop, int32_t act, void* stream) {
-    return conv_resize_fwd(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act, 1, stream);
+                                          const gt_dropout* drop, int32_t act, void* relu_bits, void* stream) {
+    return conv_resize_fwd(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act, 1, relu_bits, stream);
+}
+extern "C" int64_t gt_conv3x3_resize_bits_bytes(int32_t B, int32_t Cout, int32_t Ho, int32_t Wo) {
+    if (B <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 || (Cout & 15)) return 0;
+    return (int64_t)B * Ho * Wo * (Cout / 16) * 8;
 }
 
 extern "C" int64_t gt_conv3x3_resize_bwd_ws_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W) {
@@ -991,15 +1057,18 @@ extern "C" int64_t gt_conv3x3_resize_bwd_ws_bytes(int32_t B, int32_t Cin, int32_
 static int conv_resize_bwd(const float* g, const float* y, const float* x, const float* w, int32_t B,
                            int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                            const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes, int y_nhwc,
-                           void* stream) {
-    if (int rc = check_conv_resize(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
+                           const void* bits, void* stream) {
+    if (bits && (!y_nhwc || (Cout & 15) || CRB_CG != 8 || (reinterpret_cast<uintptr_t>(bits) & 7))) return GT_ENOTSUP;
+    if (int rc = check_conv_resize(x, w, bits ? (const void*)g : (const void*)y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
     if (!g || !dw) return GT_EINVAL;
+    if (bits && !y) y = g;                           // not read (alignment checks below see a valid pointer)
     // channels-last: a block walks whole channel groups of CRB_CG (a build-time constant) as aligned float4s
     if (y_nhwc && ((Cout & 7) || (Cout % CRB_CG) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(g)) & 15)))
         return GT_ENOTSUP;
     if (!ws || ws_bytes < gt_conv3x3_resize_bwd_ws_bytes(B, Cin, Cout, H, W)) return GT_EWS;
     ConvResizeP p{x, w, const_cast<float*>(y), g, reinterpret_cast<float*>(ws), B, Cin, Cout, H, W, Ho, Wo,
-                  scale_of(H, Ho), scale_of(W, Wo), make_drop(drop), y_nhwc, 0};
+                  scale_of(H, Ho), scale_of(W, Wo), make_drop(drop), y_nhwc, 0,
+                  reinterpret_cast<unsigned long long*>(const_cast<void*>(bits))};
     if (ceil_div((int64_t)Ho * Wo, 256 * CRB_PXT) > ceil_div((int64_t)H * W, 256 * CRB_PXT)) return GT_ENOTSUP;
     const int nx = ceil_div((int64_t)Ho * Wo, 256 * CRB_PXT);
     dim3 grid((unsigned)nx, (unsigned)ceil_div(Cout, CRB_CG), (unsigned)B);
@@ -1008,7 +1077,14 @@ static int conv_resize_bwd(const float* g, const float* y, const float* x, const
         grid = dim3((unsigned)(ceil_div(Cout, CRB_CG) * (((int64_t)nx * B + 7) / 8 * 8)), 1u, 1u);
     }
     hipStream_t st = (hipStream_t)stream;
-    switch (Cin) {
+    if (bits) {
+        switch (Cin) {
+            case 1: hipLaunchKernelGGL((conv_resize_bwd_kernel<1, true>), grid, dim3(256), 0, st, p); break;
+            case 2: hipLaunchKernelGGL((conv_resize_bwd_kernel<2, true>), grid, dim3(256), 0, st, p); break;
+            case 3: hipLaunchKernelGGL((conv_resize_bwd_kernel<3, true>), grid, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((conv_resize_bwd_kernel<4, true>), grid, dim3(256), 0, st, p); break;
+        }
+    } else switch (Cin) {
         case 1: hipLaunchKernelGGL(conv_resize_bwd_kernel<1>, grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL(conv_resize_bwd_kernel<2>, grid, dim3(256), 0, st, p); break;
         case 3: hipLaunchKernelGGL(conv_resize_bwd_kernel<3>, grid, dim3(256), 0, st, p); break;
@@ -1023,11 +1099,11 @@ extern "C" int gt_conv3x3_resize_bwd(const float* g, const float* y, const float
                                      int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                                      const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
                                      void* stream) {
-    return conv_resize_bwd(g, y, x, w, B, Cin, Cout, H, W, Ho, Wo, drop, act, dw, ws, ws_bytes, 0, stream);
+    return conv_resize_bwd(g, y, x, w, B, Cin, Cout, H, W, Ho, Wo, drop, act, dw, ws, ws_bytes, 0, nullptr, stream);
 }
 extern "C" int gt_conv3x3_resize_bwd_nhwc(const float* g, const float* y, const float* x, const float* w, int32_t B,
                                           int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
-                                          const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
-                                          void* stream) {
-    return conv_resize_bwd(g, y, x, w, B, Cin, Cout, H, W, Ho, Wo, drop, act, dw, ws, ws_bytes, 1, stream);
+                                          const gt_dropout* drop, int32_t act, const void* relu_bits, float* dw,
+                                          void* ws, int64_t ws_bytes, void* stream) {
+    return conv_resize_bwd(g, y, x, w, B, Cin, Cout, H, W, Ho, Wo, drop, act, dw, ws, ws_bytes, 1, relu_bits, stream);
 }

@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 17          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 18          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -139,10 +139,11 @@ _PROTOS = {
                                                                           C.c_void_p]),
     "gt_conv3x3_resize_bwd_ws_bytes": (C.c_int64, [C.c_int32] * 5),
     "gt_conv3x3_resize_fwd_nhwc": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.POINTER(GtDropout), C.c_int32,
-                                                                               C.c_void_p]),
+                                                                               C.c_void_p, C.c_void_p]),
     "gt_conv3x3_resize_bwd_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 7 + [C.POINTER(GtDropout), C.c_int32,
-                                                                               C.c_void_p, C.c_void_p, C.c_int64,
-                                                                               C.c_void_p]),
+                                                                               C.c_void_p, C.c_void_p, C.c_void_p,
+                                                                               C.c_int64, C.c_void_p]),
+    "gt_conv3x3_resize_bits_bytes": (C.c_int64, [C.c_int32] * 4),
     "gt_debug_conv0_mask": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gt_conv3x3_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 5 +
                               [C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -816,20 +817,30 @@ def bilinear2d_bwd(g: torch.Tensor, y_saved: Optional[torch.Tensor], in_size, in
     return dx
 
 
-def conv3x3_resize_fwd(x: torch.Tensor, w: torch.Tensor, size, drop: Optional[GtDropout], out_nhwc: bool = False) -> torch.Tensor:
+def conv3x3_resize_fwd(x: torch.Tensor, w: torch.Tensor, size, drop: Optional[GtDropout], out_nhwc: bool = False,
+                       want_bits: bool = False):
     """relu(resize(relu(dropout(conv3x3(x, w, padding=1))))) -- x [B,Cin,H,W], w [Cout,Cin,3,3] -> [B,Cout,Ho,Wo], or
-    channels-last [B,Ho,Wo,Cout] with ``out_nhwc``."""
+    channels-last [B,Ho,Wo,Cout] with ``out_nhwc``.  want_bits (channels-last, Cout % 16 == 0): also returns the byte buffer
+    of the forward's decisions (gt_hip.h: relu_bits) for conv3x3_resize_bwd -> (y, bits); bits is None when not recorded."""
     need_f32_cuda(x, w)
     B, Cin, Hh, Ww = x.shape
     Cout, Ho, Wo = w.shape[0], int(size[0]), int(size[1])
     y = torch.empty((B, Ho, Wo, Cout) if out_nhwc else (B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
-    fn = lib().gt_conv3x3_resize_fwd_nhwc if out_nhwc else lib().gt_conv3x3_resize_fwd
-    check(_timed("gt_conv3x3_resize_fwd", 2.0 * 36 * Cin * y.numel(), 4.0 * (x.numel() + y.numel()),
-                 lambda: fn(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, Cout, Hh, Ww, Ho, Wo, dp, ACT_RELU,
-                            stream_ptr()),
-                 shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_fwd")
-    return y
+    bits = None
+    if want_bits and out_nhwc:
+        nb = lib().gt_conv3x3_resize_bits_bytes(B, Cout, Ho, Wo)
+        if nb > 0:
+            bits = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    if out_nhwc:
+        call = lambda: lib().gt_conv3x3_resize_fwd_nhwc(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, Cout, Hh, Ww, Ho,
+                                                        Wo, dp, ACT_RELU, ptr(bits), stream_ptr())
+    else:
+        call = lambda: lib().gt_conv3x3_resize_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, Cout, Hh, Ww, Ho, Wo,
+                                                   dp, ACT_RELU, stream_ptr())
+    check(_timed("gt_conv3x3_resize_fwd", 2.0 * 36 * Cin * y.numel(), 4.0 * (x.numel() + y.numel()) + (bits.numel() if bits is not None else 0),
+                 call, shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_fwd")
+    return (y, bits) if want_bits else y
 
 
 def conv3x3_wgrad_nhwc(gy: torch.Tensor, ldg: int, x: torch.Tensor, ldx: int, B: int, Hh: int, Ww: int, Cin: int,
@@ -861,8 +872,9 @@ def debug_conv0_mask(mask: Optional[torch.Tensor]):
 
 
 def conv3x3_resize_bwd(g: torch.Tensor, y: torch.Tensor, x: torch.Tensor, w: torch.Tensor,
-                       drop: Optional[GtDropout], out_nhwc: bool = False) -> torch.Tensor:
-    """out_nhwc: g and y are channels-last [B,Ho,Wo,Cout] (what conv3x3_resize_fwd(out_nhwc=True) returned)."""
+                       drop: Optional[GtDropout], out_nhwc: bool = False, bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out_nhwc: g and y are channels-last [B,Ho,Wo,Cout] (what conv3x3_resize_fwd(out_nhwc=True) returned).  bits: the
+    decision buffer the forward recorded (want_bits): the backward then re-evaluates nothing and does not read y."""
     need_f32_cuda(g, y, x, w)
     B, Cin, Hh, Ww = x.shape
     Cout = w.shape[0]
@@ -870,11 +882,16 @@ def conv3x3_resize_bwd(g: torch.Tensor, y: torch.Tensor, x: torch.Tensor, w: tor
     dw = torch.empty_like(w)
     ws = workspace(x.device, lib().gt_conv3x3_resize_bwd_ws_bytes(B, Cin, Cout, Hh, Ww))
     dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
-    fn = lib().gt_conv3x3_resize_bwd_nhwc if out_nhwc else lib().gt_conv3x3_resize_bwd
-    check(_timed("gt_conv3x3_resize_bwd", 0, 4.0 * (x.numel() + 2 * y.numel()),
-                 lambda: fn(g.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), B, Cin, Cout, Hh, Ww, Ho, Wo, dp,
-                            ACT_RELU, dw.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
-                 shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_bwd")
+    if out_nhwc:
+        call = lambda: lib().gt_conv3x3_resize_bwd_nhwc(g.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), B, Cin, Cout,
+                                                        Hh, Ww, Ho, Wo, dp, ACT_RELU, ptr(bits), dw.data_ptr(),
+                                                        ws.data_ptr(), ws.numel(), stream_ptr())
+    else:
+        call = lambda: lib().gt_conv3x3_resize_bwd(g.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), B, Cin, Cout, Hh,
+                                                   Ww, Ho, Wo, dp, ACT_RELU, dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   stream_ptr())
+    nbytes = 4.0 * (x.numel() + y.numel()) + bits.numel() if bits is not None else 4.0 * (x.numel() + 2 * y.numel())
+    check(_timed("gt_conv3x3_resize_bwd", 0, nbytes, call, shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_bwd")
     return dw
 
 

@@ -154,6 +154,9 @@ def bilinear_resize(x, size, in_nhwc: bool = False, out_nhwc: bool = False, act:
     return ResizeFn.apply(x, (int(size[0]), int(size[1])), bool(in_nhwc), bool(out_nhwc), H.ACT_CODE[act])
 
 
+_crb_bits = [os.environ.get("GT_CRB_BITS", "1") != "0"]
+
+
 class Conv3x3ResizeFn(Function):
     """relu(resize(relu(dropout(conv3x3(x))))) in one pass -- the head of Interp2dEncoder (layers.py:483-495)
     when the input carries few channels and needs no gradient.  See gt_conv3x3_resize_fwd."""
@@ -163,19 +166,23 @@ class Conv3x3ResizeFn(Function):
         xc, wc = _c(x), _c(weight)
         salt = _next_salt(1)                     # the salt the stand-alone dropout would have drawn
         drop = H.dropout_desc(p_drop, salt, x.device) if p_drop > 0 else None
-        y = H.conv3x3_resize_fwd(xc, wc, size, drop, out_nhwc)
-        ctx.save_for_backward(xc, wc, y)
+        # channels-last: the forward records its four ReLU / dropout decisions per (output pixel, channel) (4 bits each,
+        # 1/8 of y), and the backward takes them from there instead of re-evaluating the convolution (GT_CRB_BITS=0: off)
+        want = bool(out_nhwc and _crb_bits[0])
+        r = H.conv3x3_resize_fwd(xc, wc, size, drop, out_nhwc, want_bits=want)
+        y, bits = r if want else (r, None)
+        ctx.save_for_backward(xc, wc, y, bits)
         ctx.cfg = (p_drop, salt, out_nhwc)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        xc, wc, y = ctx.saved_tensors
+        xc, wc, y, bits = ctx.saved_tensors
         p_drop, salt, out_nhwc = ctx.cfg
         if ctx.needs_input_grad[0]:
             raise RuntimeError("conv3x3_resize: the fused path has no input gradient")
         drop = H.dropout_desc(p_drop, salt, g.device) if p_drop > 0 else None
-        return None, H.conv3x3_resize_bwd(_c(g), y, xc, wc, drop, out_nhwc), None, None, None
+        return None, H.conv3x3_resize_bwd(_c(g), y, xc, wc, drop, out_nhwc, bits=bits), None, None, None
 
 
 def conv3x3_resize(x, weight, size, p_drop: float = 0.0, training: bool = True, out_nhwc: bool = False):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 17
+#define GT_ABI_VERSION 18
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -469,11 +469,17 @@ int64_t gt_conv3x3_resize_bwd_ws_bytes(int32_t B, int32_t Cin, int32_t Cout, int
  * of the down-scaler consumes. */
 int gt_conv3x3_resize_fwd_nhwc(const float* x, const float* w, float* y, int32_t B, int32_t Cin, int32_t Cout,
                                int32_t H, int32_t W, int32_t Ho, int32_t Wo, const gt_dropout* drop, int32_t act,
-                               void* stream);
+                               void* relu_bits, void* stream);
 int gt_conv3x3_resize_bwd_nhwc(const float* g, const float* y, const float* x, const float* w, int32_t B,
                                int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
-                               const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes,
-                               void* stream);
+                               const gt_dropout* drop, int32_t act, const void* relu_bits, float* dw, void* ws,
+                               int64_t ws_bytes, void* stream);
+/* relu_bits (optional, NULL = off; Cout % 16 == 0, 8-byte aligned, gt_conv3x3_resize_bits_bytes() bytes): the forward
+ * records 4 bits per (output pixel, channel) -- source pixel t of the bilinear stencil kept by the dropout AND positive,
+ * all four cleared when the resized value is <= 0 -- and the backward, handed the same buffer, takes its decisions from
+ * there: it neither re-evaluates the convolution at the four source pixels nor re-draws the mask, and does not read y
+ * (y may be NULL then).  Same weight gradient bit for bit decisions, half the instructions, 0.45 instead of 0.81 GB read. */
+int64_t gt_conv3x3_resize_bits_bytes(int32_t B, int32_t Cout, int32_t Ho, int32_t Wo);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient of a NARROW channels-last 3x3 convolution (padding 1, stride 1, no bias): the three convolutions of the

@@ -1426,6 +1426,35 @@ def test_conv3x3_resize_channels_last_output(H, gpu_device):
     assert rel_l2(res[1][1], res[0][1]) < 1e-6
 
 
+@pytest.mark.parametrize("Cin,p_drop,n,scale", [(1, 0.05, 141, 0.555), (1, 0.0, 141, 0.555), (2, 0.1, 64, 0.5), (3, 0.05, 33, 0.75)])
+def test_conv3x3_resize_recorded_decisions(H, gpu_device, Cin, p_drop, n, scale):
+    """relu_bits of gt_conv3x3_resize_*_nhwc: with the forward's decisions recorded (4 bits per output pixel and channel) the
+    backward re-evaluates neither the convolution nor the dropout mask and does not read y; same forward bits, same weight
+    gradient as the re-evaluating backward up to the round-off of one reassociated product (the re-evaluating path is held to
+    the unfused operators and to fp64 by test_conv3x3_resize_fused_equals_unfused / _channels_last_output)."""
+    from galerkin_transformer import ops
+    dev = gpu_device
+    x = rnd(2, Cin, n, n, dev=dev, seed=451)
+    cot = rnd(2, int(n * scale), int(n * scale), 64, dev=dev, seed=453)
+    cot[0, :5] = 0.0
+    res = []
+    old = ops._crb_bits[0]
+    try:
+        for bits in (True, False):
+            ops._crb_bits[0] = bits
+            w = rnd(64, Cin, 3, 3, dev=dev, seed=452).requires_grad_(True)
+            H.set_seed(7, dev)
+            H._salt[0] = 21
+            y = ops.conv3x3_resize(x, w, scale, p_drop=p_drop, training=True, out_nhwc=True)
+            y.backward(cot)
+            res.append((y.detach(), w.grad.detach()))
+    finally:
+        ops._crb_bits[0] = old
+    assert torch.equal(res[0][0], res[1][0])
+    assert rel_l2(res[0][1], res[1][1]) < 1e-6
+    assert float(res[0][1].abs().max()) > 0
+
+
 @pytest.mark.parametrize("B,Hh,Ww,Cin,ldx,ldg,alpha", [
     (2, 77, 77, 128, 128, -128, 1.0),       # the up-scaler's 128 -> 128 convolution (Cout = 128: blocks of 64 x 32 channels)
     (3, 78, 78, 128, 128, 144, 1.0),        # conv1 of the down-scaler: dense 128-channel input, gy = a segment of [.., 144]
