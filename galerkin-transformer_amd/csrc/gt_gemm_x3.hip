@@ -1643,8 +1643,18 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[e][0]), fabsf(v[e][1])), fmaxf(fabsf(v[e][2]), fabsf(v[e][3]))));
+        // the exponents only move when some value would reach 2^LIMIT under the current one: a wave whose lanes are all
+        // below that reports 0 ("in range") without the six cross-lane exchanges of a full reduction
+        {
+            const int xl = (int)(__float_as_uint(mx) >> 23);
+            const bool over = xl + (isB ? eb : ea) - 127 >= X3H_LIMIT;
+            if (__builtin_amdgcn_ballot_w64(over) != 0ull) {           // wave-uniform
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            } else {
+                mx = 0.f;
+            }
+        }
         if (lane == 0) red[0][wave] = mx;
         __syncthreads();                               // also: every wave is done reading the previous stage's planes
         const float ma = fmaxf(red[0][0], red[0][1]), mb = fmaxf(red[0][2], red[0][3]);
