@@ -3,6 +3,7 @@
 #   suite   the whole -m gpu suite (default arithmetic)          full    tests/test_fullsize_models_gpu.py (C3 / C4 / C5 at full size)
 #   bench   the default bench.py line (+ per-kernel table)        prof    rocprofv3 kernel stats of the steady step, one stream, by grid
 #   pmc     FETCH_SIZE / WRITE_SIZE / SQ passes -> pmc_step.json   sweep   batch sweep        work   the informational workloads
+#   fullprof  rocprofv3 kernel stats of a whole bench.py process      smoke   __graft_entry__.smoke()
 #   mode:<p> short bench in arithmetic <p>      quick:<-k expr> kernel/module tests matching      fetch   FETCH_SIZE pass only
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r05}; shift
@@ -29,6 +30,15 @@ for step in "$@"; do
       python tools/pmc_summary.py $O/pmc 60 > $O/fetch_summary.txt 2>&1
       rm -rf $O/pmc
       grep -E "x3w|x3h|x3r" $O/fetch_summary.txt | cut -c1-170;;
+    fullprof)
+      cd /tmp
+      timeout 900 rocprofv3 --kernel-trace --stats -d $O/fprof -o trace --output-format csv -- \
+          python $R/bench.py --no-cpu-baseline --no-accuracy $arg > $O/fullprof.log 2>&1
+      cd $R
+      python tools/prof_csv_summary.py $O/fprof 80 > $O/kernel_stats_whole_process.txt 2>&1
+      rm -rf $O/fprof
+      head -8 $O/kernel_stats_whole_process.txt | cut -c1-150; grep -ci "igemm\|naive_conv\|miopen\|Cijk" $O/kernel_stats_whole_process.txt;;
+    smoke) ( timeout 600 python -c "import __graft_entry__ as g; g.smoke()" ) 2>&1 | tail -2;;
     mode) ( timeout 400 python bench.py $BENCH_FAST --precision $arg 2>$O/bench_$arg.err | tail -1 ) > $O/bench_prec_$arg.json
           python -c "import json;r=json.load(open('$O/bench_prec_$arg.json'));print('precision $arg',r['value'],r['ms_per_step'])";;
     prof)
