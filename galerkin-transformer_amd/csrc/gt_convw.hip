@@ -205,12 +205,14 @@ __device__ __noinline__ void cw_loader(const float* base, int64_t ld, int H, int
     using G = CwGeom<CIT, COT, F16>;
     char* buf = cw_smem + (ROLE == 0 ? G::XS : G::YS);
     int* exps = reinterpret_cast<int*>(cw_smem + G::ES) + (ROLE == 0 ? 0 : 4);   // exponent each slot / buffer was split with
-    auto rowp = [&](int y) -> const float* { return (y >= 0 && y < H) ? base + (int64_t)y * W * ld : nullptr; };
+    auto rowp = [&](int y) __attribute__((always_inline)) -> const float* { return (y >= 0 && y < H) ? base + (int64_t)y * W * ld : nullptr; };
     CwStage<(ROLE == 0 ? G::CI : G::CO), (ROLE == 0 ? CW_NQ : CW_NQ + 2), (ROLE == 0 ? 0 : -1), CW_LOADERS, G::PL> st;
     st.init(ld, W, lt);
     int e = CWH_E0;                                        // F16: the block's running exponent of this operand
     // split + write the row in flight: the exponent first drops if this row's amax asks for it
-    auto put = [&](int slot) {
+    // (always_inline: left to its heuristics hipcc OUTLINED this lambda in the three-plane instances -- the staged row then
+    // lived in scratch memory between load() and store(): 4.4 ms instead of 1.5 for the 128 -> 128 launch)
+    auto put = [&](int slot) __attribute__((always_inline)) {
         float scale = 1.f;
         if (F16) {
             float m = st.amax();
@@ -276,7 +278,7 @@ __device__ __noinline__ void cw_mfma(float* slab, int Cin, int Cout, int ci0, in
     // One k-step = four pixel groups (the lane groups kq) of row y.  Ten groups per row: the third step has two; its lanes
     // kq >= 2 re-read group 9 and get zero x fragments instead (the ds_read addresses then are base + immediate throughout).
     // The gy fragments of tap column d + 1 are requested before the MFMAs of column d.
-    auto kstep = [&](const char* xr, const char* yr, int q, auto last) {
+    auto kstep = [&](const char* xr, const char* yr, int q, auto last) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last)::value;
         const int qq = LAST ? min(q, CW_NQ - 1) : q;
         const char* abase = xr + ((qq * CI + li) << 4);
@@ -287,7 +289,7 @@ __device__ __noinline__ void cw_mfma(float* slab, int Cin, int Cout, int ci0, in
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl)
                 a[i][pl] = *reinterpret_cast<const frag_t*>(abase + pl * (CW_NQ * CI * 16) + i * 256);
-        auto loadb = [&](int d, frag_t (&dst)[COT][PL]) {     // dx = d - 1: gy unit q - dx, stored at unit index q + 2 - d
+        auto loadb = [&](int d, frag_t (&dst)[COT][PL]) __attribute__((always_inline)) {     // dx = d - 1: gy unit q - dx, stored at unit index q + 2 - d
 #pragma unroll
             for (int j = 0; j < COT; ++j)
 #pragma unroll
