@@ -1583,6 +1583,16 @@ constexpr int X3W_PLANE = X3W_KG * 128 * 16;         // bytes of one plane of on
 // (profiles/r05_x3w_prefetch.json).  PF = 2: the request for stage s + 2 is issued when stage s has been split, a full
 // stage of split + MFMA work earlier; 32 more registers (180: two blocks per CU instead of three, four stages per CU in
 // flight instead of three).
+#ifdef GT_X3W_PROF                                 // tools/x3w_prof.py: shader-clock cycles wave 0 of a block spends per phase
+__device__ unsigned long long x3w_prof[8 * 4096];
+extern "C" int gt_debug_x3w_prof(void* dst, long long bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(x3w_prof), (size_t)bytes);
+}
+#define X3W_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define X3W_T(i)
+#endif
+
 template <int PF>
 __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * X3W_PLANE];      // A planes 0 / 1, B planes 0 / 1
@@ -1619,7 +1629,20 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
     const int st = tid & 127, r4 = st & 31, kg = st >> 5;
     const float* Op = isB ? p.B + n0 + 4 * r4 : p.A + m0 + 4 * r4;
     const int64_t ldo = isB ? p.ldb : p.lda;
-    auto fetch = [&](f32x4 (&v)[8], int k0) {
+    // A whole stage (the usual case, block-uniform test): the address of a load is a wave-uniform row pointer (token k0 + e of
+    // the operand: scalar registers, advanced by scalar adds) + a per-thread byte offset that never changes -- no vector
+    // address arithmetic and no branch per load (the general form below cost ~10 VALU / SALU instructions per load, a
+    // fifth of the split phase this kernel is bound by: tools/x3w_prof.py)
+    const uint32_t voff = (uint32_t)((8 * kg * ldo + (isB ? n0 : m0) + 4 * r4) * (int64_t)sizeof(float));
+    const char* rowbase = reinterpret_cast<const char*>(isB ? p.B : p.A);
+    auto fetch = [&](f32x4 (&v)[8], int k0) __attribute__((always_inline)) {
+        if (k0 + 32 <= kend) {
+            const char* b = rowbase + (int64_t)k0 * ldo * (int64_t)sizeof(float);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[e] = *reinterpret_cast<const f32x4*>(b + (int64_t)e * ldo * (int64_t)sizeof(float) + voff);
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + 8 * kg + e;
@@ -1635,9 +1658,13 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     int ea = X3H_E0, eb = X3H_E0;                      // block-uniform running exponents of the two operands
     float asum[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef GT_X3W_PROF
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    const unsigned long long tbeg = tlast;
+#endif
 
     // one stage: the 32 tokens [k0, k0 + 32) whose values are in v; afterwards v holds the stage PF x 32 tokens further on
-    auto stage = [&](f32x4 (&v)[8], int k0) {
+    auto stage = [&](f32x4 (&v)[8], int k0) __attribute__((always_inline)) {
         // amax of the stage (the values are in registers), per operand over its two waves
         float mx = 0.f;
 #pragma unroll
@@ -1655,8 +1682,10 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
                 mx = 0.f;
             }
         }
+        X3W_T(0);                                      // the stage's values have arrived (vmcnt) + amax
         if (lane == 0) red[0][wave] = mx;
         __syncthreads();                               // also: every wave is done reading the previous stage's planes
+        X3W_T(1);
         const float ma = fmaxf(red[0][0], red[0][1]), mb = fmaxf(red[0][2], red[0][3]);
         const int xa = (int)(__float_as_uint(ma) >> 23), xb = (int)(__float_as_uint(mb) >> 23);
         int d = 0;
@@ -1686,8 +1715,10 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
             for (int pl = 0; pl < 2; ++pl)
                 *reinterpret_cast<u32x4*>(planes + pl * X3W_PLANE + off) = u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
         }
+        X3W_T(2);                                      // exponents, split, plane stores
         if (k0 + 32 * PF < kend) fetch(v, k0 + 32 * PF);   // the values of stage s + PF travel under PF stages of work
         __syncthreads();
+        X3W_T(3);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {               // two MFMA k-steps of 16 tokens
             f16x8 am[2][2], bn[2][2];
@@ -1711,6 +1742,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
                         for (int j = 0; j < 2; ++j) acc[i][j] = mfma32h(bn[j][pb], am[i][pa], acc[i][j]);
                 }
         }
+        X3W_T(4);                                      // fragment reads + MFMA issue
     };
 
     if (PF == 1) {
@@ -1738,6 +1770,15 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
         if (tid < 128 && m0 + tid < p.M)
             p.acs[(int64_t)by * p.M + m0 + tid] = (part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid]);
     }
+#ifdef GT_X3W_PROF
+    if (tid == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = x3w_prof + 8 * blockIdx.x;
+        for (int i = 0; i < 5; ++i) o[i] = tacc[i];
+        o[5] = __builtin_readcyclecounter() - tbeg;
+        o[6] = (unsigned long long)((kend - kbeg + 31) / 32);
+        o[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     // un-scale, undo the sign, store the slab tile: lane (lr, lh) holds row m = .. + 32 i + lr and columns .. + 32 j + 8 g + 4 lh + t
     const int et = -(ea + eb);
     const float us = x3h_pow2(et < -126 ? -126 : (et > 126 ? 126 : et)) * x3_alt_sign(lr);
