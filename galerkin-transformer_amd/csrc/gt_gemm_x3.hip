@@ -1702,10 +1702,13 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
         }
         const float sc = x3h_pow2(isB ? eb : ea);
         char* planes = smem + (isB ? 2 * X3W_PLANE : 0);
+        if (do_acs && !isB) {                          // column sums of A (the bias gradient): the four rows at once, as
+            const f32x4 s4 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));   // packed adds
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asum[c] += s4[c];
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                  // row 4 r4 + c: its eight tokens -> one unit per plane
-            if (do_acs && !isB)
-                asum[c] += ((v[0][c] + v[1][c]) + (v[2][c] + v[3][c])) + ((v[4][c] + v[5][c]) + (v[6][c] + v[7][c]));
             const float sv = (GT_X3_ALT && (c & 1)) ? -sc : sc;          // odd rows enter negated
             uint32_t q[4][2];
 #pragma unroll
