@@ -111,7 +111,7 @@ def main():
 
     def run_qkv(i):
         q = sets[i % 3]
-        H.gemm(q["x"], q["w"], None, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=q["b"], precision="bf16x3",
+        H.gemm(q["x"], q["w"], None, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=q["b"],
                hn=dict(gamma=q["g"], beta=q["bt"], pos=q["pos"], out=q["out"], stats=q["st"], h=h, dk=dk, p=pd,
                        norm_mask=0b110, eps=1e-7, skip_raw=7, plain=True))
     for i in range(6):
