@@ -307,3 +307,47 @@ def test_roofline_legs_name_kernels_of_the_counter_passes_cpu():
         assert "hbm_bytes_per_launch" in leg and leg["hbm_bytes_per_launch"] > 0, label
     assert line["roofline"]["traffic"], "no counter record for the dominant kernel's launch geometry"
     assert line["roofline"]["kernel"] in pmc
+
+
+def test_ctypes_prototypes_match_the_header_cpu():
+    """Every entry point of include/gt_hip.h against its ctypes prototype in _hip._PROTOS: same number of parameters, and
+    parameter by parameter the same class (pointer / 32-bit int / 64-bit int / float / descriptor pointer), same result type.
+    A signature changed in the header but not in the binding (or the other way round) shifts every later argument silently
+    -- the symbol test cannot see that, and the first GPU call would."""
+    import ctypes as C
+    from galerkin_transformer import _hip
+    hdr = open(os.path.join(ROOT, "include", "gt_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", " ", hdr)
+    decls = re.findall(r"\b(int|int32_t|int64_t|const char\s*\*|void)\s+(gt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(decls) >= 40, len(decls)
+
+    def klass_c(param):
+        p = " ".join(param.split())
+        if p in ("void", ""):
+            return None
+        if "*" in p:
+            return "ptr"
+        base = p.rsplit(" ", 1)[0] if " " in p else p
+        base = base.replace("const ", "").strip()
+        return {"int32_t": "i32", "int": "i32", "uint32_t": "i32", "int64_t": "i64", "uint64_t": "i64", "long long": "i64",
+                "float": "f32", "double": "f64"}[base]
+
+    def klass_py(t):
+        if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_int32: "i32", C.c_int: "i32", C.c_uint32: "i32", C.c_int64: "i64", C.c_uint64: "i64", C.c_longlong: "i64",
+                C.c_float: "f32", C.c_double: "f64"}[t]
+
+    seen = set()
+    for res, name, params in decls:
+        assert name in _hip._PROTOS, name
+        seen.add(name)
+        pres, pargs = _hip._PROTOS[name]
+        want = [k for k in (klass_c(q) for q in params.split(",")) if k is not None]
+        got = [klass_py(t) for t in pargs]
+        assert got == want, (name, got, want)
+        res = " ".join(res.split())
+        assert (pres, res) in ((C.c_int, "int"), (C.c_int32, "int32_t"), (C.c_int64, "int64_t"), (C.c_char_p, "const char *"), (C.c_char_p, "const char*"),
+                               (None, "void")), (name, pres, res)
+    assert seen == set(_hip._PROTOS), sorted(set(_hip._PROTOS) - seen)
