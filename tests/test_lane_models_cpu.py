@@ -631,3 +631,114 @@ def test_packed_b_request_order_and_counted_waits(R, nk):
     if kt < nk:
         consume(kt, 1, 2)
     assert consumed_a >= set(range(nk))
+
+
+def _mfma_16x16x32(a, b, d):
+    """Lane model of v_mfma_f32_16x16x32_f16 (values kept in float64): D[16][16] += A[16][32] B[32][16];
+    lane l = 16 kq + x holds a[l][e] = A[x][8 kq + e], b[l][e] = B[8 kq + e][x] (e < 8), d[l][r] = D[4 kq + r][x]."""
+    x, kq = S.X, S.KQ
+    A = np.zeros((16, 32)); B = np.zeros((32, 16))
+    for e in range(8):
+        A[x, 8 * kq + e] = a[:, e]
+        B[8 * kq + e, x] = b[:, e]
+    D = A @ B
+    out = d.copy()
+    for r in range(4):
+        out[:, r] += D[4 * kq + r, x]
+    return out
+
+
+@pytest.mark.parametrize("T", [32, 45])
+def test_head_backward16_lane_map(T):
+    """head_bwd16_kernel (gt_head.hip, GT_PREC_F16X2 instance), one 32-row trip of one wave pair, index maps and the algebra of
+    the power-of-two scales (the fp16 rounding itself is exercised on the GPU): (1) H^T = W1 X^T, the lane's 8-float slice of a
+    row is the B operand as loaded; (2) dX^T = W1^T dh^T with the k-step enumeration hidden = 32 t + 16 (e >> 2) + 4 kq + (e & 3)
+    on both operands; (3) dW1 += dh^T X over the 32 rows, dh read transposed from the wave's tile scaled by 2^e_j, x scaled by
+    2^(c - e_j): the row scales cancel, the result carries 2^c; rows without gradient get the factor 0."""
+    HK, HN = 32, 128
+    rng = np.random.default_rng(100 + T)
+    X, W1 = rng.standard_normal((T, HK)), rng.standard_normal((HN, HK)) * 0.3
+    X *= np.exp2(rng.integers(-6, 7, size=(T, 1)))                 # rows of very different magnitude
+    b1, w2 = rng.standard_normal(HN), rng.standard_normal(HN)
+    g = rng.standard_normal(T) * np.exp2(rng.integers(-20, 1, size=T))
+    g[3] = 0.0                                                     # a row without gradient
+    j, kq = S.X, S.KQ
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    expo = lambda m: np.where(m > 0, 14 - np.floor(np.log2(np.where(m > 0, m, 1.0))), 0.0)   # puts m into [2^14, 2^15)
+    eW = float(expo(np.abs(W1).max()))
+    dX = np.full((T, HK), np.nan)
+    dW1 = np.zeros((HN, HK))
+    for m0 in range(0, T, 32):
+        for half in range(2):                                      # the two waves of the pair: hidden [64 half, +64)
+            hb = 64 * half
+            dh_lds = np.zeros((32, 64))
+            edh = np.zeros((2, 64)); rowmag = np.zeros((2, 64)); live = np.zeros((2, 64), bool)
+            ownX = {}
+            for u in range(2):
+                row = np.minimum(m0 + 16 * u + j, T - 1)
+                gv = np.where(m0 + 16 * u + j < T, g[row], 0.0)
+                xs = X[row[:, None], (8 * kq)[:, None] + np.arange(8)]
+                xm = np.abs(X[row]).max(1)                          # amax over the row's four kq lanes
+                ex = expo(xm)
+                d = np.zeros((64, 4, 4))
+                for mt in range(4):
+                    ft = hb // 16 + mt
+                    wfrag = W1[(16 * ft + j)[:, None], (8 * kq)[:, None] + np.arange(8)] * 2.0 ** eW
+                    acc = _mfma_16x16x32(wfrag, xs * np.exp2(ex)[:, None], np.zeros((64, 4)))
+                    hid = hb + 16 * mt + 4 * kq[:, None] + np.arange(4)
+                    hpre = acc * np.exp2(-ex)[:, None] * 2.0 ** -eW + b1[hid]
+                    sg = sig(hpre)
+                    d[:, mt] = gv[:, None] * w2[hid] * (sg * (1 + hpre * (1 - sg)))
+                dm = np.abs(d).reshape(64, 16).max(1)
+                dm = np.array([dm[(j == j[l])].max() for l in range(64)])      # over the row's four kq lanes
+                ed = expo(dm)
+                live[u], edh[u] = dm > 0, ed
+                rowmag[u] = np.where(dm > 0, xm * np.exp2(-ed), 0.0)
+                ds = d * np.exp2(ed)[:, None, None]
+                for l in range(64):
+                    for mt in range(4):
+                        dh_lds[16 * u + j[l], 16 * mt + 4 * kq[l]:16 * mt + 4 * kq[l] + 4] = ds[l, mt]
+                accX = [np.zeros((64, 4)), np.zeros((64, 4))]
+                for t in range(2):
+                    bfrag = np.concatenate([ds[:, 2 * t], ds[:, 2 * t + 1]], axis=1)          # e < 4: tile 2t, e >= 4: tile 2t + 1
+                    for ti in range(2):
+                        e = np.arange(8)
+                        hidden = 32 * (2 * half + t) + 16 * (e >> 2)[None, :] + 4 * kq[:, None] + (e & 3)[None, :]
+                        afrag = W1[hidden, (16 * ti + j)[:, None]] * 2.0 ** eW
+                        accX[ti] = _mfma_16x16x32(afrag, bfrag, accX[ti])
+                ownX[u] = [a * np.exp2(-ed)[:, None] * 2.0 ** -eW for a in accX]
+            partial = ownX
+            if half == 0:
+                first = partial
+            # (3) with this wave's tile
+            c = 13 - np.floor(np.log2(rowmag.max())) if rowmag.max() > 0 else 0.0
+            fr = np.zeros(32)
+            for u in range(2):
+                for l in range(64):
+                    if kq[l] == 0:
+                        fr[16 * u + j[l]] = 2.0 ** (c - edh[u, l]) if live[u, l] else 0.0
+            accW = [[np.zeros((64, 4)) for _ in range(2)] for _ in range(4)]
+            rows8 = np.minimum(m0 + 8 * kq[:, None] + np.arange(8), T - 1)
+            for mt in range(4):
+                afrag = dh_lds[(8 * kq)[:, None] + np.arange(8), (16 * mt + j)[:, None]]
+                for ti in range(2):
+                    bfrag = X[rows8, (16 * ti + j)[:, None]] * fr[(8 * kq)[:, None] + np.arange(8)]
+                    accW[mt][ti] = _mfma_16x16x32(afrag, bfrag, accW[mt][ti])
+            for l in range(64):
+                for mt in range(4):
+                    for ti in range(2):
+                        for r in range(4):
+                            dW1[hb + 16 * mt + 4 * kq[l] + r, 16 * ti + j[l]] += accW[mt][ti][l, r] * 2.0 ** -c
+            if half == 1:                                          # the pair's exchange: wave `half` stores in-features [16 half, +16)
+                for u in range(2):
+                    for hh, mine, other in ((0, first, partial), (1, partial, first)):
+                        tot = mine[u][hh] + other[u][hh]
+                        for l in range(64):
+                            if m0 + 16 * u + j[l] < T:
+                                dX[m0 + 16 * u + j[l], 16 * hh + 4 * kq[l]:16 * hh + 4 * kq[l] + 4] = tot[l]
+    H = X @ W1.T + b1
+    sg = sig(H)
+    dh = g[:, None] * w2[None, :] * (sg * (1 + H * (1 - sg)))
+    assert np.allclose(dX, dh @ W1, rtol=1e-9, atol=1e-12 * np.abs(dh @ W1).max())
+    ref = dh.T @ X
+    assert np.allclose(dW1, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
