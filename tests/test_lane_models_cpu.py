@@ -742,3 +742,54 @@ def test_head_backward16_lane_map(T):
     assert np.allclose(dX, dh @ W1, rtol=1e-9, atol=1e-12 * np.abs(dh @ W1).max())
     ref = dh.T @ X
     assert np.allclose(dW1, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("tiles,n_split", [(1, 256), (2, 256), (2, 171), (3, 171), (3, 8), (2, 5)])
+def test_x3w_chunk_major_block_order(tiles, n_split):
+    """gemm_x3w_kernel with x3w_map (gt_gemm_x3.hip): a 1-D grid of 8 ceil(n_split / 8) tiles blocks, block id % 8 = XCD;
+    XCD x owns the K chunks [x spx, (x + 1) spx) and the tiles of one chunk are consecutive blocks of that XCD.  Every
+    (tile, chunk) pair is worked exactly once, surplus blocks leave, and a chunk's tiles share an XCD back to back."""
+    spx = (n_split + 7) >> 3
+    grid = 8 * spx * tiles
+    seen = {}
+    for bid in range(grid):
+        s = bid >> 3
+        by, tile = (bid & 7) * spx + s // tiles, s % tiles
+        if by >= n_split:
+            continue
+        assert (tile, by) not in seen
+        seen[(tile, by)] = bid
+    assert set(seen) == {(t, c) for t in range(tiles) for c in range(n_split)}
+    for c in range(n_split):
+        ids = [seen[(t, c)] for t in range(tiles)]
+        assert len({i & 7 for i in ids}) == 1                                  # one XCD
+        assert [i >> 3 for i in ids] == list(range(ids[0] >> 3, (ids[0] >> 3) + tiles))   # consecutive slots of it
+
+
+@pytest.mark.parametrize("Cout,npx", [(128, 70), (64, 33), (16, 5)])
+def test_conv0_decision_bits_layout(Cout, npx):
+    """relu_bits of the fused conv0 + resize (gt_resize.hip): the forward thread of (pixel e, channel block bc of 16) writes
+    ONE 64-bit word [b][bc][e] with nibble j = channel 16 bc + j; the backward thread of (pixel e, channel group c0 of 8) reads
+    the same word, takes its low or high half by c0 & 8, and tests bit 4 j + t for channel c0 + j, source pixel t."""
+    rng = np.random.default_rng(Cout + npx)
+    B = 2
+    dec = rng.integers(0, 16, size=(B, npx, Cout))                 # the forward's four decisions per (pixel, channel)
+    words = np.zeros((B, Cout // 16, npx), dtype=np.uint64)
+    for b in range(B):
+        for bc in range(Cout // 16):
+            for e in range(npx):
+                nib = 0
+                for j4 in range(0, 16, 4):                          # the forward packs four channels at a time
+                    n16 = 0
+                    for jj in range(4):
+                        n16 |= int(dec[b, e, 16 * bc + j4 + jj]) << (4 * jj)
+                    nib |= n16 << (4 * j4)
+                words[b, bc, e] = nib
+    for b in range(B):
+        for c0 in range(0, Cout, 8):
+            for e in range(npx):
+                w64 = int(words[b, c0 >> 4, e])
+                d32 = (w64 >> 32) if (c0 & 8) else (w64 & 0xFFFFFFFF)
+                for j in range(8):
+                    for t in range(4):
+                        assert bool(d32 & (1 << (4 * j + t))) == bool((int(dec[b, e, c0 + j]) >> t) & 1)
