@@ -793,3 +793,61 @@ def test_conv0_decision_bits_layout(Cout, npx):
                 for j in range(8):
                     for t in range(4):
                         assert bool(d32 & (1 << (4 * j + t))) == bool((int(dec[b, e, c0 + j]) >> t) & 1)
+
+
+@pytest.mark.parametrize("K,with_acs", [(64, True), (45, False)])
+def test_x3w_kernel_lane_map(K, with_acs):
+    """gemm_x3w_kernel (gt_gemm_x3.hip), one 128 x 128 output tile of one K chunk: the staging roles (waves 0-1 the A tile,
+    2-3 the B tile; a thread owns rows 4 r4 .. + 3 and the eight tokens of k-group kg), the plane layout [k-group][row] of
+    16-byte units (eight tokens of one row), the fragment a lane reads for MFMA k-step ks (unit 2 ks + lh of its row), the
+    operand order of the MFMA (N-side tile first), the sign alternation of odd rows on both sides and its undo, the slab
+    store map, and the bias-gradient column sums.  Values stay float64 (the fp16 split is exercised on the GPU)."""
+    rng = np.random.default_rng(K)
+    A, B = rng.standard_normal((K, 128)), rng.standard_normal((K, 128))
+    lanes = np.arange(64)
+    lr, lh = lanes & 31, lanes >> 5
+    acc = {(w, i, jj): np.zeros((64, 16)) for w in range(4) for i in range(2) for jj in range(2)}
+    asum = np.zeros(128)
+    for k0 in range(0, K, 32):
+        planes = {"A": np.zeros((4, 128, 8)), "B": np.zeros((4, 128, 8))}     # [k-group][row][token in group]
+        for tid in range(256):
+            wave = tid >> 6
+            op = "B" if wave >= 2 else "A"
+            src = B if wave >= 2 else A
+            st = tid & 127
+            r4, kg = st & 31, st >> 5
+            v = np.zeros((8, 4))
+            for e in range(8):
+                k = k0 + 8 * kg + e
+                if k < K:
+                    v[e] = src[k, 4 * r4:4 * r4 + 4]
+            for c in range(4):
+                if op == "A" and with_acs:
+                    asum[4 * r4 + c] += v[:, c].sum()
+                sign = -1.0 if (c & 1) else 1.0                                  # odd rows enter negated (row 4 r4 + c)
+                planes[op][kg, 4 * r4 + c] = sign * v[:, c]
+        for w in range(4):
+            wm, wn = w >> 1, w & 1
+            for ks in range(2):
+                kq = 2 * ks + lh
+                am = [planes["A"][kq, wm * 64 + 32 * i + lr] for i in range(2)]     # [64 lanes][8 tokens]
+                bn = [planes["B"][kq, wn * 64 + 32 * jj + lr] for jj in range(2)]
+                for i in range(2):
+                    for jj in range(2):
+                        acc[(w, i, jj)] = _mfma32(bn[jj], am[i], acc[(w, i, jj)])
+    C = np.full((128, 128), np.nan)
+    for w in range(4):
+        wm, wn = w >> 1, w & 1
+        for i in range(2):
+            m = wm * 64 + 32 * i + lr
+            us = np.where(lr & 1, -1.0, 1.0)                                      # x3_alt_sign(lr): the row's sign
+            for jj in range(2):
+                for g_ in range(4):
+                    n = wn * 64 + 32 * jj + 8 * g_ + 4 * lh
+                    a = acc[(w, i, jj)]
+                    vals = np.stack([a[:, 4 * g_] * us, -a[:, 4 * g_ + 1] * us, a[:, 4 * g_ + 2] * us, -a[:, 4 * g_ + 3] * us], 1)
+                    for l in range(64):
+                        C[m[l], n[l]:n[l] + 4] = vals[l]
+    assert np.allclose(C, A.T @ B, atol=1e-9)
+    if with_acs:
+        assert np.allclose(asum, A.sum(0), atol=1e-9)
