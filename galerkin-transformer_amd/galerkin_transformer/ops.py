@@ -168,7 +168,7 @@ class Conv3x3ResizeFn(Function):
         drop = H.dropout_desc(p_drop, salt, x.device) if p_drop > 0 else None
         # channels-last: the forward records its four ReLU / dropout decisions per (output pixel, channel) (4 bits each,
         # 1/8 of y), and the backward takes them from there instead of re-evaluating the convolution (GT_CRB_BITS=0: off)
-        want = bool(out_nhwc and _crb_bits[0])
+        want = bool(out_nhwc and _crb_bits[0] and ctx.needs_input_grad[1])     # nothing to record for an inference pass
         r = H.conv3x3_resize_fwd(xc, wc, size, drop, out_nhwc, want_bits=want)
         y, bits = r if want else (r, None)
         ctx.save_for_backward(xc, wc, y, bits)
