@@ -15,7 +15,7 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 18          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 19          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
@@ -101,6 +101,10 @@ _PROTOS = {
     "gt_galerkin_dkv_ln": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p]),
     "gt_fourier_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.POINTER(GtDropout),
                                                                 C.c_int32, C.c_void_p]),
+    "gt_fourier16_image_bytes": (C.c_int64, [C.c_int32] * 4),
+    "gt_fourier16_presplit": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 4 + [C.c_void_p]),
+    "gt_fourier16_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.POINTER(GtDropout),
+                                                                  C.c_int32, C.c_void_p]),
     "gt_dropact_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(GtDropout), C.c_int32, C.POINTER(GtDropout),
                                  C.c_int32, C.c_void_p]),
     "gt_dropact_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(GtDropout), C.c_int32,
@@ -319,7 +323,7 @@ def set_precision_classes(classes: Optional[dict]):
     old = dict(_prec_class)
     _prec_class.clear()
     for k, v in (classes or {}).items():
-        if k not in ("hn", "conv", "convw", "wgrad", "batched", "tok", "head") or v not in PREC_CODE:
+        if k not in ("hn", "conv", "convw", "wgrad", "batched", "tok", "head", "fourier") or v not in PREC_CODE:
             raise ValueError(f"set_precision_classes: bad entry {k}={v}")
         _prec_class[k] = v
     return old
@@ -1046,6 +1050,49 @@ def dft_synthesis(F, Z, Y, nb: int, n: int, P: int, Co: int, X2, W2, C2: int, bi
 
 
 FOURIER_DP = (20, 36, 52)
+
+
+def fourier16_active(precision: Optional[str] = None) -> bool:
+    """True when the Fourier-type attention runs on the two-term fp16 kernels (gt_fourier16.hip): the default arithmetic;
+    `f32` keeps the bit-exact fp32-MFMA kernel, the bf16 modes have no Fourier kernel of their own and use it too."""
+    if "fourier" in _prec_class:
+        return PREC_CODE[_prec_class["fourier"]] == PREC_F16X2
+    return (_precision[0] if precision is None else PREC_CODE[precision]) == PREC_F16X2
+
+
+def fourier16_presplit(tensors, B: int, n: int, h: int, DP: int):
+    """Head tiles [B*n, h, DP] (up to four) -> their image blocks (uint8 tensors), one launch."""
+    tensors = list(tensors)
+    assert 1 <= len(tensors) <= 4
+    need_f32_cuda(*tensors)
+    nb = int(lib().gt_fourier16_image_bytes(B, n, h, DP))
+    if nb <= 0:
+        raise GtNotSupported(f"gt_fourier16: head tile width {DP}")
+    imgs = [torch.empty(nb, dtype=torch.uint8, device=tensors[0].device) for _ in tensors]
+    xs = [t.data_ptr() for t in tensors] + [None] * (4 - len(tensors))
+    is_ = [t.data_ptr() for t in imgs] + [None] * (4 - len(tensors))
+    check(_timed("gt_fourier16_presplit", 0.0, len(tensors) * (4.0 * B * n * h * DP + nb),
+                 lambda: lib().gt_fourier16_presplit(*xs, *is_, B, n, h, DP, stream_ptr()),
+                 shape=(B, n, h, DP, len(tensors))), "gt_fourier16_presplit")
+    return imgs
+
+
+def fourier16_attn(F1, F2, T1, T2, B: int, n: int, h: int, DP: int, scale: float, mask, drop, owner_is_key: bool,
+                   O1=None, O2=None):
+    """One pass of gt_fourier16_attn; F1, F2, T1, T2 are image blocks of fourier16_presplit.  Returns O1 (and O2)."""
+    dev = T1.device
+    if O1 is None:
+        O1 = torch.empty(B * n, h, DP, dtype=torch.float32, device=dev)
+    if O2 is None and F2 is not None:
+        O2 = torch.empty_like(O1)
+    need_f32_cuda(mask, O1, O2)
+    dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
+    nprod = 2 if F2 is not None else 1
+    check(_timed("gt_fourier16_attn", 4.0 * nprod * B * h * n * n * DP, 4.0 * (3 + nprod) * B * n * h * DP,
+                 lambda: lib().gt_fourier16_attn(F1.data_ptr(), ptr(F2), T1.data_ptr(), T2.data_ptr(), O1.data_ptr(),
+                                                 ptr(O2), B, n, h, DP, scale, ptr(mask), dp, int(owner_is_key),
+                                                 stream_ptr()), shape=(B, n, h, DP, nprod)), "gt_fourier16_attn")
+    return (O1, O2) if F2 is not None else O1
 
 
 def fourier_attn(F1, F2, T1, T2, B: int, n: int, h: int, DP: int, scale: float, mask, drop, owner_is_key: bool,

@@ -887,7 +887,15 @@ class SimpleAttentionFn(Function):
             flash = (not need_w) and DP in H.FOURIER_DP
             if flash:
                 # fused (Q'K'^T * scale .* mask) V': the n x n matrix never reaches HBM
-                att = H.fourier_attn(Qp, None, Kp, Vp, B, n, h, DP, scale, mask, d_attn, False).reshape(T, hD)
+                if H.fourier16_active():
+                    # two-term fp16 kernels: the head tiles are split once into fragment-ordered images, kept for the backward
+                    imgs = H.fourier16_presplit((Qp, Kp, Vp), B, n, h, DP)
+                    att = H.fourier16_attn(imgs[0], None, imgs[1], imgs[2], B, n, h, DP, scale, mask, d_attn,
+                                           False).reshape(T, hD)
+                    ctx.f16_imgs = imgs
+                else:
+                    att = H.fourier_attn(Qp, None, Kp, Vp, B, n, h, DP, scale, mask, d_attn, False).reshape(T, hD)
+                    ctx.f16_imgs = None
                 S = None
             else:
                 S = torch.empty(B, h, n, n, dtype=torch.float32, device=dev)
@@ -984,8 +992,15 @@ class SimpleAttentionFn(Function):
             if S is None:
                 # fused passes: dQ' = (dO V'^T .* m) K' ;  dV' = (S .* m)^T dO, dK' = (dO V'^T .* m)^T Q'
                 datt3 = datt.reshape(T, h, DP)
-                H.fourier_attn(datt3, None, Vp, Kp, B, n, h, DP, scale, mask, d_attn, False, O1=dO3[0])
-                H.fourier_attn(Kp, Vp, Qp, datt3, B, n, h, DP, scale, mask, d_attn, True, O1=dO3[2], O2=dO3[1])
+                imgs = getattr(ctx, "f16_imgs", None)
+                if imgs is not None:
+                    iq, ik, iv = imgs
+                    (ido,) = H.fourier16_presplit((datt3,), B, n, h, DP)
+                    H.fourier16_attn(ido, None, iv, ik, B, n, h, DP, scale, mask, d_attn, False, O1=dO3[0])
+                    H.fourier16_attn(ik, iv, iq, ido, B, n, h, DP, scale, mask, d_attn, True, O1=dO3[2], O2=dO3[1])
+                else:
+                    H.fourier_attn(datt3, None, Vp, Kp, B, n, h, DP, scale, mask, d_attn, False, O1=dO3[0])
+                    H.fourier_attn(Kp, Vp, Qp, datt3, B, n, h, DP, scale, mask, d_attn, True, O1=dO3[2], O2=dO3[1])
             else:
                 dS = torch.empty(B, h, n, n, dtype=torch.float32, device=dev)
                 H.gemm(datt, Vp, dS, n, n, DP, lda=hD, ldb=hD, ldc=n, batch=(B, h), a_bs=(n * hD, DP),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 18
+#define GT_ABI_VERSION 19
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -336,6 +336,21 @@ int gt_galerkin_dkv_ln_plain(const float* Kp, const float* Vp, const float* dM, 
 int gt_fourier_attn(const float* F1, const float* F2, const float* T1, const float* T2, float* O1, float* O2,
                     int32_t B, int32_t n, int32_t h, int32_t DP, float scale, const float* mask,
                     const gt_dropout* drop, int32_t owner_is_key, void* stream);
+
+/* The same operator (layers.py:672-705, the three uses above) in the two-term fp16 arithmetic (GT_PREC_F16X2: three products
+ * per contraction on v_mfma_f32_16x16x32_f16, fp32 accumulation, fp32-class results) -- ABI v19.  The head tiles are split
+ * ONCE per use into "images": per (batch, head, tile of 32 token rows) the two fp16 planes in MFMA fragment order, in the
+ * layout of each of the two products, with the tile's power-of-two exponent and its largest row norm in a header.
+ *     gt_fourier16_image_bytes   size of ONE tensor's image block (header + images) for head tiles [B*n][h][DP]
+ *     gt_fourier16_presplit      X0..X3 (up to four head-tile tensors, NULL-terminated) -> image blocks I0..I3, one launch
+ *     gt_fourier16_attn          as gt_fourier_attn with F1, F2, T1, T2 = image blocks of the tensors named there
+ * DP in {20, 36, 52}, else GT_ENOTSUP. */
+int64_t gt_fourier16_image_bytes(int32_t B, int32_t n, int32_t h, int32_t DP);
+int gt_fourier16_presplit(const float* X0, const float* X1, const float* X2, const float* X3, void* I0, void* I1, void* I2,
+                          void* I3, int32_t B, int32_t n, int32_t h, int32_t DP, void* stream);
+int gt_fourier16_attn(const void* F1, const void* F2, const void* T1, const void* T2, float* O1, float* O2, int32_t B,
+                      int32_t n, int32_t h, int32_t DP, float scale, const float* mask, const gt_dropout* drop,
+                      int32_t owner_is_key, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Truncated-DFT stages along the contiguous grid axis of SpectralConv2d (layers.py:1176 rfft2 and :1187
