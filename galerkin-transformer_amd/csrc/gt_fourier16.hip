@@ -67,6 +67,19 @@ __device__ __forceinline__ void f16_split_pair(float a, float b, uint32_t& hi, u
     hi = __builtin_bit_cast(uint32_t, h0);
     lo = __builtin_bit_cast(uint32_t, h1);
 }
+// the score phase's version: (a0 m0, a1 m1) -> packed h0, h1 in four instructions.  v_fma_mix{lo,hi}_f16 evaluate the fp32 fma
+// and round it to one half of the destination: h0 = f16(a m) (m is a power of two or 0: the product is exact) and
+// h1 = f16(a m - h0) (the residual is exact in fp32) -- no separate multiply, no conversions (8 issue slots per pair with
+// v_pk_mul_f32 / v_cvt / v_pk_fma_f32: tools/valu_rate_probe.hip, a packed fp32 instruction costs two)
+__device__ __forceinline__ void f16_mulsplit_pair(float a0, float m0, float a1, float m1, uint32_t& hi, uint32_t& lo) {
+    uint32_t h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(m0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(m1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "v"(m0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(a1), "v"(m1), "v"(h));
+    hi = h;
+    lo = l;
+}
 // acc += a b, a = ah + al, b = bh + bl: small terms first
 __device__ __forceinline__ f32x4 f16_mma3(ff16x8 ah, ff16x8 al, ff16x8 bh, ff16x8 bl, f32x4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
@@ -171,10 +184,15 @@ struct F16P {
     float scale;
     int owner_is_key;
 };
-enum { F16_PLAIN = 0, F16_DROP = 1, F16_DROPH = 2, F16_MASK = 3 };   // DROPH: thresh has no low 16 bits (p = 0.5)
+// DROPH: per-element hash, threshold without low 16 bits.  DROPB: p = 0.5 drawn per 4 x 4 block of the score matrix -- ONE hash
+// per block (query >> 2, key >> 2), element (q, k) keeps iff bit 16 + 4 (q & 3) + (k & 3) of it is set (gt_hip.h:
+// gt_dropout_block16): a lane's four result registers of a 16 x 16 score tile are four keys (or four queries) of one block,
+// so the hash is evaluated once per register QUAD in both orientations -- the score phase is bound by instruction issue
+// (profiles/r06c_fourier16_sq_counters.txt) and the per-element hash was 128 of its 200 instructions per tile.
+enum { F16_PLAIN = 0, F16_DROP = 1, F16_DROPH = 2, F16_MASK = 3, F16_DROPB = 4 };
 
 template <int DP, bool DUAL, int MODE>
-__global__ __launch_bounds__(256, DUAL ? 2 : 3) void fourier16_kernel(const F16P p) {
+__global__ __launch_bounds__(256, DUAL ? 2 : (DP > 36 ? 3 : 4)) void fourier16_kernel(const F16P p) {
     using G = F16G<DP>;
     constexpr int NM = G::NM, TG = G::TG, NS = G::NS, ND = G::ND;
     constexpr int STAGE = DUAL ? 2 * G::IMG : G::IMG;            // one image of each stream tensor / T1's rm + T2's tr
@@ -257,6 +275,22 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 3) void fourier16_kernel(const F16P
         }
         hstep = p.owner_is_key ? (uint32_t)p.n * GOLD : GOLD;      // idx step per stream row, times G
     }
+    uint32_t bpos[4] = {0u, 0u, 0u, 0u};
+    if (MODE == F16_DROPB) {
+        // block index ((b h + head) nq4 + (query >> 2)) nq4 + (key >> 2); the lane's stream rows 16 mt + 4 kq + r of tile t
+        // are rows 4 (8 t + 4 mt + kq) + r: one block per (nt, mt)
+        const uint32_t key = drop_key_dev(p.drop), nq4 = (uint32_t)((p.n + 3) >> 2);
+        const uint32_t zn4 = ((uint32_t)b * (uint32_t)p.h + (uint32_t)head) * nq4;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const uint32_t own4 = (uint32_t)(o0 + 16 * nt + j) >> 2;
+            const uint32_t blk = p.owner_is_key ? (zn4 + (uint32_t)kq) * nq4 + own4 : (zn4 + own4) * nq4 + (uint32_t)kq;
+            hw[nt] = blk * GOLD + key;
+        }
+        hstep = p.owner_is_key ? nq4 * GOLD : GOLD;               // step per block along the stream axis, times G
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bpos[r] = 16u + (p.owner_is_key ? 4u * r + (uint32_t)(j & 3) : 4u * (uint32_t)(j & 3) + r);
+    }
     const float osign = (j & 1) ? -1.f : 1.f;                     // owner half of the chain sign (-1)^(dim + owner)
 
     f32x4 acc1[ND][2], acc2[DUAL ? ND : 1][2];
@@ -325,6 +359,15 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 3) void fourier16_kernel(const F16P
                 }
             }
         }
+        // The score phase reads the MFMA results from inline asm (f16_mulsplit_pair), and hipcc's hazard recogniser does not
+        // look into inline asm: without this the first v_fma_mix* after the last MFMA read stale registers (measured: 2.9e-5
+        // instead of 3e-7).  An 8-pass MFMA result needs 11 wait states before a VALU access; all score registers pass
+        // through this statement, so every MFMA above has issued before it and every reader below comes after it.
+        if (DUAL)
+            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(sa[0][0]), "+v"(sa[0][1]), "+v"(sa[1][0]), "+v"(sa[1][1]), "+v"(sb[0][0]),
+                         "+v"(sb[0][1]), "+v"(sb[DUAL ? 1 : 0][0]), "+v"(sb[DUAL ? 1 : 0][1]));
+        else
+            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(sa[0][0]), "+v"(sa[0][1]), "+v"(sa[1][0]), "+v"(sa[1][1]));
         // running exponents (wave-uniform integer arithmetic) and the score multipliers
         float sigA, sigB = 0.f;
         {
@@ -364,14 +407,25 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 3) void fourier16_kernel(const F16P
         ff16x8 ph[2], pl_[2], qh[DUAL ? 2 : 1], ql[DUAL ? 2 : 1];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            float va[8], vb[8];
+            float va[8], vb[8], wa[8], wb[8];                       // score values and their multipliers
             uint32_t hk = hw[nt];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
+                uint32_t xb = 0u;
+                if (MODE == F16_DROPB) {
+                    // bits 16..31 of the finaliser do not depend on its last step x ^= x >> 16
+                    xb = hk;
+                    xb ^= xb >> 16; xb *= 0x85ebca6bu; xb ^= xb >> 13; xb *= 0xc2b2ae35u;
+                    hk += 4u * hstep;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float ma = sigA, mb = sigB;
-                    if (MODE == F16_DROP || MODE == F16_DROPH) {
+                    if (MODE == F16_DROPB) {
+                        const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int32_t)xb, bpos[r], 1u);
+                        ma = __uint_as_float(__float_as_uint(sigA) & km);
+                        if (DUAL) mb = __uint_as_float(__float_as_uint(sigB) & km);
+                    } else if (MODE == F16_DROP || MODE == F16_DROPH) {
                         uint32_t x = hk;
                         x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u;
                         if (MODE == F16_DROPH) {
@@ -394,20 +448,24 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 3) void fourier16_kernel(const F16P
                         ma = m * sigA;
                         if (DUAL) mb = m * sigB;
                     }
-                    va[4 * mt + r] = sa[mt][nt][r] * ma;
-                    if (DUAL) vb[4 * mt + r] = sb[mt][nt][r] * mb;
+                    va[4 * mt + r] = sa[mt][nt][r];
+                    wa[4 * mt + r] = ma;
+                    if (DUAL) {
+                        vb[4 * mt + r] = sb[mt][nt][r];
+                        wb[4 * mt + r] = mb;
+                    }
                 }
-                hk += 12u * hstep;
+                if (MODE != F16_DROPB) hk += 12u * hstep;
             }
-            hw[nt] = hk;                                          // advanced by 32 stream rows
+            hw[nt] = hk;                                          // advanced by 32 stream rows (8 blocks)
             uint32_t hi[4], lo[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f16_split_pair(va[2 * e], va[2 * e + 1], hi[e], lo[e]);
+            for (int e = 0; e < 4; ++e) f16_mulsplit_pair(va[2 * e], wa[2 * e], va[2 * e + 1], wa[2 * e + 1], hi[e], lo[e]);
             ph[nt] = __builtin_bit_cast(ff16x8, fu32x4{hi[0], hi[1], hi[2], hi[3]});
             pl_[nt] = __builtin_bit_cast(ff16x8, fu32x4{lo[0], lo[1], lo[2], lo[3]});
             if (DUAL) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f16_split_pair(vb[2 * e], vb[2 * e + 1], hi[e], lo[e]);
+                for (int e = 0; e < 4; ++e) f16_mulsplit_pair(vb[2 * e], wb[2 * e], vb[2 * e + 1], wb[2 * e + 1], hi[e], lo[e]);
                 qh[nt] = __builtin_bit_cast(ff16x8, fu32x4{hi[0], hi[1], hi[2], hi[3]});
                 ql[nt] = __builtin_bit_cast(ff16x8, fu32x4{lo[0], lo[1], lo[2], lo[3]});
             }
@@ -431,7 +489,7 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 3) void fourier16_kernel(const F16P
     }
     // O^T tile (dt, nt): rows = dims 16 dt + 4 kq + r, column = owner o0 + 16 nt + j  ->  O[owner][dim .. dim + 3];
     // the chain sign (-1)^(dim + owner) = (-1)^(r + j) comes off with the scales
-    const float fs = p.scale * ((MODE == F16_DROP || MODE == F16_DROPH) ? p.drop.scale : 1.f);
+    const float fs = p.scale * ((MODE == F16_DROP || MODE == F16_DROPH || MODE == F16_DROPB) ? p.drop.scale : 1.f);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int ow = o0 + 16 * nt + j;
@@ -454,19 +512,21 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 3) void fourier16_kernel(const F16P
 }
 
 template <int DP>
-static void fourier16_launch(const F16P& p, bool dual, hipStream_t st) {
+static void fourier16_launch(const F16P& p, bool dual, bool block16, hipStream_t st) {
     int mode = F16_PLAIN;
     if (p.mask) mode = F16_MASK;
-    else if (p.drop.thresh) mode = (p.drop.thresh & 0xffffu) ? F16_DROP : F16_DROPH;
+    else if (p.drop.thresh) mode = block16 ? F16_DROPB : ((p.drop.thresh & 0xffffu) ? F16_DROP : F16_DROPH);
     const dim3 grid((unsigned)p.total);
 #define GT_F16(D, M) hipLaunchKernelGGL((fourier16_kernel<DP, D, M>), grid, dim3(256), 0, st, p)
     if (dual) {
-        if (mode == F16_DROPH) GT_F16(true, F16_DROPH);
+        if (mode == F16_DROPB) GT_F16(true, F16_DROPB);
+        else if (mode == F16_DROPH) GT_F16(true, F16_DROPH);
         else if (mode == F16_DROP) GT_F16(true, F16_DROP);
         else if (mode == F16_MASK) GT_F16(true, F16_MASK);
         else GT_F16(true, F16_PLAIN);
     } else {
-        if (mode == F16_DROPH) GT_F16(false, F16_DROPH);
+        if (mode == F16_DROPB) GT_F16(false, F16_DROPB);
+        else if (mode == F16_DROPH) GT_F16(false, F16_DROPH);
         else if (mode == F16_DROP) GT_F16(false, F16_DROP);
         else if (mode == F16_MASK) GT_F16(false, F16_MASK);
         else GT_F16(false, F16_PLAIN);
@@ -493,6 +553,34 @@ extern "C" int64_t gt_fourier16_image_bytes(int32_t B, int32_t n, int32_t h, int
     if (!img || B <= 0 || n <= 0 || h <= 0) return 0;
     const int ntile = ceil_div(n, 32);
     return f16_hdr_bytes((int64_t)B * h, ntile) + (int64_t)B * h * ntile * img;
+}
+
+// S[bh][q][k] *= keep(q, k) / (1 - p) with the 4 x 4-block mask of F16_DROPB: what the materialising path (attention weights
+// requested) applies to the score matrix a gt_gemm wrote, so that it draws the mask the fused kernels draw.
+__global__ __launch_bounds__(256) void dropout_block16_kernel(float* S, int64_t BH, int n, DropDev d) {
+    const uint32_t nq4 = (uint32_t)((n + 3) >> 2);
+    const int64_t total = BH * (int64_t)n * nq4;
+    const uint32_t key = drop_key_dev(d);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const uint32_t k4 = (uint32_t)(i % nq4);
+        const int64_t row = i / nq4;                               // bh * n + q
+        const uint32_t q = (uint32_t)(row % n), bh = (uint32_t)(row / n);
+        uint32_t x = ((bh * nq4 + (q >> 2)) * nq4 + k4) * 0x9e3779b1u + key;
+        x = fmix32(x);
+        float* s = S + row * (int64_t)n + 4 * (int64_t)k4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (4 * k4 + c < (uint32_t)n) s[c] = ((x >> (16u + 4u * (q & 3u) + c)) & 1u) ? s[c] * d.scale : 0.f;
+    }
+}
+
+extern "C" int gt_dropout_block16(float* S, int64_t BH, int32_t n, const gt_dropout* drop, void* stream) {
+    if (!S || BH <= 0 || n <= 0 || !drop || drop->p != 0.5f || !drop->seed) return GT_EINVAL;
+    const int64_t total = BH * (int64_t)n * ((n + 3) >> 2);
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(dropout_block16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, S, BH, n, make_drop(drop));
+    GT_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int gt_fourier16_presplit(const float* X0, const float* X1, const float* X2, const float* X3, void* I0, void* I1,
@@ -527,9 +615,10 @@ extern "C" int gt_fourier16_presplit(const float* X0, const float* X1, const flo
 
 extern "C" int gt_fourier16_attn(const void* F1, const void* F2, const void* T1, const void* T2, float* O1, float* O2,
                                  int32_t B, int32_t n, int32_t h, int32_t DP, float scale, const float* mask,
-                                 const gt_dropout* drop, int32_t owner_is_key, void* stream) {
+                                 const gt_dropout* drop, int32_t block16, int32_t owner_is_key, void* stream) {
     if (!F1 || !T1 || !T2 || !O1 || B <= 0 || n <= 0 || h <= 0) return GT_EINVAL;
     if (!f16_img_bytes(DP)) return GT_ENOTSUP;
+    if (block16 && drop && drop->p > 0.f && drop->p != 0.5f) return GT_EINVAL;
     const bool dual = F2 != nullptr;
     if (dual && !O2) return GT_EINVAL;
     if (drop && drop->p > 0.f && !drop->seed) return GT_EINVAL;
@@ -548,9 +637,9 @@ extern "C" int gt_fourier16_attn(const void* F1, const void* F2, const void* T1,
     p.scale = scale; p.owner_is_key = owner_is_key;
     hipStream_t st = (hipStream_t)stream;
     switch (DP) {
-        case 20: fourier16_launch<20>(p, dual, st); break;
-        case 36: fourier16_launch<36>(p, dual, st); break;
-        default: fourier16_launch<52>(p, dual, st); break;
+        case 20: fourier16_launch<20>(p, dual, block16 != 0, st); break;
+        case 36: fourier16_launch<36>(p, dual, block16 != 0, st); break;
+        default: fourier16_launch<52>(p, dual, block16 != 0, st); break;
     }
     GT_LAUNCH_CHECK();
     return 0;

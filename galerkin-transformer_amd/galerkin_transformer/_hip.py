@@ -104,7 +104,8 @@ _PROTOS = {
     "gt_fourier16_image_bytes": (C.c_int64, [C.c_int32] * 4),
     "gt_fourier16_presplit": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 4 + [C.c_void_p]),
     "gt_fourier16_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_void_p, C.POINTER(GtDropout),
-                                                                  C.c_int32, C.c_void_p]),
+                                                                  C.c_int32, C.c_int32, C.c_void_p]),
+    "gt_dropout_block16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(GtDropout), C.c_void_p]),
     "gt_dropact_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(GtDropout), C.c_int32, C.POINTER(GtDropout),
                                  C.c_int32, C.c_void_p]),
     "gt_dropact_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(GtDropout), C.c_int32,
@@ -1077,9 +1078,27 @@ def fourier16_presplit(tensors, B: int, n: int, h: int, DP: int):
     return imgs
 
 
+def fourier16_block_mask(drop) -> bool:
+    """The attention-score mask of the fp16 Fourier path is drawn per 4 x 4 block when p = 0.5 (the reference's always-on
+    F.dropout default, layers.py:700-701) -- see gt_hip.h: gt_dropout_block16; any other p keeps one hash per element."""
+    return drop is not None and drop.p == 0.5 and os.environ.get("GT_F16_BLOCK_MASK", "1") != "0"
+
+
+def dropout_block16(S: torch.Tensor, BH: int, n: int, drop) -> torch.Tensor:
+    """In place: S[bh, q, k] *= keep(q, k) / (1 - p) with the block mask of gt_fourier16_attn(block16 = 1)."""
+    need_f32_cuda(S)
+    assert S.is_contiguous() and S.numel() == BH * n * n
+    check(_timed("gt_dropout_block16", 0.0, 8.0 * S.numel(),
+                 lambda: lib().gt_dropout_block16(S.data_ptr(), BH, n, C.byref(drop), stream_ptr())), "gt_dropout_block16")
+    return S
+
+
 def fourier16_attn(F1, F2, T1, T2, B: int, n: int, h: int, DP: int, scale: float, mask, drop, owner_is_key: bool,
-                   O1=None, O2=None):
-    """One pass of gt_fourier16_attn; F1, F2, T1, T2 are image blocks of fourier16_presplit.  Returns O1 (and O2)."""
+                   O1=None, O2=None, block16=None):
+    """One pass of gt_fourier16_attn; F1, F2, T1, T2 are image blocks of fourier16_presplit.  Returns O1 (and O2).
+    block16: draw the dropout mask per 4 x 4 block (default: fourier16_block_mask(drop))."""
+    if block16 is None:
+        block16 = mask is None and fourier16_block_mask(drop)
     dev = T1.device
     if O1 is None:
         O1 = torch.empty(B * n, h, DP, dtype=torch.float32, device=dev)
@@ -1090,8 +1109,9 @@ def fourier16_attn(F1, F2, T1, T2, B: int, n: int, h: int, DP: int, scale: float
     nprod = 2 if F2 is not None else 1
     check(_timed("gt_fourier16_attn", 4.0 * nprod * B * h * n * n * DP, 4.0 * (3 + nprod) * B * n * h * DP,
                  lambda: lib().gt_fourier16_attn(F1.data_ptr(), ptr(F2), T1.data_ptr(), T2.data_ptr(), O1.data_ptr(),
-                                                 ptr(O2), B, n, h, DP, scale, ptr(mask), dp, int(owner_is_key),
-                                                 stream_ptr()), shape=(B, n, h, DP, nprod)), "gt_fourier16_attn")
+                                                 ptr(O2), B, n, h, DP, scale, ptr(mask), dp, int(bool(block16)),
+                                                 int(owner_is_key), stream_ptr()), shape=(B, n, h, DP, nprod)),
+          "gt_fourier16_attn")
     return (O1, O2) if F2 is not None else O1
 
 

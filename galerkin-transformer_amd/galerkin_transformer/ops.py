@@ -885,13 +885,17 @@ class SimpleAttentionFn(Function):
             wpad[:, :, :Dr] = wf.reshape(d, h, Dr)
             wpad = wpad.reshape(d, hD)
             flash = (not need_w) and DP in H.FOURIER_DP
+            # fp16 arithmetic: the p = 0.5 score mask is drawn per 4 x 4 block (one hash per block: gt_hip.h), by the fused
+            # kernels and by the materialising path alike; decided once per forward, the backward follows it
+            blk16 = bool(H.fourier16_active() and d_attn is not None and H.fourier16_block_mask(d_attn))
+            ctx.f16_block = blk16
             if flash:
                 # fused (Q'K'^T * scale .* mask) V': the n x n matrix never reaches HBM
                 if H.fourier16_active():
                     # two-term fp16 kernels: the head tiles are split once into fragment-ordered images, kept for the backward
                     imgs = H.fourier16_presplit((Qp, Kp, Vp), B, n, h, DP)
                     att = H.fourier16_attn(imgs[0], None, imgs[1], imgs[2], B, n, h, DP, scale, mask, d_attn,
-                                           False).reshape(T, hD)
+                                           False, block16=blk16).reshape(T, hD)
                     ctx.f16_imgs = imgs
                 else:
                     att = H.fourier_attn(Qp, None, Kp, Vp, B, n, h, DP, scale, mask, d_attn, False).reshape(T, hD)
@@ -900,9 +904,11 @@ class SimpleAttentionFn(Function):
             else:
                 S = torch.empty(B, h, n, n, dtype=torch.float32, device=dev)
                 H.gemm(Qp, Kp, S, n, n, DP, lda=hD, ldb=hD, ldc=n, batch=(B, h), a_bs=(n * hD, DP),
-                       b_bs=(n * hD, DP), c_bs=(h * n * n, n * n), alpha=scale, drop=d_attn,
+                       b_bs=(n * hD, DP), c_bs=(h * n * n, n * n), alpha=scale, drop=None if blk16 else d_attn,
                        aux_op=H.AUX_MUL if mask is not None else H.AUX_NONE, aux=mask, ldaux=n,
                        aux_bs=(h * n * n, n * n))
+                if blk16:
+                    H.dropout_block16(S, B * h, n, d_attn)
                 att = torch.empty(T, hD, dtype=torch.float32, device=dev)
                 H.gemm(S, Vp, att, n, DP, n, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
                        a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))
@@ -996,17 +1002,22 @@ class SimpleAttentionFn(Function):
                 if imgs is not None:
                     iq, ik, iv = imgs
                     (ido,) = H.fourier16_presplit((datt3,), B, n, h, DP)
-                    H.fourier16_attn(ido, None, iv, ik, B, n, h, DP, scale, mask, d_attn, False, O1=dO3[0])
-                    H.fourier16_attn(ik, iv, iq, ido, B, n, h, DP, scale, mask, d_attn, True, O1=dO3[2], O2=dO3[1])
+                    H.fourier16_attn(ido, None, iv, ik, B, n, h, DP, scale, mask, d_attn, False, O1=dO3[0],
+                                     block16=ctx.f16_block)
+                    H.fourier16_attn(ik, iv, iq, ido, B, n, h, DP, scale, mask, d_attn, True, O1=dO3[2], O2=dO3[1],
+                                     block16=ctx.f16_block)
                 else:
                     H.fourier_attn(datt3, None, Vp, Kp, B, n, h, DP, scale, mask, d_attn, False, O1=dO3[0])
                     H.fourier_attn(Kp, Vp, Qp, datt3, B, n, h, DP, scale, mask, d_attn, True, O1=dO3[2], O2=dO3[1])
             else:
                 dS = torch.empty(B, h, n, n, dtype=torch.float32, device=dev)
+                blk16 = getattr(ctx, "f16_block", False)
                 H.gemm(datt, Vp, dS, n, n, DP, lda=hD, ldb=hD, ldc=n, batch=(B, h), a_bs=(n * hD, DP),
-                       b_bs=(n * hD, DP), c_bs=(h * n * n, n * n), alpha=scale, drop=d_attn,
+                       b_bs=(n * hD, DP), c_bs=(h * n * n, n * n), alpha=scale, drop=None if blk16 else d_attn,
                        aux_op=H.AUX_MUL if mask is not None else H.AUX_NONE, aux=mask, ldaux=n,
                        aux_bs=(h * n * n, n * n))
+                if blk16:
+                    H.dropout_block16(dS, B * h, n, d_attn)
                 # dV' = S^T datt ; dQ' = dS K' ; dK' = dS^T Q'
                 H.gemm(S, datt, dO3[2], n, DP, n, layout_a=1, layout_b=1, lda=n, ldb=hD, ldc=hD, batch=(B, h),
                        a_bs=(h * n * n, n * n), b_bs=(n * hD, DP), c_bs=(n * hD, DP))

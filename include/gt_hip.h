@@ -350,7 +350,15 @@ int gt_fourier16_presplit(const float* X0, const float* X1, const float* X2, con
                           void* I3, int32_t B, int32_t n, int32_t h, int32_t DP, void* stream);
 int gt_fourier16_attn(const void* F1, const void* F2, const void* T1, const void* T2, float* O1, float* O2, int32_t B,
                       int32_t n, int32_t h, int32_t DP, float scale, const float* mask, const gt_dropout* drop,
-                      int32_t owner_is_key, void* stream);
+                      int32_t block16, int32_t owner_is_key, void* stream);
+/* block16 != 0 (p must be 0.5 -- the reference's always-on F.dropout(p_attn), layers.py:700-701): the attention-score mask
+ * is drawn per 4 x 4 block of the [n x n] matrix of each (batch, head): ONE hash per block,
+ *     x = fmix32( (((b h + head) nq4 + (query >> 2)) nq4 + (key >> 2)) * 0x9e3779b1 + key(seed, salt) ),  nq4 = ceil(n / 4),
+ *     keep(query, key) = bit 16 + 4 (query & 3) + (key & 3) of x,
+ * instead of one hash per element (block16 = 0: the index documented at gt_fourier_attn).  gt_dropout_block16 applies the
+ * same mask (and the 1 / (1 - p) rescale) in place to a materialised score matrix S [BH][n][n]: the path that returns the
+ * attention weights runs it behind its score gt_gemm, so both paths draw one mask. */
+int gt_dropout_block16(float* S, int64_t BH, int32_t n, const gt_dropout* drop, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Truncated-DFT stages along the contiguous grid axis of SpectralConv2d (layers.py:1176 rfft2 and :1187

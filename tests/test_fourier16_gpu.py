@@ -45,11 +45,11 @@ def _ref(Q, K, V, dO, B, n, h, DP, scale, mask):
     return back(S @ v), back(dS @ k), back(dS.transpose(-1, -2) @ q), back(S.transpose(-1, -2) @ do)
 
 
-def _run16(H, Q, K, V, dO, B, n, h, DP, scale, mask, drop):
+def _run16(H, Q, K, V, dO, B, n, h, DP, scale, mask, drop, block16=False):
     iq, ik, iv, ido = H.fourier16_presplit((Q, K, V, dO), B, n, h, DP)
-    out = H.fourier16_attn(iq, None, ik, iv, B, n, h, DP, scale, mask, drop, False)
-    dq = H.fourier16_attn(ido, None, iv, ik, B, n, h, DP, scale, mask, drop, False)
-    dv, dk = H.fourier16_attn(ik, iv, iq, ido, B, n, h, DP, scale, mask, drop, True)
+    out = H.fourier16_attn(iq, None, ik, iv, B, n, h, DP, scale, mask, drop, False, block16=block16)
+    dq = H.fourier16_attn(ido, None, iv, ik, B, n, h, DP, scale, mask, drop, False, block16=block16)
+    dv, dk = H.fourier16_attn(ik, iv, iq, ido, B, n, h, DP, scale, mask, drop, True, block16=block16)
     torch.cuda.synchronize()
     return out, dq, dk, dv
 
@@ -91,10 +91,36 @@ def test_fourier16_dropout_draws_the_mask_of_the_fp32_kernel(H, gpu_device, B, n
     scale = 1.0 / math.sqrt(DP - 2) / n
     H.set_seed(991, dev)
     drop = H.dropout_desc(p, 11, dev)
-    got = _run16(H, Q, K, V, dO, B, n, h, DP, scale, None, drop)
+    got = _run16(H, Q, K, V, dO, B, n, h, DP, scale, None, drop, block16=False)
     f32 = _run32(H, Q, K, V, dO, B, n, h, DP, scale, None, drop)
     for name, g, f in zip(("out", "dQ", "dK", "dV"), got, f32):
         assert rel_l2(g, f) < TOL, (name, rel_l2(g, f))
+
+
+@pytest.mark.parametrize("B,n,h,DP", [(2, 200, 4, 36), (1, 77, 4, 20), (2, 131, 2, 52), (1, 5, 2, 36)])
+def test_fourier16_block_mask(H, gpu_device, B, n, h, DP):
+    """block16: the p = 0.5 mask per 4 x 4 block of the score matrix.  gt_dropout_block16 materialises it (applied to a matrix of
+    ones); the three fused passes are held to float64 with exactly that mask; its statistics: half the entries kept, the 16
+    bits of a block uncorrelated."""
+    dev = gpu_device
+    Q, K, V, dO = (t.to(dev) for t in _tiles(B, n, h, DP, seed=11 * n))
+    scale = 1.0 / math.sqrt(DP - 2) / n
+    H.set_seed(77, dev)
+    drop = H.dropout_desc(0.5, 21, dev)
+    mask = H.dropout_block16(torch.ones(B, h, n, n, device=dev), B * h, n, drop)
+    assert set(mask.unique().tolist()) <= {0.0, 2.0}
+    ref = _ref(Q, K, V, dO, B, n, h, DP, scale, mask)
+    got = _run16(H, Q, K, V, dO, B, n, h, DP, scale, None, drop, block16=True)
+    for name, g, r in zip(("out", "dQ", "dK", "dV"), got, ref):
+        assert rel_l2(g, r) < TOL, (name, rel_l2(g, r))
+    if n >= 128:
+        keep = (mask > 0).float()
+        assert abs(float(keep.mean()) - 0.5) < 4.0 / math.sqrt(keep.numel())
+        n4 = n // 4 * 4
+        blocks = keep[..., :n4, :n4].reshape(B * h, n4 // 4, 4, n4 // 4, 4).permute(0, 1, 3, 2, 4).reshape(-1, 16)
+        c = torch.corrcoef(blocks.T.double())
+        off = c - torch.eye(16, device=dev, dtype=torch.float64)
+        assert float(off.abs().max()) < 6.0 / math.sqrt(blocks.shape[0])
 
 
 @pytest.mark.parametrize("scales", [(1e-6, 1e5, 1e-3, 1e8), (1e4, 1e4, 1e4, 1e4), (1e-12, 1e-12, 1e-12, 1e-12)])
@@ -134,11 +160,19 @@ def test_fourier16_time_vs_fp32_kernel(H, gpu_device):
         return e0.elapsed_time(e1) / 5
 
     timed(lambda: _run32(H, Q, K, V, dO, B, n, h, DP, scale, None, drop))          # clocks up
-    t16 = timed(lambda: _run16(H, Q, K, V, dO, B, n, h, DP, scale, None, drop))
+    t16 = timed(lambda: _run16(H, Q, K, V, dO, B, n, h, DP, scale, None, drop, block16=True))
     t32 = timed(lambda: _run32(H, Q, K, V, dO, B, n, h, DP, scale, None, drop))
     imgs = H.fourier16_presplit((Q, K, V, dO), B, n, h, DP)
     tf = timed(lambda: H.fourier16_attn(imgs[0], None, imgs[1], imgs[2], B, n, h, DP, scale, None, drop, False))
     td = timed(lambda: H.fourier16_attn(imgs[1], imgs[2], imgs[0], imgs[3], B, n, h, DP, scale, None, drop, True))
+    tfe = timed(lambda: H.fourier16_attn(imgs[0], None, imgs[1], imgs[2], B, n, h, DP, scale, None, drop, False, block16=False))
+    tde = timed(lambda: H.fourier16_attn(imgs[1], imgs[2], imgs[0], imgs[3], B, n, h, DP, scale, None, drop, True, block16=False))
+    print(f"\nper-element hash (p = 0.5, top-bit shortcut): fwd {tfe:.3f}, dual {tde:.3f}")
     tp = timed(lambda: H.fourier16_presplit((Q, K, V, dO), B, n, h, DP))
+    tfp = timed(lambda: H.fourier16_attn(imgs[0], None, imgs[1], imgs[2], B, n, h, DP, scale, None, None, False))
+    tdp = timed(lambda: H.fourier16_attn(imgs[1], imgs[2], imgs[0], imgs[3], B, n, h, DP, scale, None, None, True))
+    d3 = H.dropout_desc(0.3, 3, dev)
+    tf3 = timed(lambda: H.fourier16_attn(imgs[0], None, imgs[1], imgs[2], B, n, h, DP, scale, None, d3, False))
+    print(f"\nwithout dropout: fwd {tfp:.3f}, dual {tdp:.3f}; p = 0.3 (full hash + compare): fwd {tf3:.3f}")
     print(f"\nfourier B={B} n={n}: f16x2 three passes {t16:.3f} ms (fwd {tf:.3f}, dual {td:.3f}, presplit x4 {tp:.3f}) vs fp32 MFMA {t32:.3f} ms")
     assert t16 < t32
