@@ -26,6 +26,7 @@
 // addends toward -inf -- the dim sign is baked into the "tr" image, the owner sign rides on sigma.
 #include "gt_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace gt {
 
@@ -191,8 +192,12 @@ struct F16P {
 // (profiles/r06c_fourier16_sq_counters.txt) and the per-element hash was 128 of its 200 instructions per tile.
 enum { F16_PLAIN = 0, F16_DROP = 1, F16_DROPH = 2, F16_MASK = 3, F16_DROPB = 4 };
 
-template <int DP, bool DUAL, int MODE>
-__global__ __launch_bounds__(256, DUAL ? 2 : (DP > 36 ? 3 : 4)) void fourier16_kernel(const F16P p) {
+// NW = waves per block (4 or 8): a block owns 32 NW owner rows and all of them share one stream tile in LDS.  The stream images
+// go L2 -> LDS by direct loads and that path saturates near 6.4 TB/s for the chip (MI355X_MICROARCH.md: ldsdma-fill); with
+// 128 owners per tile the C3 passes asked for 4.4 - 5.3 TB/s of it (1.24 GB per launch) and did not get faster without the
+// dropout hash, with 256 owners for half of that.
+template <int DP, bool DUAL, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW, DUAL ? 2 : (DP > 36 ? 3 : 4)) void fourier16_kernel(const F16P p) {
     using G = F16G<DP>;
     constexpr int NM = G::NM, TG = G::TG, NS = G::NS, ND = G::ND;
     constexpr int STAGE = DUAL ? 2 * G::IMG : G::IMG;            // one image of each stream tensor / T1's rm + T2's tr
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256, DUAL ? 2 : (DP > 36 ? 3 : 4)) void fourier16_k
     const int logical = xcd * per + min(xcd, rem) + (wg >> 3);
     const int bh = logical / p.nblk, xblk = logical - bh * p.nblk;
     const int b = bh / p.h, head = bh - b * p.h;
-    const int otile = xblk * 4 + wave;                           // this wave's 32 owner rows
+    const int otile = xblk * NW + wave;                          // this wave's 32 owner rows
     const bool olive = otile < p.ntile;
     const int ot = olive ? otile : p.ntile - 1;
     const int o0 = otile * 32;
@@ -223,8 +228,8 @@ __global__ __launch_bounds__(256, DUAL ? 2 : (DP > 36 ? 3 : 4)) void fourier16_k
         const uint8_t* s1 = p.T1 + p.hdr + (tile0 + t) * G::IMG;
         const uint8_t* s2 = p.T2 + p.hdr + (tile0 + t) * G::IMG + (DUAL ? 0 : G::RM_BYTES);
 #pragma unroll
-        for (int i = 0; i < (NCH + 3) / 4; ++i) {
-            const int q = wave + 4 * i;
+        for (int i = 0; i < (NCH + NW - 1) / NW; ++i) {
+            const int q = wave + NW * i;
             if (q < NCH) {
                 const uint8_t* src = (q < N1 ? s1 + q * 1024 : s2 + (q - N1) * 1024) + lane * 16;
                 __builtin_amdgcn_global_load_lds((f16_glb_ptr_t)src, (f16_lds_ptr_t)(&smem[buf][q * 1024]), 16, 0, 0);
@@ -325,49 +330,6 @@ __global__ __launch_bounds__(256, DUAL ? 2 : (DP > 36 ? 3 : 4)) void fourier16_k
         const uint8_t* st = smem[t & 1];
         const uint8_t* zp = reinterpret_cast<const uint8_t*>(zero_g);
 
-        // first product: score tiles (stream rows x owner columns), 2 row tiles x 2 column tiles per wave
-        f32x4 sa[2][2], sb[DUAL ? 2 : 1][2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                sa[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (DUAL) sb[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const uint8_t* a0;
-                int pl;
-                if (s < NM) {
-                    a0 = st + offm + (mt * 16 * 4 * NM + 4 * s) * 16;
-                    pl = G::MAIN_G * 16;
-                } else {
-                    a0 = st + offt + mt * 16 * TG * 16;
-                    pl = G::TAIL_G * 16;
-                }
-                const uint8_t* pa = (s < NM || tail_ok) ? a0 + OFF_T1RM : zp;
-                const ff16x8 ah = *reinterpret_cast<const ff16x8*>(pa);
-                const ff16x8 al = *reinterpret_cast<const ff16x8*>((s < NM || tail_ok) ? pa + pl : zp);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) sa[mt][nt] = f16_mma3(ah, al, f1h[nt][s], f1l[nt][s], sa[mt][nt]);
-                if (DUAL) {
-                    const uint8_t* pb = (s < NM || tail_ok) ? a0 + OFF_T2RM : zp;
-                    const ff16x8 bh = *reinterpret_cast<const ff16x8*>(pb);
-                    const ff16x8 bl = *reinterpret_cast<const ff16x8*>((s < NM || tail_ok) ? pb + pl : zp);
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) sb[mt][nt] = f16_mma3(bh, bl, f2h[nt][s], f2l[nt][s], sb[mt][nt]);
-                }
-            }
-        }
-        // The score phase reads the MFMA results from inline asm (f16_mulsplit_pair), and hipcc's hazard recogniser does not
-        // look into inline asm: without this the first v_fma_mix* after the last MFMA read stale registers (measured: 2.9e-5
-        // instead of 3e-7).  An 8-pass MFMA result needs 11 wait states before a VALU access; all score registers pass
-        // through this statement, so every MFMA above has issued before it and every reader below comes after it.
-        if (DUAL)
-            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(sa[0][0]), "+v"(sa[0][1]), "+v"(sa[1][0]), "+v"(sa[1][1]), "+v"(sb[0][0]),
-                         "+v"(sb[0][1]), "+v"(sb[DUAL ? 1 : 0][0]), "+v"(sb[DUAL ? 1 : 0][1]));
-        else
-            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(sa[0][0]), "+v"(sa[0][1]), "+v"(sa[1][0]), "+v"(sa[1][1]));
         // running exponents (wave-uniform integer arithmetic) and the score multipliers
         float sigA, sigB = 0.f;
         {
@@ -402,45 +364,111 @@ __global__ __launch_bounds__(256, DUAL ? 2 : (DP > 36 ? 3 : 4)) void fourier16_k
             }
             sigB = osign * f16_pow2(EB - e2 - ef2 - e1);
         }
+        // keep masks of this tile's score elements (dropout modes), in front of the first product in program order: they do
+        // not depend on it, and the sched_group_barrier sequence behind the product interleaves them with its MFMAs
+        // (a wave's own VALU under its own matrix instructions; the score phase is issue-bound)
+        uint32_t km[2][8];
+        constexpr bool HASHED = MODE == F16_DROP || MODE == F16_DROPH || MODE == F16_DROPB;
+        if (HASHED) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                uint32_t hk = hw[nt];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    if (MODE == F16_DROPB) {
+                        // bits 16..31 of the finaliser do not depend on its last step x ^= x >> 16
+                        uint32_t xb = hk;
+                        xb ^= xb >> 16; xb *= 0x85ebca6bu; xb ^= xb >> 13; xb *= 0xc2b2ae35u;
+                        hk += 4u * hstep;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) km[nt][4 * mt + r] = (uint32_t)__builtin_amdgcn_sbfe((int32_t)xb, bpos[r], 1u);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            uint32_t x = hk;
+                            x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u;
+                            if (MODE == F16_DROPH) {
+                                // the finaliser's last step x ^= x >> 16 leaves the top 16 bits alone and the threshold
+                                // has no bits below them: keep <=> top bit
+                                km[nt][4 * mt + r] = (uint32_t)((int32_t)x >> 31);
+                            } else {
+                                x ^= x >> 16;
+                                km[nt][4 * mt + r] = x >= p.drop.thresh ? 0xffffffffu : 0u;
+                            }
+                            hk += hstep;
+                        }
+                        hk += 12u * hstep;
+                    }
+                }
+                hw[nt] = hk;                                      // advanced by 32 stream rows (8 blocks)
+            }
+        }
+
+        // first product: score tiles (stream rows x owner columns), 2 row tiles x 2 column tiles per wave
+        f32x4 sa[2][2], sb[DUAL ? 2 : 1][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                sa[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (DUAL) sb[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint8_t* a0;
+                int pl;
+                if (s < NM) {
+                    a0 = st + offm + (mt * 16 * 4 * NM + 4 * s) * 16;
+                    pl = G::MAIN_G * 16;
+                } else {
+                    a0 = st + offt + mt * 16 * TG * 16;
+                    pl = G::TAIL_G * 16;
+                }
+                const uint8_t* pa = (s < NM || tail_ok) ? a0 + OFF_T1RM : zp;
+                const ff16x8 ah = *reinterpret_cast<const ff16x8*>(pa);
+                const ff16x8 al = *reinterpret_cast<const ff16x8*>((s < NM || tail_ok) ? pa + pl : zp);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) sa[mt][nt] = f16_mma3(ah, al, f1h[nt][s], f1l[nt][s], sa[mt][nt]);
+                if (DUAL) {
+                    const uint8_t* pb = (s < NM || tail_ok) ? a0 + OFF_T2RM : zp;
+                    const ff16x8 bh = *reinterpret_cast<const ff16x8*>(pb);
+                    const ff16x8 bl = *reinterpret_cast<const ff16x8*>((s < NM || tail_ok) ? pb + pl : zp);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) sb[mt][nt] = f16_mma3(bh, bl, f2h[nt][s], f2l[nt][s], sb[mt][nt]);
+                }
+            }
+        }
+        if (HASHED) {
+            constexpr int NMF = 12 * NS * (DUAL ? 2 : 1), NVA = MODE == F16_DROPB ? 40 : 16 * 7;
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, (NVA + NMF - 1) / NMF, 0);    // its share of the mask VALU
+            }
+        }
+        // The score phase reads the MFMA results from inline asm (f16_mulsplit_pair), and hipcc's hazard recogniser does not
+        // look into inline asm: without this the first v_fma_mix* after the last MFMA read stale registers (measured: 2.9e-5
+        // instead of 3e-7).  An 8-pass MFMA result needs 11 wait states before a VALU access; all score registers pass
+        // through this statement, so every MFMA above has issued before it and every reader below comes after it.
+        if (DUAL)
+            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(sa[0][0]), "+v"(sa[0][1]), "+v"(sa[1][0]), "+v"(sa[1][1]), "+v"(sb[0][0]),
+                         "+v"(sb[0][1]), "+v"(sb[DUAL ? 1 : 0][0]), "+v"(sb[DUAL ? 1 : 0][1]));
+        else
+            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(sa[0][0]), "+v"(sa[0][1]), "+v"(sa[1][0]), "+v"(sa[1][1]));
         // mask, scale, split: element (stream row 32 t + 16 mt + 4 kq + r, owner column o0 + 16 nt + j).  Rows / columns
         // beyond n hold exact zeros (zero image rows, zeroed owner fragments), whatever the mask says.
         ff16x8 ph[2], pl_[2], qh[DUAL ? 2 : 1], ql[DUAL ? 2 : 1];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float va[8], vb[8], wa[8], wb[8];                       // score values and their multipliers
-            uint32_t hk = hw[nt];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                uint32_t xb = 0u;
-                if (MODE == F16_DROPB) {
-                    // bits 16..31 of the finaliser do not depend on its last step x ^= x >> 16
-                    xb = hk;
-                    xb ^= xb >> 16; xb *= 0x85ebca6bu; xb ^= xb >> 13; xb *= 0xc2b2ae35u;
-                    hk += 4u * hstep;
-                }
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float ma = sigA, mb = sigB;
-                    if (MODE == F16_DROPB) {
-                        const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int32_t)xb, bpos[r], 1u);
-                        ma = __uint_as_float(__float_as_uint(sigA) & km);
-                        if (DUAL) mb = __uint_as_float(__float_as_uint(sigB) & km);
-                    } else if (MODE == F16_DROP || MODE == F16_DROPH) {
-                        uint32_t x = hk;
-                        x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u;
-                        if (MODE == F16_DROPH) {
-                            // the finaliser's last step x ^= x >> 16 leaves the top 16 bits alone and the threshold has
-                            // no bits below them: keep <=> top bit
-                            const uint32_t km = (uint32_t)((int32_t)x >> 31);
-                            ma = __uint_as_float(__float_as_uint(sigA) & km);
-                            if (DUAL) mb = __uint_as_float(__float_as_uint(sigB) & km);
-                        } else {
-                            x ^= x >> 16;
-                            const bool keep = x >= p.drop.thresh;
-                            ma = keep ? sigA : 0.f;
-                            if (DUAL) mb = keep ? sigB : 0.f;
-                        }
-                        hk += hstep;
+                    if (HASHED) {
+                        ma = __uint_as_float(__float_as_uint(sigA) & km[nt][4 * mt + r]);
+                        if (DUAL) mb = __uint_as_float(__float_as_uint(sigB) & km[nt][4 * mt + r]);
                     } else if (MODE == F16_MASK) {
                         const int sr = min(32 * t + 16 * mt + 4 * kq + r, p.n - 1), ow = min(o0 + 16 * nt + j, p.n - 1);
                         const int qi = p.owner_is_key ? sr : ow, ki = p.owner_is_key ? ow : sr;
@@ -455,9 +483,6 @@ __global__ __launch_bounds__(256, DUAL ? 2 : (DP > 36 ? 3 : 4)) void fourier16_k
                         wb[4 * mt + r] = mb;
                     }
                 }
-                if (MODE != F16_DROPB) hk += 12u * hstep;
-            }
-            hw[nt] = hk;                                          // advanced by 32 stream rows (8 blocks)
             uint32_t hi[4], lo[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) f16_mulsplit_pair(va[2 * e], wa[2 * e], va[2 * e + 1], wa[2 * e + 1], hi[e], lo[e]);
@@ -511,13 +536,13 @@ __global__ __launch_bounds__(256, DUAL ? 2 : (DP > 36 ? 3 : 4)) void fourier16_k
     }
 }
 
-template <int DP>
-static void fourier16_launch(const F16P& p, bool dual, bool block16, hipStream_t st) {
+template <int DP, int NW>
+static void fourier16_launch_nw(const F16P& p, bool dual, bool block16, hipStream_t st) {
     int mode = F16_PLAIN;
     if (p.mask) mode = F16_MASK;
     else if (p.drop.thresh) mode = block16 ? F16_DROPB : ((p.drop.thresh & 0xffffu) ? F16_DROP : F16_DROPH);
     const dim3 grid((unsigned)p.total);
-#define GT_F16(D, M) hipLaunchKernelGGL((fourier16_kernel<DP, D, M>), grid, dim3(256), 0, st, p)
+#define GT_F16(D, M) hipLaunchKernelGGL((fourier16_kernel<DP, D, M, NW>), grid, dim3(64 * NW), 0, st, p)
     if (dual) {
         if (mode == F16_DROPB) GT_F16(true, F16_DROPB);
         else if (mode == F16_DROPH) GT_F16(true, F16_DROPH);
@@ -532,6 +557,23 @@ static void fourier16_launch(const F16P& p, bool dual, bool block16, hipStream_t
         else GT_F16(false, F16_PLAIN);
     }
 #undef GT_F16
+}
+
+// waves per block: 8 when that still leaves at least ~2 blocks per CU's worth of work (halves the image traffic), else 4
+// Measured at C3's layer shape (B = 8, n = 3721; tests/test_fourier16_gpu.py -k time): forward 0.247 ms with 8 waves per block
+// vs 0.271 with 4; the dual pass (2 waves per SIMD) 0.586 vs 0.546 -- it keeps 4.
+static int f16_pick_nw(int64_t BH, int ntile, bool dual) {
+    if (const char* e = getenv("GT_F16_NW")) { const int v = atoi(e); if (v == 4 || v == 8) return v; }
+    return (!dual && ntile >= 16 && BH * ((ntile + 7) / 8) >= 384) ? 8 : 4;
+}
+
+template <int DP>
+static void fourier16_launch(F16P& p, bool dual, bool block16, int64_t BH, hipStream_t st) {
+    const int nw = f16_pick_nw(BH, p.ntile, dual);
+    p.nblk = ceil_div(p.ntile, nw);
+    p.total = (int)(BH * p.nblk);
+    if (nw == 8) fourier16_launch_nw<DP, 8>(p, dual, block16, st);
+    else fourier16_launch_nw<DP, 4>(p, dual, block16, st);
 }
 
 static int64_t f16_hdr_bytes(int64_t BH, int ntile) { return (BH * ntile * 8 + 1023) / 1024 * 1024; }
@@ -629,17 +671,15 @@ extern "C" int gt_fourier16_attn(const void* F1, const void* F2, const void* T1,
     p.F1 = static_cast<const uint8_t*>(F1); p.F2 = static_cast<const uint8_t*>(F2);
     p.T1 = static_cast<const uint8_t*>(T1); p.T2 = static_cast<const uint8_t*>(T2);
     p.O1 = O1; p.O2 = O2; p.mask = mask; p.drop = make_drop(mask ? nullptr : drop);
-    p.n = n; p.h = h; p.ntile = ceil_div(n, 32); p.nblk = ceil_div(p.ntile, 4);
-    const int64_t total = (int64_t)B * h * p.nblk;
-    if (total > 0x7fffffff) return GT_EINVAL;
-    p.total = (int)total;
+    p.n = n; p.h = h; p.ntile = ceil_div(n, 32);
+    if ((int64_t)B * h * ceil_div(p.ntile, 4) > 0x7fffffff) return GT_EINVAL;
     p.hdr = f16_hdr_bytes((int64_t)B * h, p.ntile);
     p.scale = scale; p.owner_is_key = owner_is_key;
     hipStream_t st = (hipStream_t)stream;
     switch (DP) {
-        case 20: fourier16_launch<20>(p, dual, block16 != 0, st); break;
-        case 36: fourier16_launch<36>(p, dual, block16 != 0, st); break;
-        default: fourier16_launch<52>(p, dual, block16 != 0, st); break;
+        case 20: fourier16_launch<20>(p, dual, block16 != 0, (int64_t)B * h, st); break;
+        case 36: fourier16_launch<36>(p, dual, block16 != 0, (int64_t)B * h, st); break;
+        default: fourier16_launch<52>(p, dual, block16 != 0, (int64_t)B * h, st); break;
     }
     GT_LAUNCH_CHECK();
     return 0;
