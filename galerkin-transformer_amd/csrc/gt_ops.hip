@@ -483,8 +483,10 @@ __global__ __launch_bounds__(256, 2) void galerkin_dkv_kernel(const DkvP p) {
             a2[mt][s] = live * dm[k * DP + cc];
         }
     }
-    const int ntile = (p.n + 15) >> 4;
-    for (int tile = wave; tile < ntile; tile += 4) {
+    // token tiles of this (batch, head) are shared out over gridDim.y blocks (ex4: B h = 16 would leave 240 CUs idle)
+    const int ntile = (p.n + 15) >> 4, per = (ntile + gridDim.y - 1) / gridDim.y;
+    const int tend = min(ntile, (int)(blockIdx.y + 1) * per);
+    for (int tile = blockIdx.y * per + wave; tile < tend; tile += 4) {
         const int t = 16 * tile + j, tc = min(t, p.n - 1);
         const float* kr = p.Kp + base + (int64_t)tc * hD;
         const float* vr = p.Vp + base + (int64_t)tc * hD;
@@ -1032,25 +1034,37 @@ __global__ __launch_bounds__(256) void galerkin_ktv_lds_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------ galerkin finalize
+// One block per (batch, head, group of FIN_RB rows of M): row j of P needs row j of M only.  (Round 5: one block per
+// (batch, head) walked the whole 52 x 52 matrix with n_slabs dependent loads per element -- 178 us at ex4's 16 x 64 slabs.)
+constexpr int FIN_RB = 4;
 __global__ __launch_bounds__(256) void galerkin_fin_fwd_kernel(
     const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int h, int DP, int Dr, int d,
     float inv_n, const float* __restrict__ mask, DropDev drop, const float* __restrict__ Wfc,
     float* __restrict__ Mt, float* __restrict__ P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sM = lds;               // [DP][DP]
-    float* sW = lds + DP * DP;     // [d][Dr]
+    float* sM = lds;                    // [FIN_RB][DP]
+    float* sW = lds + FIN_RB * DP;      // [d][Dr]
     const int bh = blockIdx.x, b = bh / h, hh = bh % h;
+    const int j0 = blockIdx.y * FIN_RB, nr = min(FIN_RB, DP - j0);
     const uint32_t key = drop_key_dev(drop);
     const int64_t mo = (int64_t)bh * DP * DP;
-    for (int e = threadIdx.x; e < DP * DP; e += blockDim.x) {
-        const int j = e / DP, c = e % DP;
-        float s = 0.f;
-        for (int k = 0; k < n_slabs; ++k) s += slabs[k * slab_stride + mo + e];
+    for (int le = threadIdx.x; le < nr * DP; le += blockDim.x) {
+        const int e = j0 * DP + le, j = e / DP, c = e % DP;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;           // four independent chains: the loads overlap
+        int k = 0;
+        for (; k + 4 <= n_slabs; k += 4) {
+            s0 += slabs[(k + 0) * slab_stride + mo + e];
+            s1 += slabs[(k + 1) * slab_stride + mo + e];
+            s2 += slabs[(k + 2) * slab_stride + mo + e];
+            s3 += slabs[(k + 3) * slab_stride + mo + e];
+        }
+        for (; k < n_slabs; ++k) s0 += slabs[k * slab_stride + mo + e];
+        const float s = (s0 + s1) + (s2 + s3);
         float mul = inv_n;
         if (mask) mul *= mask[mo + e];
         else if (drop.thresh) mul *= drop_mul(drop, key, (uint32_t)(mo + e));
         const float v = (j < Dr && c < Dr) ? s * mul : 0.f;
-        sM[e] = v;
+        sM[le] = v;
         Mt[mo + e] = v;
     }
     for (int e = threadIdx.x; e < d * Dr; e += blockDim.x) {
@@ -1059,15 +1073,15 @@ __global__ __launch_bounds__(256) void galerkin_fin_fwd_kernel(
     }
     __syncthreads();
     float* Pb = P + ((int64_t)b * h * DP + (int64_t)hh * DP) * d;
-    for (int e = threadIdx.x; e < DP * d; e += blockDim.x) {
-        const int j = e / d, c = e % d;
+    for (int le = threadIdx.x; le < nr * d; le += blockDim.x) {
+        const int jl = le / d, c = le % d, j = j0 + jl;
         float acc = 0.f;
         if (j < Dr) {
-            const float* mr = sM + j * DP;
+            const float* mr = sM + jl * DP;
             const float* wr = sW + c * Dr;
             for (int ee = 0; ee < Dr; ++ee) acc = fmaf(mr[ee], wr[ee], acc);
         }
-        Pb[e] = acc;
+        Pb[(int64_t)j * d + c] = acc;
     }
 }
 
@@ -1483,7 +1497,9 @@ extern "C" int gt_galerkin_dkv(const float* Kp, const float* Vp, const float* dM
          reinterpret_cast<uintptr_t>(dVp)) & 15)
         return GT_EALIGN;
     DkvP p{Kp, Vp, dM, dKp, dVp, n, h};
-    dim3 grid((unsigned)(B * h));
+    const int ntile = (n + 15) / 16;
+    const int chunks = std::max(1, std::min({(1024 + B * h - 1) / (B * h), (ntile + 7) / 8, 65535}));
+    dim3 grid((unsigned)(B * h), (unsigned)chunks);
     hipStream_t st = (hipStream_t)stream;
     if (DP == 20) hipLaunchKernelGGL(galerkin_dkv_kernel<1>, grid, dim3(256), 0, st, p);
     else if (DP == 36) hipLaunchKernelGGL(galerkin_dkv_kernel<2>, grid, dim3(256), 0, st, p);
@@ -1553,9 +1569,9 @@ extern "C" int gt_galerkin_finalize_fwd(const float* slabs, int32_t n_slabs, int
         n_tokens <= 0)
         return GT_EINVAL;
     if (drop && drop->p > 0.f && !drop->seed) return GT_EINVAL;
-    const size_t lds = ((size_t)DP * DP + (size_t)d * Dr) * sizeof(float);
+    const size_t lds = ((size_t)FIN_RB * DP + (size_t)d * Dr) * sizeof(float);
     if (int rc = allow_big_lds(galerkin_fin_fwd_kernel, lds)) return rc;
-    hipLaunchKernelGGL(galerkin_fin_fwd_kernel, dim3(B * h), dim3(256), lds, (hipStream_t)stream, slabs,
+    hipLaunchKernelGGL(galerkin_fin_fwd_kernel, dim3(B * h, (DP + FIN_RB - 1) / FIN_RB), dim3(256), lds, (hipStream_t)stream, slabs,
                        n_slabs, slab_stride, h, DP, Dr, d, 1.f / (float)n_tokens, mask,
                        make_drop(mask ? nullptr : drop), Wfc, Mt, P);
     GT_LAUNCH_CHECK();
