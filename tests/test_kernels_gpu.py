@@ -265,7 +265,7 @@ def test_galerkin_finalize(H, gpu_device, B, h, dk, p, d, use_mask):
 
 def test_layernorm(H, gpu_device):
     dev = gpu_device
-    for T, d in ((1000, 48), (517, 128), (64, 200)):
+    for T, d in ((1000, 48), (517, 128), (64, 200), (70001, 48), (33, 64), (5, 4), (4099, 20)):   # d <= 64: narrow-row kernels
         x = rnd(T, d, dev=dev, seed=31)
         g, b = 1 + 0.1 * rnd(d, dev=dev, seed=32), 0.1 * rnd(d, dev=dev, seed=33)
         y, st = H.layernorm_fwd(x, g, b, 1e-5)
