@@ -4,14 +4,15 @@
 layers on the 43x43 coarse grid, two SpectralConv2d decoder layers at 141x141).
 
     python bench.py --gpus N --steps K --warmup W [--batch B_per_gpu] [--scaling weak|strong --global-batch G]
-                    [--workload ...] [--loss mse|weighted_l2] [--precision bf16x3|f32|bf16x2|bf16]
+                    [--workload ...] [--loss mse|weighted_l2] [--precision f16x2|bf16x3|f32|bf16x2|bf16]
 
 A step = forward + loss + backward + (gradient all-reduce) + clip_grad_norm_(0.99) + Adam on one batch of
 synthetic tensors already resident in HBM (the recipe of the reference's examples/ex2_memory_profile.py:58-71
 plus the optimizer of examples/ex2_darcy.py).  Every dropout of config.yml is active (train mode), including
 the reference's always-on p=0.5 attention dropout.  Operands, accumulators and results are fp32; the contractions
-run in the library's default arithmetic (``bf16x3``: fp32 operands split exactly into three bf16 terms, six plane
-products on the bf16 MFMA pipe, fp32 accumulation -- the mode the 1e-5 parity tests run in); ``--precision f32``
+run in the library's default arithmetic (``f16x2``: every fp32 operand value as two fp16 terms under an in-kernel
+power-of-two scale, three products on the f16 MFMA pipe, fp32 accumulation -- the mode the 1e-5 parity tests run in;
+``bf16x3`` = three bf16 terms / six products, the default of rounds 2-3, is still selectable); ``--precision f32``
 selects the bit-exact fp32 MFMA kernels, and the default run reports both.
 
 One process per GPU (launched by torch.distributed.run for N>1), batch-sharded data parallel: the per-GPU batch is
@@ -321,7 +322,10 @@ def timed_run(tr, steps, warmup, world):
     return elapsed
 
 
-def roofline_leg(trainer, precision):
+FOURIER_KEYS = ("gt_fourier16_attn", "gt_fourier_attn")
+
+
+def roofline_leg(trainer, precision, workload="ex2_darcy141"):
     """Per-launch HIP-event timing of one eager step, then the dominant hot-path kernel re-timed back-to-back on the
     launch stream; plus the per-leg table (head norm, K^T V, FFN, Q.P) the north star asks for."""
     from galerkin_transformer import _hip
@@ -338,9 +342,9 @@ def roofline_leg(trainer, precision):
     trainer.shape_table = prof.table(by_shape=True)
     # dominant kernel of the hand-written path = the GEMM template instance with the largest share of
     # the step; within it, the launch shape that accounts for most of that time
-    gemm_keys = [k for k in table if k.startswith("gemm_")]
+    gemm_keys = [k for k in table if k.startswith("gemm_") or k in FOURIER_KEYS]
     dom = max(gemm_keys, key=lambda k: table[k]["ms"])
-    recs = [r for r in prof.records if r[0] == dom and r[5] is not None]
+    recs = [r for r in prof.records if r[0] == dom and (r[5] is not None or dom in FOURIER_KEYS)]
     by_shape, n_shape = {}, {}
     for r in recs:
         by_shape[r[6]] = by_shape.get(r[6], 0.0) + r[3].elapsed_time(r[4])
@@ -364,19 +368,21 @@ def roofline_leg(trainer, precision):
         k[1] += r[3].elapsed_time(r[4])
     launch_kinds = [dict(algorithmic_bytes=b, launches=n, avg_launch_us=round(ms / n * 1e3, 2),
                          hbm_gbs=round(b / (ms / n * 1e-3) / 1e9, 1)) for b, (n, ms) in sorted(kinds.items())]
-    call, _keep = best[5]
-    reps = 50
-    for _ in range(3):
-        call()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        call()
-    e1.record()
-    torch.cuda.synchronize()
-    replay_s = e0.elapsed_time(e1) / reps * 1e-3
-    x3 = "x3" in dom
-    products = PLANE_PRODUCTS.get(precision, 1) if x3 else 1
+    replay_s = None
+    if best[5] is not None:
+        call, _keep = best[5]
+        reps = 50
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        replay_s = e0.elapsed_time(e1) / reps * 1e-3
+    x3 = "x3" in dom or dom == "gt_fourier16_attn"
+    products = (3 if dom == "gt_fourier16_attn" else PLANE_PRODUCTS.get(precision, 1)) if x3 else 1
     peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
     useful = mean_flops / dur_s / 1e12                   # 2 M N K per launch: what the caller asked for
     executed = useful * products                         # flops the matrix pipe actually retires
@@ -386,24 +392,36 @@ def roofline_leg(trainer, precision):
     # HBM traffic of this kernel + launch shape from the rocprofv3 --pmc passes (tools/gpu_pmc.sh), when a
     # measurement for exactly this launch is on file under profiles/
     traffic, tsrc = None, None
+    kernel_symbol = "gt::" + dom.replace("+splitk", "")
+    pmc_file = "pmc_step.json" if workload == "ex2_darcy141" else f"pmc_step_{workload}.json"
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_step.json")) as f:
+        with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pj = json.load(f)
-        # one launch geometry of the symbol: the split-operand kernels run 256 threads per 128 x 128 output tile
-        Ms, Ns = best[6][0], best[6][1]
-        grid = -(-Ms // 128) * -(-Ns // 128) * 256 * best[6][3]
-        rec = pj.get("_by_grid", {}).get(f"gt::{dom.replace('+splitk', '')}|{grid}") if x3_name(dom) else None
+        rec, grid = None, None
+        if dom in FOURIER_KEYS:
+            # the template instance of this head-tile width and pass kind (single score / dual), whatever its mask mode
+            want = f"{'fourier16' if dom == 'gt_fourier16_attn' else 'fourier_core'}_kernel<"
+            dual = "true" if best[6][4] == 2 else "false"
+            cands = [k for k in pj if k.startswith("gt::" + want) and f", {dual}," in k]
+            if cands:
+                kernel_symbol = max(cands, key=lambda k: pj[k].get("calls_seen", 0))
+                rec = pj[kernel_symbol]
+        elif x3_name(dom):
+            # one launch geometry of the symbol: the split-operand kernels run 256 threads per 128 x 128 output tile
+            Ms, Ns = best[6][0], best[6][1]
+            grid = -(-Ms // 128) * -(-Ns // 128) * 256 * best[6][3]
+            rec = pj.get("_by_grid", {}).get(f"gt::{dom.replace('+splitk', '')}|{grid}")
         if rec and "read_bytes" in rec and "write_bytes" in rec:
             traffic = int(rec["read_bytes"] + rec["write_bytes"])
-            tsrc = (pj.get("_source", "") + f"; the {rec['calls_seen']} launches of this symbol with grid size {grid} "
-                    "(every launch of this output shape in the step, averaged)")
+            tsrc = (pj.get("_source", "") + f"; the {rec['calls_seen']} launches of this symbol" +
+                    (f" with grid size {grid}" if grid else "") + " (every launch of this shape in the profiled steps, averaged)")
     except (OSError, ValueError):
         pass
-    roof = dict(bound=bound, kernel="gt::" + dom.replace("+splitk", ""), launch_shape_MNKb=list(best[6]),
+    roof = dict(bound=bound, kernel=kernel_symbol, launch_shape_MNKb=list(best[6]),
                 includes_splitk_reduce=dom.endswith("+splitk"), launches_per_step=len(recs),
                 share_of_hip_path=round(table[dom]["ms"] / sum(v["ms"] for v in table.values()), 3),
                 avg_launch_us=round(dur_s * 1e6, 2), launches_of_this_shape=n_shape[top_shape],
-                replay_back_to_back_us=round(replay_s * 1e6, 2),
+                replay_back_to_back_us=(round(replay_s * 1e6, 2) if replay_s else None),
                 # all launch shapes of this kernel symbol in one step (what a profiler's per-kernel average mixes)
                 symbol_avg_launch_us_all_shapes=round(table[dom]["ms"] / table[dom]["calls"] * 1e3, 2),
                 achieved=round(executed if bound == "mfma" else hbm, 2),
@@ -421,47 +439,77 @@ def roofline_leg(trainer, precision):
     # of the same kernel symbol from the rocprofv3 --pmc passes on file (profiles/pmc_step.json: FETCH_SIZE doubled
     # for gfx950, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES in separate passes -- tools/gpu_measure.sh, tools/pmc_to_json.py)
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_step.json")) as f:
+        with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
     except (OSError, ValueError):
         pmc = {}
+    if traffic and kernel_symbol in pmc and "mfma_util_at_2.4GHz" in pmc[kernel_symbol]:
+        roof["mfma"]["busy_frac_profiled_pass"] = round(pmc[kernel_symbol]["mfma_util_at_2.4GHz"], 3)
     legs = {}
     pk = "gemm_x3h_kernel" if precision == "f16x2" else "gemm_x3p_kernel"     # the packed-B instances of the arithmetic
-    for label, key, sym in ((l, k.replace("gemm_x3p_kernel", pk), s_.replace("gemm_x3p_kernel", pk)) for l, k, s_ in LEGS):
-        t = table.get(key) or table.get(key.replace("+splitk", ""))
-        if not t or t["ms"] <= 0:
-            continue
-        us = t["ms"] / t["calls"] * 1e3
-        leg = dict(us=round(us, 1), launches=t["calls"])
-        if t["flops"] > 0:
-            leg["useful_tflops"] = round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2)
-        c = pmc.get(sym)
-        if c and "read_bytes" in c and "write_bytes" in c:
-            by = c["read_bytes"] + c["write_bytes"]
-            leg.update(hbm_bytes_per_launch=int(by), hbm_gbs=round(by / us / 1e3, 1),
-                       hbm_frac=round(by / us / 1e3 / PEAK_HBM_GBS, 4))
-            if "mfma_util_at_2.4GHz" in c:
-                leg["mfma_busy_frac_profiled_pass"] = round(c["mfma_util_at_2.4GHz"], 3)
-        legs[label] = leg
+    shape_rows = prof.table(by_shape=True)
+    for label, key, sym, pred in LEGS:
+        key, sym = key.replace("gemm_x3p_kernel", pk), sym.replace("gemm_x3p_kernel", pk)
+        leg = leg_record(table, shape_rows, pmc, key, sym, pred)
+        if leg:
+            legs[label] = leg
     roof["legs"] = legs
     return roof, table
 
 
-# roofline legs: label, key of the HIP-event table (_hip.Profile), kernel symbol in profiles/pmc_step.json
-# (tests/test_host_cpu.py checks that every symbol named here exists in that file)
-LEGS = (("qkv_proj+headnorm_fwd", "gemm_x3p_kernel<0, 32, 0, 128>", "gt::gemm_x3p_kernel<0, 32, 0, 128>"),
-        ("headnorm_fwd", "gt_headnorm_fwd", "gt::headnorm_fwd_v2_kernel"),
-        ("headnorm_bwd", "gt_headnorm_bwd", "gt::headnorm_bwd_v2_kernel"),
-        ("galerkin_ktv", "gt_galerkin_ktv", "gt::galerkin_ktv_lds_kernel<2>"),
-        ("galerkin_dkv", "gt_galerkin_dkv", "gt::galerkin_dkv_kernel<2>"),
-        ("galerkin_dkv+headnorm_bwd", "gt_galerkin_dkv_ln", "gt::galerkin_dkv_ln_kernel<2, true>"),
-        ("galerkin_qp(Q'.P with fc folded)", "gemm_x3r_kernel<0, 1, 3, 3, 0, 0>", "gt::gemm_x3r_kernel<0, 1, 3, 3, 0, 0>"),
-        ("token_gemms(packed B)", "gemm_x3p_kernel<0, 0, 0, 128>", "gt::gemm_x3p_kernel<0, 0, 0, 128>"),
-        ("conv3x3_implicit", "gemm_x3p_kernel<0, 0, 1, 128>", "gt::gemm_x3p_kernel<0, 0, 1, 128>"),
-        ("conv3x3_implicit_narrow(down-scaler)", "gemm_x3p_kernel<0, 0, 1, 64>", "gt::gemm_x3p_kernel<0, 0, 1, 64>"),
-        ("conv3x3_wgrad(LDS planes)", "gt_conv3x3_wgrad_nhwc", "gt::convw_kernel<4, 2, 1>"),
-        ("weight_gradients(f16x2 planes in LDS)", "gemm_x3w_kernel<2>+splitk", "gt::gemm_x3w_kernel<2>"),
-        ("weight_gradients(ring)", "gemm_x3r_kernel<1, 1, 3, 3, 0, 0>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 0>"))
+def leg_record(table, shape_rows, pmc, key, sym, pred):
+    """One roofline leg: mean HIP-event time of the launches of host entry `key` (only those whose recorded shape satisfies
+    `pred`, when given) and the counter bytes of kernel symbol `sym` from profiles/pmc_step.json.  Time and bytes must be
+    averages over THE SAME launches: a host entry that launches several kernel instances (gt_conv3x3_wgrad_nhwc: one
+    template instance per channel geometry) is split into one leg per instance by `pred` -- round 4's single leg divided the
+    widest instance's bytes by the mean time of four launches of three shapes."""
+    if pred is None:
+        t = table.get(key) or table.get(key.replace("+splitk", ""))
+    else:
+        t = dict(calls=0, ms=0.0, flops=0.0, bytes=0.0)
+        for k, r in shape_rows.items():
+            name, _, shp = k.partition(" (")
+            if name in (key, key.replace("+splitk", "")) and shp and pred(tuple(int(v) for v in shp.rstrip(")").split(",") if v.strip())):
+                for f in t:
+                    t[f] += r[f]
+    if not t or t["calls"] == 0 or t["ms"] <= 0:
+        return None
+    us = t["ms"] / t["calls"] * 1e3
+    leg = dict(us=round(us, 1), launches=t["calls"], kernel=sym)
+    if t["flops"] > 0:
+        leg["useful_tflops"] = round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2)
+    c = pmc.get(sym)
+    if c and "read_bytes" in c and "write_bytes" in c:
+        by = c["read_bytes"] + c["write_bytes"]
+        leg.update(hbm_bytes_per_launch=int(by), hbm_gbs=round(by / us / 1e3, 1), hbm_frac=round(by / us / 1e3 / PEAK_HBM_GBS, 4),
+                   counter_launches_seen=c.get("calls_seen"))
+        if "mfma_util_at_2.4GHz" in c:
+            leg["mfma_busy_frac_profiled_pass"] = round(c["mfma_util_at_2.4GHz"], 3)
+    return leg
+
+
+# roofline legs: label, key of the HIP-event table (_hip.Profile), kernel symbol in profiles/pmc_step.json, and -- where one
+# host entry launches several kernel instances -- a predicate on the launch's recorded shape that selects the launches of
+# THAT symbol (tests/test_host_cpu.py: every symbol exists in the counter file, every hbm_gbs of the committed line is
+# recomputed from the counter file and the per-shape event table)
+LEGS = (("qkv_proj+headnorm_fwd", "gemm_x3p_kernel<0, 32, 0, 128>", "gt::gemm_x3p_kernel<0, 32, 0, 128>", None),
+        ("headnorm_fwd", "gt_headnorm_fwd", "gt::headnorm_fwd_v2_kernel", None),
+        ("headnorm_bwd", "gt_headnorm_bwd", "gt::headnorm_bwd_v2_kernel", None),
+        ("galerkin_ktv", "gt_galerkin_ktv", "gt::galerkin_ktv_lds_kernel<2>", None),
+        ("galerkin_dkv", "gt_galerkin_dkv", "gt::galerkin_dkv_kernel<2>", None),
+        ("galerkin_dkv+headnorm_bwd", "gt_galerkin_dkv_ln", "gt::galerkin_dkv_ln_kernel<2, true>", None),
+        ("galerkin_qp(Q'.P with fc folded)", "gemm_x3r_kernel<0, 1, 3, 3, 0, 0>", "gt::gemm_x3r_kernel<0, 1, 3, 3, 0, 0>", None),
+        ("token_gemms(packed B)", "gemm_x3p_kernel<0, 0, 0, 128>", "gt::gemm_x3p_kernel<0, 0, 0, 128>", None),
+        ("conv3x3_implicit", "gemm_x3p_kernel<0, 0, 1, 128>", "gt::gemm_x3p_kernel<0, 0, 1, 128>", None),
+        ("conv3x3_implicit_narrow(down-scaler)", "gemm_x3p_kernel<0, 0, 1, 64>", "gt::gemm_x3p_kernel<0, 0, 1, 64>", None),
+        # gt_conv3x3_wgrad_nhwc, shape (B, H, W, Cin, Cout): one kernel instance per channel geometry
+        ("conv3x3_wgrad 128->128 (up-scaler)", "gt_conv3x3_wgrad_nhwc", "gt::convw_kernel<4, 2, 1>", lambda sh: sh[3:5] == (128, 128)),
+        ("conv3x3_wgrad 128->48 (down-scaler)", "gt_conv3x3_wgrad_nhwc", "gt::convw_kernel<4, 3, 1>", lambda sh: sh[3:5] == (128, 48)),
+        ("conv3x3_wgrad 48->48 (down-scaler)", "gt_conv3x3_wgrad_nhwc", "gt::convw_kernel<3, 3, 1>", lambda sh: sh[3:5] == (48, 48)),
+        ("weight_gradients(f16x2 planes in LDS)", "gemm_x3w_kernel<2>+splitk", "gt::gemm_x3w_kernel<2>", None),
+        ("weight_gradients(ring)", "gemm_x3r_kernel<1, 1, 3, 3, 0, 0>+splitk", "gt::gemm_x3r_kernel<1, 1, 3, 3, 0, 0>", None),
+        ("fourier_attention(f16x2)", "gt_fourier16_attn", "gt::fourier16_kernel<36, false, 4, 8>", lambda sh: sh[4] == 1),
+        ("fourier_attention_dual(f16x2)", "gt_fourier16_attn", "gt::fourier16_kernel<36, true, 4, 4>", lambda sh: sh[4] == 2))
 
 
 def x3_name(key: str) -> bool:
@@ -631,7 +679,7 @@ def main():
                     help="ex2_darcy141 is the headline metric; the others are informational")
     ap.add_argument("--loss", default="mse", choices=["mse", "weighted_l2"])
     ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16x2", "bf16", "f16x2"],
-                    help="arithmetic of the contractions (default: the library default, bf16x3)")
+                    help="arithmetic of the contractions (default: the library default, f16x2)")
     ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets the "
@@ -701,7 +749,7 @@ def main():
     roof, table = (None, {})
     if rank == 0 and not a.no_roofline:
         try:
-            roof, table = roofline_leg(tr, precision)
+            roof, table = roofline_leg(tr, precision, a.workload)
         except Exception as e:
             print(f"[bench] roofline leg failed: {type(e).__name__}: {e}", file=sys.stderr)
     cpu = None

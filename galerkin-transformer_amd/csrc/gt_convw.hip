@@ -43,6 +43,7 @@
 #include <type_traits>
 
 #include "gt_common.h"
+#include <atomic>
 
 namespace gt {
 
@@ -352,8 +353,9 @@ __device__ __noinline__ void cw_mfma(float* slab, int Cin, int Cout, int ci0, in
     }
 
     // partial result: accumulator register r of lane (li, kq) = (x position 16 i + 4 kq + r, gy position 16 j + li)
-    const int et = -eacc;
-    const float us = F16 ? cw_pow2(et < -126 ? -126 : (et > 126 ? 126 : et)) : 1.f;
+    const int et = -eacc, etc = et < -126 ? -126 : (et > 126 ? 126 : et);
+    const float us = F16 ? cw_pow2(etc) : 1.f;
+    const int erest = F16 ? et - etc : 0;                  // non-zero only for operands ~2^-100 below unit scale
 #pragma unroll
     for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -366,7 +368,8 @@ __device__ __noinline__ void cw_mfma(float* slab, int Cin, int Cout, int ci0, in
                     const int ci = ci0 + cw_chan_of_pos(pa, CI), co = co0 + cw_chan_of_pos(pb, CO);
                     const float sg = ((r + li) & 1) ? -us : us;        // position parities (16 i + 4 kq and 16 j are even)
                     if (ci < Cin && co < Cout)
-                        ((cw_gf32*)slab)[((int64_t)((dy + 1) * 3 + d) * Cin + ci) * Cout + co] = sg * acc[d][i][j][r];
+                        ((cw_gf32*)slab)[((int64_t)((dy + 1) * 3 + d) * Cin + ci) * Cout + co] =
+                            erest ? ldexpf(sg * acc[d][i][j][r], erest) : sg * acc[d][i][j][r];
                 }
 }
 
@@ -448,9 +451,14 @@ static bool cw_plan(int B, int H, int W, int Cin, int Cout, int f16, CwPlan* pl)
 using namespace gt;
 
 extern "C" int64_t gt_conv3x3_wgrad_nhwc_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
-    CwPlan pl;
-    if (!cw_plan(B, H, W, Cin, Cout, 0, &pl)) return 0;    // the slab count does not depend on the arithmetic
-    return (int64_t)B * pl.chunks * 9 * Cin * Cout * (int64_t)sizeof(float);
+    // the row chunks depend on the channel blocks and those on the arithmetic (Cout = 48, Cin % 64 == 0: four input tiles in
+    // fp16, three or two in bf16): the size that serves BOTH plans (the fp16 launch wrote up to ~2x the slabs the
+    // bf16 plan had advertised)
+    CwPlan p0, p1;
+    const bool ok0 = cw_plan(B, H, W, Cin, Cout, 0, &p0), ok1 = cw_plan(B, H, W, Cin, Cout, 1, &p1);
+    if (!ok0 && !ok1) return 0;
+    const int chunks = std::max(ok0 ? p0.chunks : 0, ok1 ? p1.chunks : 0);
+    return (int64_t)B * chunks * 9 * Cin * Cout * (int64_t)sizeof(float);
 }
 
 extern "C" int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* x, int64_t ldx, float* dw, int32_t B,
@@ -461,19 +469,23 @@ extern "C" int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* 
     CwPlan pl;
     if (!cw_plan(B, H, W, Cin, Cout, precision == GT_PREC_F16X2, &pl)) return GT_ENOTSUP;
     if (((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(x)) & 15) || (ldg & 3) || (ldx & 3)) return GT_EALIGN;
-    if (!ws || ws_bytes < gt_conv3x3_wgrad_nhwc_ws_bytes(B, H, W, Cin, Cout)) return GT_EWS;
+    if (!ws || ws_bytes < (int64_t)B * pl.chunks * 9 * Cin * Cout * (int64_t)sizeof(float)) return GT_EWS;   // the plan launched
     if ((int64_t)B * pl.chunks > 0x7fffffffLL) return GT_EINVAL;
     ConvWP p{gy, ldg, x, ldx, reinterpret_cast<float*>(ws), B, H, W, Cin, Cout, pl.chunks, pl.rows};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(B * pl.chunks), (unsigned)pl.ciblocks, (unsigned)pl.coblocks);
     // more than 64 KB of LDS per block: the limit is raised once per kernel instance
-    static bool raised[16] = {};
+    // (the attribute is per device: one bit per device ordinal, set once; concurrent host threads at worst set it twice)
+    static std::atomic<uint64_t> raised[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t dbit = 1ull << (dev & 63);
     auto launch = [&](auto kern, int idx) -> int {
-        if (!raised[idx]) {
+        if (!(raised[idx].load(std::memory_order_acquire) & dbit)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)pl.lds) != hipSuccess)
                 return GT_ENOTSUP;
-            raised[idx] = true;
+            raised[idx].fetch_or(dbit, std::memory_order_release);
         }
         hipLaunchKernelGGL(kern, grid, dim3(CW_THREADS), pl.lds, st, p);
         return 0;

@@ -1518,10 +1518,14 @@ __device__ __forceinline__ void x3p_body(const GemmP& p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int et = -(ea[i] + ebp[j]);
-                const float sg = x3h_pow2(et < -126 ? -126 : (et > 126 ? 126 : et)) * (MI == 1 ? tsgn : ((GT_X3_ALT && (i & 1)) ? -1.f : 1.f));
+                const int et = -(ea[i] + ebp[j]), etc = et < -126 ? -126 : (et > 126 ? 126 : et);
+                const float sg = x3h_pow2(etc) * (MI == 1 ? tsgn : ((GT_X3_ALT && (i & 1)) ? -1.f : 1.f));
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] *= (GT_X3_ALT && (e & 1)) ? -sg : sg;
+                if (et != etc) {       // row amax x tile amax below ~2^-100: the rest of the power of two (no cliff)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = ldexpf(acc[i][j][e], et - etc);
+                }
             }
     } else {
 #if GT_X3_ALT
@@ -1783,8 +1787,16 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
     }
 #endif
     // un-scale, undo the sign, store the slab tile: lane (lr, lh) holds row m = .. + 32 i + lr and columns .. + 32 j + 8 g + 4 lh + t
-    const int et = -(ea + eb);
-    const float us = x3h_pow2(et < -126 ? -126 : (et > 126 ? 126 : et)) * x3_alt_sign(lr);
+    const int et = -(ea + eb), etc = et < -126 ? -126 : (et > 126 ? 126 : et);
+    const float us = x3h_pow2(etc) * x3_alt_sign(lr);
+    if (et != etc) {                   // operands below ~2^-100 of unit scale: apply the rest of the power of two first
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = ldexpf(acc[i][j][e], et - etc);
+    }
     float* C = p.C + (int64_t)by * p.c_split;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

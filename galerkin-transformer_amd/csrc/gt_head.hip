@@ -19,6 +19,7 @@
 // The backward splits the hidden axis over a PAIR of waves (64 each; the full 128 would need > 256 registers
 // per lane for the dW1 accumulators): the pair exchanges its two partial dX^T tiles through LDS once per tile.
 #include "gt_common.h"
+#include <atomic>
 #include <algorithm>
 
 namespace gt {
@@ -809,9 +810,17 @@ extern "C" int gt_mlp_head_bwd(const float* X, int64_t T, int32_t K, int32_t N, 
         const int64_t n32 = (T + 31) / 32;
         const int blocks16 = (int)std::min<int64_t>(512, (n32 + 1) / 2);
         HeadP q{X, W1, b1, w2, nullptr, g, nullptr, dX, reinterpret_cast<float*>(ws), T, (int)((T + 15) / 16)};
-        static const int ok[3] = {head16_allow_lds(head_bwd16_kernel<GT_ACT_NONE>), head16_allow_lds(head_bwd16_kernel<GT_ACT_RELU>),
-                                  head16_allow_lds(head_bwd16_kernel<GT_ACT_SILU>)};
-        if (ok[0] | ok[1] | ok[2]) return GT_ENOTSUP;
+        // the opt-in is per DEVICE: one bit per device ordinal (a process driving several GPUs)
+        static std::atomic<uint64_t> raised{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t dbit = 1ull << (dev & 63);
+        if (!(raised.load(std::memory_order_acquire) & dbit)) {
+            if (head16_allow_lds(head_bwd16_kernel<GT_ACT_NONE>) | head16_allow_lds(head_bwd16_kernel<GT_ACT_RELU>) |
+                head16_allow_lds(head_bwd16_kernel<GT_ACT_SILU>))
+                return GT_ENOTSUP;
+            raised.fetch_or(dbit, std::memory_order_release);
+        }
         if (act == GT_ACT_SILU)
             hipLaunchKernelGGL((head_bwd16_kernel<GT_ACT_SILU>), dim3(blocks16), dim3(256), H16_SMEM, st, q);
         else if (act == GT_ACT_RELU)

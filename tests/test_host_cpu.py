@@ -286,27 +286,62 @@ def test_scaler_chain_eligibility_mirrors_the_segment_kernels_cpu():
     assert not ok(128, (43, 43), B=2)                            # below the token-row size of the narrow implicit GEMMs
 
 
+def _bench_record(tag="r06"):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = [os.path.join(root, "profiles", f) for f in (f"{tag}_bench.json", f"{tag}_bench_table.json", "pmc_step.json")]
+    if not all(os.path.exists(q) for q in paths):
+        pytest.skip(f"profiles/{tag}_bench.json / _bench_table.json / pmc_step.json not recorded yet")
+    line = json.loads(open(paths[0]).read().strip().splitlines()[0])
+    return line, json.load(open(paths[1])), json.load(open(paths[2]))
+
+
 def test_roofline_legs_name_kernels_of_the_counter_passes_cpu():
     """bench.py's `roofline.legs` look their HBM bytes up by kernel symbol in profiles/pmc_step.json: a leg whose symbol is
     not in that file silently loses its counters (VERDICT r2 and r3 both found one).  Every leg the committed bench line
     reports must resolve, in the arithmetic that line ran in, and must carry the counters; the dominant kernel's launch
     geometry must be on file too (`roofline.traffic`)."""
     import bench
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "pmc_step.json")) as f:
-        pmc = json.load(f)
-    with open(os.path.join(root, "profiles", "r05_bench.json")) as f:
-        line = json.loads(f.read().strip().splitlines()[0])
+    line, _, pmc = _bench_record()
     pk = "gemm_x3h_kernel" if line["config"]["precision"] == "f16x2" else "gemm_x3p_kernel"
-    sym = {label: s.replace("gemm_x3p_kernel", pk) for label, _, s in bench.LEGS}
+    sym = {label: s.replace("gemm_x3p_kernel", pk) for label, _, s, _ in bench.LEGS}
     legs = line["roofline"]["legs"]
-    assert len(legs) >= 8, sorted(legs)
+    assert len(legs) >= 10, sorted(legs)
     for label, leg in legs.items():
         assert label in sym, label
         assert sym[label] in pmc, (label, sym[label])
+        assert leg["kernel"] == sym[label]
         assert "hbm_bytes_per_launch" in leg and leg["hbm_bytes_per_launch"] > 0, label
     assert line["roofline"]["traffic"], "no counter record for the dominant kernel's launch geometry"
     assert line["roofline"]["kernel"] in pmc
+
+
+def test_roofline_legs_recompute_from_the_committed_records_cpu():
+    """every `hbm_gbs` of the committed bench line must be (counter bytes of ITS kernel
+    symbol) / (mean HIP-event time of the launches of THAT symbol) -- recomputed here from profiles/pmc_step.json and the
+    per-shape event table written by the same bench run; a leg whose host entry launches several kernel instances must be
+    split by shape (the three gt_conv3x3_wgrad_nhwc geometries), and all legs must have seen the same number of profiled steps."""
+    import bench
+    line, table, pmc = _bench_record()
+    pk = "gemm_x3h_kernel" if line["config"]["precision"] == "f16x2" else "gemm_x3p_kernel"
+    legs = line["roofline"]["legs"]
+    ratios = {}
+    for label, key, sym, pred in bench.LEGS:
+        if label not in legs:
+            continue
+        key, sym = key.replace("gemm_x3p_kernel", pk), sym.replace("gemm_x3p_kernel", pk)
+        rec = bench.leg_record(table["by_kernel"], table["by_shape"], pmc, key, sym, pred)
+        assert rec is not None, label
+        got = legs[label]
+        assert got["launches"] == rec["launches"], label
+        assert abs(got["us"] - rec["us"]) <= 0.06, (label, got["us"], rec["us"])
+        by = pmc[sym]["read_bytes"] + pmc[sym]["write_bytes"]
+        assert abs(got["hbm_gbs"] - by / got["us"] / 1e3) <= 0.002 * got["hbm_gbs"] + 0.2, (label, got["hbm_gbs"], by / got["us"] / 1e3)
+        assert 0 < got["hbm_frac"] < 1.0, (label, got["hbm_frac"])
+        ratios[label] = pmc[sym]["calls_seen"] / got["launches"]
+    # the counter passes profiled the same number of steps for every kernel (launches per step x steps seen)
+    assert len({round(v, 6) for v in ratios.values()}) == 1, ratios
+    conv = [l for l in legs if l.startswith("conv3x3_wgrad")]
+    assert len(conv) == 3, conv
 
 
 def test_ctypes_prototypes_match_the_header_cpu():

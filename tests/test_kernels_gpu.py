@@ -1556,6 +1556,64 @@ def test_gemm_f16x2_dynamic_row_scaling(H, gpu_device, N, K):
                                                                     float(err3.pow(2).mean().sqrt()), float(err3.max())))
 
 
+def test_gemm_f16x2_tiny_magnitudes_have_no_power_of_two_cliff(H, gpu_device):
+    """the un-scale exponent -(row exponent + tile exponent) used to be clamped to [-126, 126]; with row amax x tile
+    amax below ~2^-100 the result came out a power of two too large.  Rows at 1e-30, 1e-34 and 1e-37 against weights at 1e-3
+    and 1e-6: every row fp32-class relative to its own scale (results down to ~1e-43 are subnormal: absolute bound there)."""
+    dev = gpu_device
+    M, N, K = 16384 + 256, 128, 128
+    g = torch.Generator().manual_seed(4242)
+    A = torch.randn(M, K, generator=g)
+    A[:512] *= 1e-30
+    A[512:1024] *= 1e-34
+    A[1024:1536] *= 1e-37
+    Bm = torch.randn(N, K, generator=g) * 1e-3
+    Bm[:32] *= 1e-3
+    Ad, Bd = A.to(dev), Bm.to(dev)
+    ref = A.double() @ Bm.double().t()
+    C = torch.empty(M, N, device=dev)
+    H.gemm(Ad, Bd, C, M, N, K, lda=K, ldb=K, ldc=N, precision="f16x2")
+    torch.cuda.synchronize()
+    assert "gemm_x3h_kernel" in H.gemm_kernel_name(Ad, Bd, M, N, K, lda=K, ldb=K, ldc=N, precision="f16x2")
+    got = C.double().cpu()
+    for lo, hi in ((0, 512), (512, 1024), (1024, 1536), (1536, M)):
+        r, c = ref[lo:hi], got[lo:hi]
+        scale = A[lo:hi].double().abs() @ Bm.double().abs().t()    # un-cancelled magnitude of every output
+        # fp32-class relative to sum |a||b|, plus a few subnormal steps (1.4e-45) where the result itself is subnormal
+        assert bool(((c - r).abs() <= 2e-6 * scale + 6e-45).all()), (lo, hi, float(((c - r).abs() / scale.clamp_min(1e-300)).max()))
+        if float(r.abs().max()) > 1e-36:                           # not a power of two off: the norms agree
+            assert abs(float(c.norm() / r.norm()) - 1.0) < 1e-4, (lo, hi, float(c.norm() / r.norm()))
+
+
+@pytest.mark.parametrize("B,Hh", [(16, 32), (22, 32), (40, 48), (64, 80)])
+def test_conv3x3_wgrad_nhwc_workspace_contract(H, gpu_device, B, Hh):
+    """gt_conv3x3_wgrad_nhwc_ws_bytes planned with the bf16 channel blocks while the fp16 launch could use
+    more row chunks (Cout = 48, Cin % 64 == 0) and wrote past the advertised size.  A workspace of EXACTLY ws_bytes with a
+    canary behind it, in both arithmetics; one byte less is refused."""
+    import ctypes as C
+    dev = gpu_device
+    Ww, Cin, Cout = 40, 128, 48
+    T = B * Hh * Ww
+    x, gy = rnd(T, Cin, dev=dev, seed=801), rnd(T, Cout, dev=dev, seed=802)
+    L = H.lib()
+    need = int(L.gt_conv3x3_wgrad_nhwc_ws_bytes(B, Hh, Ww, Cin, Cout))
+    assert need > 0 and need % 4 == 0
+    res = {}
+    for prec in ("f16x2", "bf16x3"):
+        buf = torch.full((need // 4 + 4096,), 12345.0, device=dev)
+        dw = torch.empty(Cout, Cin, 3, 3, device=dev)
+        rc = L.gt_conv3x3_wgrad_nhwc(gy.data_ptr(), Cout, x.data_ptr(), Cin, dw.data_ptr(), B, Hh, Ww, Cin, Cout, 1.0,
+                                     H.PREC_CODE[prec], buf.data_ptr(), need, H.stream_ptr())
+        torch.cuda.synchronize()
+        assert rc == 0, (prec, rc)
+        assert bool((buf[need // 4:] == 12345.0).all()), f"{prec}: wrote past gt_conv3x3_wgrad_nhwc_ws_bytes"
+        res[prec] = dw
+        rc = L.gt_conv3x3_wgrad_nhwc(gy.data_ptr(), Cout, x.data_ptr(), Cin, dw.data_ptr(), B, Hh, Ww, Cin, Cout, 1.0,
+                                     H.PREC_CODE[prec], buf.data_ptr(), 1024, H.stream_ptr())
+        assert rc == -3, (prec, rc)                                # GT_EWS
+    assert rel_l2(res["f16x2"], res["bf16x3"].double()) < 5e-6
+
+
 def test_conv3x3_f16x2_matches_conv2d(H, gpu_device):
     """The implicit 3x3 convolution (forward and data gradient) in GT_PREC_F16X2 against torch's conv2d in fp64."""
     from galerkin_transformer import ops
