@@ -30,7 +30,10 @@ class FlatClipAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.params = params
         dev = params[0].device
-        H.need_f32_cuda(*params)
+        # the flat buckets (and the collective on them) are device-agnostic -- the multi-rank CPU tests run them over
+        # gloo; the update itself is HIP only: apply() refuses CPU tensors (no CPU fallback for the optimizer step)
+        if any(p.dtype != torch.float32 for p in params):
+            raise TypeError("FlatClipAdam: fp32 parameters")
         if any(p.device != dev for p in params):
             raise ValueError("FlatClipAdam: all parameters must live on one device")
         self.max_norm = float(max_norm) if max_norm else 0.0
@@ -133,6 +136,7 @@ class FlatClipAdam(torch.optim.Optimizer):
 
     def apply(self):
         """norm -> clip -> Adam on the flat buffers (capturable: no host read-back)."""
+        H.need_f32_cuda(self.flat_param, self.flat_grad)
         g = self.param_groups[0]
         L = H.lib()
         st = H.stream_ptr()

@@ -88,3 +88,64 @@ def test_shard_range_and_rank_seed():
     assert [shard_range(10, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 8)]
     assert shard_range(10, 3, 4, drop_last=False) == (9, 10)
     assert len({rank_seed(1127802, r) for r in range(8)}) == 8
+
+
+def _worker8(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "galerkin-transformer_amd"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from galerkin_transformer.distributed import broadcast_parameters, init_distributed, rank_seed, shard_range
+    from galerkin_transformer.optim import FlatClipAdam
+    init_distributed("gloo")
+    model = _model(300 + rank)
+    broadcast_parameters(model, src=0)
+    opt = FlatClipAdam(model.parameters(), lr=1e-3, max_norm=0.99)      # buckets + collective; the HIP update is not run here
+    assert opt.world == world
+    g = torch.Generator().manual_seed(9)
+    X, Y = torch.randn(64, 12, generator=g), torch.randn(64, 3, generator=g)
+    lo, hi = shard_range(64, rank, world)
+    ((model(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+    opt.gather_grads()
+    opt.all_reduce()
+    try:
+        opt.apply()
+        refused = False
+    except RuntimeError as e:
+        refused = "no CPU fallback" in str(e)
+    q.put((rank, (lo, hi), rank_seed(1127802, rank), opt.flat_grad.numpy().copy() / world, list(opt.offsets), refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_clip_adam_bucket_allreduce_eight_ranks_gloo():
+    """the path the driver's 8-GPU run takes -- FlatClipAdam's flat gradient bucket (16-byte
+    aligned parameter offsets), ONE in-place sum-all-reduce, the 1 / world average folded in afterwards -- with EIGHT ranks
+    over gloo: the averaged bucket equals the single-process gradient of the whole batch on every rank, shards partition the
+    batch, dropout seeds differ per rank, and the optimizer update itself refuses CPU tensors (no CPU fallback)."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = _model(300)
+    g = torch.Generator().manual_seed(9)
+    X, Y = torch.randn(64, 12, generator=g), torch.randn(64, 3, generator=g)
+    ((ref(X) - Y) ** 2).mean().backward()
+    shards = [r[1] for r in res]
+    assert shards == [(8 * i, 8 * i + 8) for i in range(8)]
+    assert len({r[2] for r in res}) == 8
+    for rank, _, _, flat, offsets, refused in res:
+        assert refused, "FlatClipAdam.apply() must not run on CPU tensors"
+        flat = torch.from_numpy(flat)
+        for p, o in zip(ref.parameters(), offsets):
+            assert o % 4 == 0
+            assert torch.allclose(flat[o:o + p.numel()].view_as(p), p.grad, rtol=1e-5, atol=1e-7), rank

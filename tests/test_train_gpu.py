@@ -152,6 +152,27 @@ def _run_bench_ranks(extra, port, timeout=900):
     return json.loads(lines[0])
 
 
+def test_bench_eight_ranks_on_one_gpu_gloo(gpu_device):
+    """the exact launch the driver uses for the 8-GPU run (torch.distributed.run, 8 ranks, --gpus 8)
+    with the ranks sharing cuda:0 over gloo at per-rank batch 2: split graphs, the flat all-reduce between them, barrier +
+    max-over-ranks timing, ONE JSON line from rank 0.  (RCCL itself needs the 8-GPU node.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29551", os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--batch", "2",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-f32-leg", "--no-accuracy"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp8"
+    assert rec["scaling"] == "weak" and rec["value"] > 0 and np.isfinite(rec["config"]["final_loss"])
+
+
 def test_bench_strong_scaling_two_ranks_gloo(gpu_device):
     """--scaling strong: the global batch is fixed and split over the ranks (two ranks sharing cuda:0 over gloo); also
     the ex3 inverse-problem workload (BASELINE configs[3]: the DDP configuration) through the same path."""
