@@ -57,6 +57,22 @@ __device__ inline float drop_mul(const DropDev& d, uint32_t key, uint32_t idx) {
     return (drop_hash(key, idx) >= d.thresh) ? d.scale : 0.f;
 }
 
+// Two fp32 values times a power of two s -> packed fp16 heads h0 = f16(x s) and residuals h1 = f16(x s - h0), in FOUR instructions:
+// v_fma_mix{lo,hi}_f16 evaluate the fp32 fma and round it (RNE, gradual underflow) into one half of the destination -- no
+// separate multiply, no conversions.  Bit-identical to  r = x s; h0 = cvt_pk_f16_f32(r); h1 = cvt_pk_f16_f32(r - f32(h0))
+// (eight issue slots per pair: a packed fp32 instruction costs two, tools/valu_rate_probe.hip) except for the sign of exact
+// zeros (tools/fma_mix_split_probe.hip, checked on gfx950 incl. fp16-subnormal heads and residuals).
+// The operands must not be fresh MFMA results: hipcc's hazard recogniser does not look into inline asm (gt_fourier16.hip).
+__device__ __forceinline__ void f16_mulsplit_pair(float a0, float m0, float a1, float m1, uint32_t& hi, uint32_t& lo) {
+    uint32_t h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(m0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(m1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "v"(m0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(a1), "v"(m1), "v"(h));
+    hi = h;
+    lo = l;
+}
+
 // SiLU on the hardware exp2 / rcp units (1 ulp each; 5 VALU ops instead of ~27 for expf + IEEE division).
 __device__ inline float sigmoid_f(float x) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
@@ -77,6 +93,24 @@ __device__ inline void gelu_both(float x, float& a, float& da) {
     const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
     a = x * cdf;
     da = cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+// value of lane (l ^ 32): v_permlane32_swap (gfx950) exchanges the wave's halves on the VALU -- no LDS round trip and no
+// s_waitcnt as with __shfl_xor(v, 32) = ds_bpermute_b32.  Returns (own half's values, other half's values) merged per lane.
+__device__ __forceinline__ float xor32(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // sw[0]: lanes 0..31 everywhere, sw[1]: lanes 32..63
+    return __uint_as_float((threadIdx.x & 32) ? sw[0] : sw[1]);
+}
+__device__ __forceinline__ float xor32_max(float v) {                       // max(v[l], v[l ^ 32]) without the select
+    const uint32_t u = __float_as_uint(v);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
 __device__ inline float wave_sum(float v) {

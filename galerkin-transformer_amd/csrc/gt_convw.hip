@@ -169,9 +169,9 @@ struct CwStage {
                 if (PL == 3) {
                     cw_split3(sg * v[it][0][c], sg * v[it][1][c], h0);
                     cw_split3(sg * v[it][2][c], sg * v[it][3][c], h1);
-                } else {
-                    cw_split2h(sg * v[it][0][c], sg * v[it][1][c], h0);
-                    cw_split2h(sg * v[it][2][c], sg * v[it][3][c], h1);
+                } else {                                    // scale and split in four v_fma_mix*_f16 per pair (gt_common.h)
+                    f16_mulsplit_pair(v[it][0][c], sg, v[it][1][c], sg, h0[0], h0[1]);
+                    f16_mulsplit_pair(v[it][2][c], sg, v[it][3][c], sg, h1[0], h1[1]);
                 }
 #pragma unroll
                 for (int pl = 0; pl < PL; ++pl)

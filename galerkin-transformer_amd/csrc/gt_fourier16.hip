@@ -68,19 +68,6 @@ __device__ __forceinline__ void f16_split_pair(float a, float b, uint32_t& hi, u
     hi = __builtin_bit_cast(uint32_t, h0);
     lo = __builtin_bit_cast(uint32_t, h1);
 }
-// the score phase's version: (a0 m0, a1 m1) -> packed h0, h1 in four instructions.  v_fma_mix{lo,hi}_f16 evaluate the fp32 fma
-// and round it to one half of the destination: h0 = f16(a m) (m is a power of two or 0: the product is exact) and
-// h1 = f16(a m - h0) (the residual is exact in fp32) -- no separate multiply, no conversions (8 issue slots per pair with
-// v_pk_mul_f32 / v_cvt / v_pk_fma_f32: tools/valu_rate_probe.hip, a packed fp32 instruction costs two)
-__device__ __forceinline__ void f16_mulsplit_pair(float a0, float m0, float a1, float m1, uint32_t& hi, uint32_t& lo) {
-    uint32_t h, l;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(m0));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(m1));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "v"(m0), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(a1), "v"(m1), "v"(h));
-    hi = h;
-    lo = l;
-}
 // acc += a b, a = ah + al, b = bh + bl: small terms first
 __device__ __forceinline__ f32x4 f16_mma3(ff16x8 ah, ff16x8 al, ff16x8 bh, ff16x8 bl, f32x4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);

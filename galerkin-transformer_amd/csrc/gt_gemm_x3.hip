@@ -155,6 +155,9 @@ __device__ __forceinline__ void x3_alt_undo(f32x16 (&acc)[NI][NJ], float rsgn) {
 //     product.  Nothing can overflow (the check precedes the split), a row whose early stages are its largest simply
 //     resolves the later ones relative to that maximum, like any fp32 accumulation does.
 // The accumulators are un-scaled together with the GT_X3_ALT sign, before the epilogue.
+#ifndef GT_X3H_CVT_SPLIT
+#define GT_X3H_CVT_SPLIT 0      // 1: the round-4 split (multiply, v_cvt_pk, two v_cvt, subtract, v_cvt_pk) for A/B timing
+#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int X3H_E0 = 120;                       // start exponent: any non-zero first stage sets the real one
@@ -162,13 +165,17 @@ constexpr int X3H_TARGET = 13, X3H_LIMIT = 15;    // scaled row amax is put in [
 
 __device__ __forceinline__ float x3h_pow2(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }   // -126 <= e <= 127
 
-// two scaled fp32 -> two packed fp16 pairs
+// two fp32 times the scale -> two packed fp16 pairs (round 5: four v_fma_mix* instead of multiply + conversions, gt_common.h)
 __device__ __forceinline__ void x3h_split_pair(float a, float b, float s, uint32_t (&out)[2]) {
+#if GT_X3H_CVT_SPLIT
     const f32x2 r = f32x2{a, b} * s;
     const f16x2 h0 = __builtin_convertvector(r, f16x2);           // v_cvt_pk_f16_f32 (RNE)
     const f16x2 h1 = __builtin_convertvector(r - __builtin_convertvector(h0, f32x2), f16x2);
     out[0] = __builtin_bit_cast(uint32_t, h0);
     out[1] = __builtin_bit_cast(uint32_t, h1);
+#else
+    f16_mulsplit_pair(a, s, b, s, out[0], out[1]);
+#endif
 }
 
 __device__ __forceinline__ f32x16 mfma32h(f16x8 a, f16x8 b, f32x16 c) {
@@ -421,14 +428,14 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
                 float sum = 0.f;
 #pragma unroll
                 for (int q = 0; q < GPS; ++q) sum += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
-                sum += __shfl_xor(sum, 32, 64);
+                sum = xor32_sum(sum);
                 mu = sum * inv;
                 float ss = 0.f;
 #pragma unroll
                 for (int q = 0; q < GPS; ++q)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) { const float c0 = v[q][t] - mu; ss = fmaf(c0, c0, ss); }
-                ss += __shfl_xor(ss, 32, 64);
+                ss = xor32_sum(ss);
                 rstd = 1.f / sqrtf(ss * inv + p.hn_eps);
             }
             float* seg = srow + sg * DP;
@@ -1386,9 +1393,12 @@ __device__ __forceinline__ void x3p_body(const GemmP& p) {
             if constexpr (F16) {
                 // the row's amax of this stage (both k-halves); lower the row's exponent -- and rescale what the lane has
                 // accumulated for it -- before anything could overflow
-                float amax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
-                                   fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
-                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                // (a chain, so that it becomes four v_max3_f32 with |.| modifiers; the other k-half of the row sits in lane
+                // l ^ 32: one v_permlane32_swap instead of a ds_bpermute round trip per tile and stage)
+                float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2]));
+                amax = fmaxf(fmaxf(amax, fabsf(v[3])), fabsf(v[4]));
+                amax = fmaxf(fmaxf(amax, fabsf(v[5])), fabsf(v[6]));
+                amax = xor32_max(fmaxf(amax, fabsf(v[7])));
                 const int ex = (int)(__float_as_uint(amax) >> 23);
                 const bool need = ex + ea[i] - 127 >= X3H_LIMIT;
                 if (__any(need)) {                        // wave-uniform

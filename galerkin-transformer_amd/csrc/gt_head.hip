@@ -328,6 +328,8 @@ __device__ __forceinline__ int h16_exp_for(float amax) {
     return ex == 0 ? 0 : (141 - ex > 126 ? 126 : 141 - ex);      // <= 126: 2^-e stays a normal number too
 }
 __device__ __forceinline__ void h16_split_pair(float a, float b, float s, uint32_t& hi, uint32_t& lo) {
+    // (the four-instruction v_fma_mix* form of gt_common.h was SLOWER here: head_bwd16 485 -> 512 us in the step -- these
+    // kernels are bound by the quarter-rate v_exp / v_rcp of SiLU, and opaque asm in their long VALU chains costs scheduling)
     const f32x2 r = f32x2{a, b} * s;
     const hf16x2 h0 = __builtin_convertvector(r, hf16x2);               // v_cvt_pk_f16_f32 (RNE)
     const hf16x2 h1 = __builtin_convertvector(r - __builtin_convertvector(h0, f32x2), hf16x2);

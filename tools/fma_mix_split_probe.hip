@@ -11,7 +11,13 @@ __global__ void k(const float* a, const float* m, uint32_t* out) {
 }
 int main() {
     float ha[128], hm[128]; uint32_t ho[128];
-    for (int i = 0; i < 128; ++i) { ha[i] = 1.2345678f * (i + 1) * (i % 3 == 0 ? -1 : 1); hm[i] = (i % 5 == 0) ? 0.f : 4.f; }
+    // normal values, zeros, and values whose fp16 residual (and, for the last quarter, whose fp16 head) is SUBNORMAL in fp16:
+    // v_cvt_pk_f16_f32 produces gradual underflow; the mix instructions must too for a drop-in replacement
+    for (int i = 0; i < 128; ++i) {
+        ha[i] = 1.2345678f * (i + 1) * (i % 3 == 0 ? -1 : 1); hm[i] = (i % 5 == 0) ? 0.f : 4.f;
+        if (i % 4 == 1) { ha[i] = (1.f + (i + 1) * 0x1p-21f) * (i % 8 == 1 ? 1.f : 0x1p-6f); hm[i] = 1.f; }      // residual ~2^-20 .. 2^-27
+        if (i % 4 == 2) { ha[i] = (3.f + i) * 0x1p-20f; hm[i] = 0x1p-2f; }                                          // head itself subnormal
+    }
     float *a, *m; uint32_t* o;
     hipMalloc(&a, 512); hipMalloc(&m, 512); hipMalloc(&o, 512);
     hipMemcpy(a, ha, 512, hipMemcpyHostToDevice); hipMemcpy(m, hm, 512, hipMemcpyHostToDevice);
