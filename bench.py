@@ -211,7 +211,7 @@ class Trainer:
         self.loss_fn = make_loss(workload, loss)
         self.flat = optimizer == "flat"
         if self.flat:
-            self.opt = gt.FlatClipAdam(self.params, lr=lr, max_norm=clip)
+            self.opt = gt.FlatClipAdam(self.params, lr=lr, max_norm=clip, model=model)
             self.opt_kind = "FlatClipAdam (gt_grad_sqnorm + gt_adam_clip_step on one flat bucket)"
             self.reducer = None
         else:

@@ -1040,7 +1040,7 @@ constexpr int FIN_RB = 4;
 __global__ __launch_bounds__(256) void galerkin_fin_fwd_kernel(
     const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int h, int DP, int Dr, int d,
     float inv_n, const float* __restrict__ mask, DropDev drop, const float* __restrict__ Wfc,
-    float* __restrict__ Mt, float* __restrict__ P) {
+    float* __restrict__ Mt, float* __restrict__ P, float* __restrict__ Pv, int pdim) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sM = lds;                    // [FIN_RB][DP]
     float* sW = lds + FIN_RB * DP;      // [d][Dr]
@@ -1082,6 +1082,9 @@ __global__ __launch_bounds__(256) void galerkin_fin_fwd_kernel(
             for (int ee = 0; ee < Dr; ++ee) acc = fmaf(mr[ee], wr[ee], acc);
         }
         Pb[(int64_t)j * d + c] = acc;
+        // the value rows of P once more, compact [B][h dk][d]: the B operand of the backward's dQ product (it used to be
+        // sliced out of P by an ATen copy in every backward)
+        if (Pv && j >= pdim && j < Dr) Pv[((int64_t)b * h * (Dr - pdim) + (int64_t)hh * (Dr - pdim) + (j - pdim)) * d + c] = acc;
     }
 }
 
@@ -1635,16 +1638,16 @@ extern "C" int gt_galerkin_dkv_ln_plain(const float* Kp, const float* Vp, const 
 extern "C" int gt_galerkin_finalize_fwd(const float* slabs, int32_t n_slabs, int64_t slab_stride, int32_t B,
                                         int32_t h, int32_t DP, int32_t Dr, int32_t d, int32_t n_tokens,
                                         const float* mask, const gt_dropout* drop, const float* Wfc,
-                                        float* Mt, float* P, void* stream) {
+                                        float* Mt, float* P, float* Pv, int32_t pos_dim, void* stream) {
     if (!slabs || !Wfc || !Mt || !P || n_slabs <= 0 || B <= 0 || h <= 0 || Dr <= 0 || DP < Dr || d <= 0 ||
-        n_tokens <= 0)
+        n_tokens <= 0 || pos_dim < 0 || pos_dim >= Dr)
         return GT_EINVAL;
     if (drop && drop->p > 0.f && !drop->seed) return GT_EINVAL;
     const size_t lds = ((size_t)FIN_RB * DP + (size_t)d * Dr) * sizeof(float);
     if (int rc = allow_big_lds(galerkin_fin_fwd_kernel, lds)) return rc;
     hipLaunchKernelGGL(galerkin_fin_fwd_kernel, dim3(B * h, (DP + FIN_RB - 1) / FIN_RB), dim3(256), lds, (hipStream_t)stream, slabs,
                        n_slabs, slab_stride, h, DP, Dr, d, 1.f / (float)n_tokens, mask,
-                       make_drop(mask ? nullptr : drop), Wfc, Mt, P);
+                       make_drop(mask ? nullptr : drop), Wfc, Mt, P, Pv, pos_dim);
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -119,8 +119,8 @@ _PROTOS = {
     "gt_dft_synthesis": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                                                      C.c_int32, C.c_void_p, C.c_void_p]),
     "gt_galerkin_finalize_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64] + [C.c_int32] * 6 +
-                                 [C.c_void_p, C.POINTER(GtDropout), C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p]),
+                                 [C.c_void_p, C.POINTER(GtDropout), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.c_void_p]),
     "gt_galerkin_finalize_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GtDropout),
                                            C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p,
                                                                             C.c_void_p]),
@@ -707,16 +707,18 @@ def headnorm_bwd(d_out: torch.Tensor, qkv: torch.Tensor, gamma: Optional[torch.T
 
 def galerkin_finalize_fwd(slabs: torch.Tensor, n_slabs: int, slab_stride: int, B: int, h: int, DP: int,
                           Dr: int, d: int, n_tokens: int, mask: Optional[torch.Tensor],
-                          drop: Optional[GtDropout], Wfc: torch.Tensor):
+                          drop: Optional[GtDropout], Wfc: torch.Tensor, value_rows_of: Optional[int] = None):
+    """value_rows_of = p (coordinate columns): also return Pv [B, h (Dr - p), d], the value rows of P."""
     need_f32_cuda(slabs, mask, Wfc)
     dev = slabs.device
     Mt = torch.empty(B, h, DP, DP, dtype=torch.float32, device=dev)
     P = torch.empty(B, h * DP, d, dtype=torch.float32, device=dev)
+    Pv = torch.empty(B, h * (Dr - value_rows_of), d, dtype=torch.float32, device=dev) if value_rows_of is not None else None
     dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
     check(_timed("gt_galerkin_finalize_fwd", 0, 0, lambda: lib().gt_galerkin_finalize_fwd(slabs.data_ptr(), n_slabs, slab_stride, B, h, DP, Dr, d, n_tokens,
-                                         ptr(mask), dp, Wfc.data_ptr(), Mt.data_ptr(), P.data_ptr(),
-                                         stream_ptr())), "gt_galerkin_finalize_fwd")
-    return Mt, P
+                                         ptr(mask), dp, Wfc.data_ptr(), Mt.data_ptr(), P.data_ptr(), ptr(Pv),
+                                         value_rows_of or 0, stream_ptr())), "gt_galerkin_finalize_fwd")
+    return (Mt, P) if value_rows_of is None else (Mt, P, Pv)
 
 
 def galerkin_finalize_bwd(dPt: torch.Tensor, Mt: torch.Tensor, mask: Optional[torch.Tensor],

@@ -354,18 +354,32 @@ class SimpleAttention(nn.Module):
         else:
             self.norm_Q = mk()
 
+    def _norm_pair(self):
+        if self.attention_type in _LINEAR_FAMILY:
+            return self.norm_K, self.norm_V, 0b110
+        return self.norm_Q, self.norm_K, 0b011
+
+    def _pack_groups(self):
+        """The parameter lists _packed() concatenates, in concatenation order (optim.FlatClipAdam(model=...) lays each
+        group out contiguously, and ops.packed_params then returns views instead of copies)."""
+        groups = [[l.weight for l in self.linears]]
+        if all(l.bias is not None for l in self.linears):
+            groups.append([l.bias for l in self.linears])
+        if self.add_norm:
+            first, second, _ = self._norm_pair()
+            groups.append([m.weight for m in first] + [m.weight for m in second])
+            groups.append([m.bias for m in first] + [m.bias for m in second])
+        return groups
+
     def _packed(self):
-        wqkv = torch.cat([l.weight for l in self.linears], dim=0)
-        bqkv = torch.cat([l.bias for l in self.linears], dim=0)
+        wqkv = ops.packed_params([l.weight for l in self.linears])
+        bqkv = ops.packed_params([l.bias for l in self.linears])
         gamma = beta = None
         mask = 0
         if self.add_norm:
-            if self.attention_type in _LINEAR_FAMILY:
-                first, second, mask = self.norm_K, self.norm_V, 0b110
-            else:
-                first, second, mask = self.norm_Q, self.norm_K, 0b011
-            gamma = torch.stack([m.weight for m in first] + [m.weight for m in second])
-            beta = torch.stack([m.bias for m in first] + [m.bias for m in second])
+            first, second, mask = self._norm_pair()
+            gamma = ops.packed_params([m.weight for m in first] + [m.weight for m in second])
+            beta = ops.packed_params([m.bias for m in first] + [m.bias for m in second])
             gamma = gamma.view(2, self.n_head, self.d_k)
             beta = beta.view(2, self.n_head, self.d_k)
         return wqkv, bqkv, gamma, beta, mask

@@ -330,6 +330,73 @@ _conv_wgrad_planes = [os.environ.get("GT_CONV_WGRAD_PLANES", "1") != "0"]   # gt
 
 
 
+class _PackedParamsFn(Function):
+    """cat(params, dim 0) of parameters that lie back to back in memory: the result is a VIEW over them (no copy), and
+    the gradient is handed back as slices of the packed gradient (no copies either)."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        ctx.rows = [p.shape[0] for p in params]
+        p0 = params[0]
+        rows = sum(ctx.rows)
+        out = p0.detach().as_strided((rows,) + tuple(p0.shape[1:]), p0.stride())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, r0 = [], 0
+        for r in ctx.rows:
+            outs.append(g[r0:r0 + r])
+            r0 += r
+        return tuple(outs)
+
+
+def packed_params(params):
+    """torch.cat(params, 0) -- as a zero-copy view when the tensors follow each other in memory (FlatClipAdam(model=...)
+    lays SimpleAttention's groups out that way), else as the copy it always was.  1-D parameters of equal length stack to
+    [len(params) * n] (callers view it)."""
+    ok = all(p.is_contiguous() and p.dtype == params[0].dtype and p.shape[1:] == params[0].shape[1:] for p in params)
+    if ok:
+        nxt = params[0].data_ptr()
+        for p in params:
+            if p.data_ptr() != nxt:
+                ok = False
+                break
+            nxt += p.numel() * p.element_size()
+    if ok and params[0].is_cuda:
+        st = params[0].untyped_storage()
+        last = params[-1]
+        ok = last.data_ptr() + last.numel() * last.element_size() <= st.data_ptr() + st.nbytes()
+    if ok and params[0].is_cuda:
+        return _PackedParamsFn.apply(*params)
+    return torch.cat(list(params), dim=0)
+
+
+_gather_cache = {}
+
+
+def _gathered(w, key, fn):
+    """fn(w) for a pure re-layout `fn` (flips, permutes, zero padding, reshapes) as ONE index_select (+ one multiply by a 0 / 1
+    mask when fn pads): the index table is worked out once per (fn, shape) by running fn on the element numbers.  The filter
+    re-layouts of the scaler convolutions run every step (the weights change every step): flip + permute + zeros + copy +
+    contiguous per filter were 26 ATen launches per step (tools/aten_in_step.py), now 8."""
+    k = (key, tuple(w.shape), str(w.device))
+    ent = _gather_cache.get(k)
+    if ent is None:
+        src = torch.arange(1, w.numel() + 1, dtype=torch.float64).reshape(w.shape)
+        r = fn(src)
+        flat = r.reshape(-1)
+        idx = (flat.to(torch.int64) - 1).clamp_min(0).to(w.device)
+        mask = (flat > 0).to(torch.float32).to(w.device) if bool((flat == 0).any()) else None
+        ent = (idx, mask, tuple(r.shape))
+        _gather_cache[k] = ent
+    idx, mask, shape = ent
+    out = w.detach().reshape(-1).index_select(0, idx)
+    if mask is not None:
+        out = out * mask
+    return out.view(shape)
+
+
 def _conv_k_order(w):
     """[N, 9 taps, C] filter -> [N, 9 C] in the contraction order of the implicit-GEMM kernel (gt_hip.h: cv_*): channel
     blocks of CB outermost, the nine taps of a block adjacent."""
@@ -355,7 +422,7 @@ class Conv3x3NhwcFn(Function):
         B, Hh, Ww, Cin = x.shape
         Cout = weight.shape[0]
         xc = _c(x)
-        wf = _conv_k_order(weight.permute(0, 2, 3, 1).reshape(Cout, 9, Cin))       # [Cout][tap][Cin] -> k order
+        wf = _gathered(weight, "conv_fwd", lambda t: _conv_k_order(t.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)))   # [Cout][tap][Cin] -> k order
         y = torch.empty(B, Hh, Ww, Cout, dtype=torch.float32, device=x.device)
         ctx.prec = H.get_precision()             # the backward products run in the arithmetic of the forward
         H.gemm(xc, wf, y, B * Hh * Ww, Cout, 9 * Cin, lda=Cin, ldb=9 * Cin, ldc=Cout, conv=(Hh, Ww, Cin),
@@ -373,7 +440,7 @@ class Conv3x3NhwcFn(Function):
         dev = g.device
         if ctx.needs_input_grad[0]:
             # dx[pix][ci] = sum_tap sum_co gy[pix - shift(tap)][co] W[co][ci][tap]: tap' = 8 - tap has the opposite shift
-            wd = _conv_k_order(weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9, Cout))     # [Cin][tap'][Cout]
+            wd = _gathered(weight, "conv_dgrad", lambda t: _conv_k_order(t.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9, Cout)))     # [Cin][tap'][Cout]
             dx = torch.empty(B, Hh, Ww, Cin, dtype=torch.float32, device=g.device)
             with H.side_branch(dev, B * Hh * Ww):        # the data gradient next to the weight gradient below
                 try:
@@ -477,7 +544,7 @@ class ScalerConvChainFn(Function):
         cin = (C0, CP, CP)
         ctx.prec = H.get_precision()             # bf16x3 or f16x2 (scaler_chain_ok); the backward runs in the same arithmetic
         for i, w in enumerate(ws):
-            wf = _conv_k_order(_pad_filter(w, CP, cin[i]))                            # [CP, 9 cin] in k order
+            wf = _gathered(w, ("chain_fwd", CP, cin[i]), lambda t, ci_=cin[i]: _conv_k_order(_pad_filter(t, CP, ci_)))   # [CP, 9 cin] in k order
             A = x0c.reshape(T, C0) if i == 0 else cat[:, (i - 1) * CP:i * CP]
             H.gemm(A, wf, cat[:, i * CP:(i + 1) * CP], T, CP, 9 * cin[i], lda=(C0 if i == 0 else 3 * CP), ldb=9 * cin[i],
                    ldc=3 * CP, conv=(Hh, Ww, cin[i]), act=H.ACT_RELU,
@@ -517,7 +584,8 @@ class ScalerConvChainFn(Function):
                     dws[i] = _scaler_wgrad(seg, ldseg, xin, ldx, ws[i], B, Hh, Ww, CP, cin[i], scale, prec)
             # dx[pix][ci] = scale * sum_tap sum_co dpre[pix - shift(tap)][co] W[co][ci][tap]: tap' = 8 - tap
             if i > 0 or ctx.needs_input_grad[0]:
-                wd = _conv_k_order(_pad_filter(ws[i].flip(2, 3).transpose(0, 1), cin[i], CP))   # [cin, 9 CP] in k order
+                wd = _gathered(ws[i], ("chain_dgrad", CP, cin[i]),
+                               lambda t, ci_=cin[i]: _conv_k_order(_pad_filter(t.flip(2, 3).transpose(0, 1), ci_, CP)))   # [cin, 9 CP] in k order
                 if i == 0:
                     dx0 = torch.empty(T, C0, dtype=torch.float32, device=dev)
                     H.gemm(seg, wd, dx0, T, C0, 9 * CP, lda=ldseg, ldb=9 * CP, ldc=C0, conv=(Hh, Ww, CP), alpha=scale,
@@ -871,12 +939,12 @@ class SimpleAttentionFn(Function):
                 slabs = torch.empty(1, B, h, DP, DP, dtype=torch.float32, device=dev)
                 H.gemm(Kp, Vp, slabs, DP, DP, n, layout_a=1, layout_b=1, lda=hD, ldb=hD, ldc=DP, batch=(B, h),
                        a_bs=(n * hD, DP), b_bs=(n * hD, DP), c_bs=(h * DP * DP, DP * DP), split_k=0)
-            Mt, P = H.galerkin_finalize_fwd(slabs, slabs.shape[0], B * h * DP * DP, B, h, DP, Dr, d, n, mask,
-                                            d_attn, wf)
+            Mt, P, Pv = H.galerkin_finalize_fwd(slabs, slabs.shape[0], B * h * DP * DP, B, h, DP, Dr, d, n, mask,
+                                                d_attn, wf, value_rows_of=p)
             H.gemm(Qp, P, out, n, d, hD, layout_b=1, lda=hD, ldb=d, ldc=d, batch=(B, 1), a_bs=(n * hD, 0),
                    b_bs=(hD * d, 0), c_bs=(n * d, 0), bias=bfc, drop=d_out, res=rc, ldr=d, r_bs=(n * d, 0),
                    out_scale=sign)
-            ctx.save_for_backward(xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask, beta if plain else None)
+            ctx.save_for_backward(xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask, beta if plain else None, Pv)
             ctx.plain = plain
             attn_w = Mt[:, :, :Dr, :Dr]
         else:
@@ -939,7 +1007,7 @@ class SimpleAttentionFn(Function):
         dbfc = None
         if kind == "galerkin":
             dbfc = torch.empty(d, dtype=torch.float32, device=dev) if hbf else None
-            xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask, beta_plain = ctx.saved_tensors
+            xc, wq, gamma, wf, qkv, stats, out3, Mt, P, mask, beta_plain, Pv = ctx.saved_tensors
             d_attn = H.dropout_desc(p_attn, salt, dev) if (p_attn > 0 and mask is None) else None
             Qp, Kp, Vp = out3[0], out3[1], out3[2]
             # dP^T[b] = (sign*g*mask1)^T[b] Q'[b]        [B, d, h*DP]
@@ -956,7 +1024,6 @@ class SimpleAttentionFn(Function):
                 # of P and write the Q block of d_qkv directly -- one 128-wide tile column instead of h*DP = 144, no
                 # dQ' round trip
                 dqkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
-                Pv = P.view(B, h, DP, d)[:, :, p:p + dk, :].reshape(B, d, d)
                 H.gemm(g, Pv, dqkv, n, d, d, lda=d, ldb=d, ldc=3 * d, batch=(B, 1), a_bs=(n * d, 0),
                        b_bs=(d * d, 0), c_bs=(n * 3 * d, 0), a_drop=d_out, a_drop_sign=sign, a_drop_ld=d,
                        a_drop_bstride=n * d, alpha=(sign if d_out is None else 1.0))

@@ -23,7 +23,11 @@ from . import _hip as H
 
 class FlatClipAdam(torch.optim.Optimizer):
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, max_norm: Optional[float] = None, group=None):
+                 weight_decay: float = 0.0, max_norm: Optional[float] = None, group=None, model: Optional[torch.nn.Module] = None):
+        """model (optional): modules that concatenate some of their parameters on every forward (SimpleAttention: the packed
+        QKV weight / bias and the per-head LayerNorm parameters) publish those groups through ``_pack_groups()``; the groups
+        are laid out back to back in the bucket, so the module gets its packed tensor as a VIEW of the bucket instead of four
+        ``torch.cat`` / ``torch.stack`` launches per layer and step (ops.packed_params)."""
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError("FlatClipAdam: no trainable parameters")
@@ -39,11 +43,23 @@ class FlatClipAdam(torch.optim.Optimizer):
         self.max_norm = float(max_norm) if max_norm else 0.0
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        # every tensor starts on a 16-byte boundary of the bucket (the kernels use 16-byte accesses)
-        self.offsets, off = [], 0
-        for p in params:
-            self.offsets.append(off)
-            off += (p.numel() + 3) // 4 * 4
+        # every tensor starts on a 16-byte boundary of the bucket (the kernels use 16-byte accesses); the members of a pack
+        # group follow each other without padding (their sizes must then be multiples of four -- else the group is ignored)
+        order, placed = [], set()
+        index = {id(p): i for i, p in enumerate(params)}
+        if model is not None:
+            for m in model.modules():
+                for grp in (m._pack_groups() if hasattr(m, "_pack_groups") else []):
+                    ids = [index.get(id(p)) for p in grp]
+                    if any(i is None or i in placed for i in ids) or any(p.numel() % 4 for p in grp):
+                        continue
+                    order.extend(ids)
+                    placed.update(ids)
+        order.extend(i for i in range(len(params)) if i not in placed)
+        self.offsets, off = [0] * len(params), 0
+        for i in order:
+            self.offsets[i] = off
+            off += (params[i].numel() + 3) // 4 * 4
         self.numel = off
         f32 = dict(dtype=torch.float32, device=dev)
         self.flat_param = torch.zeros(off, **f32)

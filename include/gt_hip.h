@@ -293,7 +293,9 @@ int gt_galerkin_ktv_affine(const float* Kp, const float* Vp, const float* gamma,
 int gt_galerkin_finalize_fwd(const float* slabs, int32_t n_slabs, int64_t slab_stride,
                              int32_t B, int32_t h, int32_t DP, int32_t Dr, int32_t d, int32_t n_tokens,
                              const float* mask, const gt_dropout* drop, const float* Wfc,
-                             float* Mt, float* P, void* stream);
+                             float* Mt, float* P, float* Pv, int32_t pos_dim, void* stream);
+/* (Pv, optional: the value rows pos_dim .. Dr-1 of every head's block of P once more, compact [B][h (Dr - pos_dim)][d] --
+ * the B operand of the backward's dQ product.) */
 int gt_galerkin_finalize_bwd(const float* dPt, const float* Mt, const float* mask,
                              const gt_dropout* drop, const float* Wfc,
                              int32_t B, int32_t h, int32_t DP, int32_t Dr, int32_t d, int32_t n_tokens,

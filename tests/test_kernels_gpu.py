@@ -240,7 +240,10 @@ def test_galerkin_finalize(H, gpu_device, B, h, dk, p, d, use_mask):
     Wfc = rnd(d, h * Dr, dev=dev, seed=29, scale=0.3)
     mask = ((torch.rand(B, h, DP, DP, device=dev) > 0.5).float() * 2.0) if use_mask else None
     Mt, P = H.galerkin_finalize_fwd(slabs, S, B * h * DP * DP, B, h, DP, Dr, d, n, mask, None, Wfc)
+    Mt2, P2, Pv = H.galerkin_finalize_fwd(slabs, S, B * h * DP * DP, B, h, DP, Dr, d, n, mask, None, Wfc, value_rows_of=p)
     torch.cuda.synchronize()
+    assert torch.equal(Mt, Mt2) and torch.equal(P, P2)
+    assert torch.equal(Pv, P.view(B, h, DP, d)[:, :, p:p + dk, :].reshape(B, h * dk, d))   # the value rows, compact
     s64 = slabs.double().requires_grad_(True)
     w64 = Wfc.double().requires_grad_(True)
     M64 = s64.sum(0)[..., :Dr, :Dr] / n

@@ -84,6 +84,47 @@ def test_run_train_ns_rollout_device_loader_flat_adam(gpu_device, tmp_path):
     assert np.isfinite(res["best_val_metric"])
 
 
+def test_packed_parameter_views_equal_the_copies(gpu_device):
+    """FlatClipAdam(model=...) lays SimpleAttention's pack groups out back to back, so the packed QKV weight / bias and the
+    per-head LayerNorm parameters are VIEWS of the bucket (no torch.cat / torch.stack launches); without `model` they are
+    copies.  Both must train identically, and the views must really alias the parameters."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip
+    outs = []
+    for with_model in (False, True):
+        torch.manual_seed(3)
+        model = gt.FourierTransformer2D(**bench.darcy_config()).to(gpu_device).train()
+        gt.set_attention_dropout("reference")
+        batch = bench.synthetic_batch(2, gpu_device, 5)
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = gt.FlatClipAdam(params, lr=1e-3, max_norm=0.99, model=model if with_model else None)
+        attn = model.encoder_layers[0].attn
+        wqkv, bqkv, gamma, beta, _ = attn._packed()
+        aliased = wqkv.data_ptr() == attn.linears[0].weight.data_ptr()
+        assert aliased == with_model
+        if with_model:
+            assert bqkv.data_ptr() == attn.linears[0].bias.data_ptr() and gamma.data_ptr() == attn.norm_K[0].weight.data_ptr()
+            assert torch.equal(wqkv, torch.cat([l.weight for l in attn.linears])) and tuple(gamma.shape) == (2, attn.n_head, attn.d_k)
+            assert torch.equal(beta.reshape(-1), torch.cat([m.bias for m in list(attn.norm_K) + list(attn.norm_V)]))
+        _hip.set_seed(50, gpu_device)
+        _hip._salt[0] = 7
+        for _ in range(2):
+            for p in params:
+                p.grad = None
+            _hip.advance_seed(gpu_device)
+            out = model(batch["node"], None, batch["pos"], batch["grid"])["preds"]
+            ((out - batch["target"]) ** 2).mean().backward()
+            opt.step()
+        torch.cuda.synchronize()
+        outs.append([p.detach().clone() for p in model.parameters()])
+    worst = max(float((a - b).abs().max()) for a, b in zip(*outs))
+    assert worst < 1e-6, worst
+
+
 def test_graph_step_equals_eager_step(gpu_device):
     """Same seed => the captured training step (fwd+bwd+clip+Adam, all dropouts on) updates the
     parameters exactly like the eager step."""

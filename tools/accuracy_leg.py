@@ -94,7 +94,7 @@ def run(impl: str, epochs: int = EPOCHS, log=None, optimizer: str = "flat", attn
         gt.set_attention_dropout(attn_dropout)
         gt.get_seed(dropout_seed, printout=False)
         Loss, train_batch, validate = gt.WeightedL2Loss2d, UF.train_batch_darcy, UF.validate_epoch_darcy
-        opt = (gt.FlatClipAdam(model.parameters(), lr=1e-3, max_norm=0.99) if optimizer == "flat"
+        opt = (gt.FlatClipAdam(model.parameters(), lr=1e-3, max_norm=0.99, model=model) if optimizer == "flat"
                else torch.optim.Adam(model.parameters(), lr=1e-3))
     g = torch.Generator().manual_seed(SEED)
     tl = DataLoader(train, batch_size=BATCH, shuffle=True, drop_last=True, generator=g)
