@@ -225,6 +225,7 @@ class Trainer:
         self.use_graph = use_graph
 
     def fwd_bwd(self):
+        self._hip.weight_packs.refresh()         # every weight of the step packed in ONE launch (they changed in opt_step)
         self._hip.advance_seed(self.dev)
         loss = self.loss_fn(self.model, self.batch)
         loss.backward()
@@ -241,6 +242,7 @@ class Trainer:
             self.reducer.reduce()
 
     def opt_step(self):
+        self._hip.weight_packs.invalidate()      # the weights are about to change
         if self.flat:
             self.opt.apply()
         else:

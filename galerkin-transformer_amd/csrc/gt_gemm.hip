@@ -662,7 +662,7 @@ static int64_t ws_bytes_one(const gt_gemm_desc* d) {
     Plan pl;
     if (d && !getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return tsmm_ws_bytes(d);
     if (make_plan(d, &pl)) return 0;
-    if (pl.x3 && x3_packed_ok(d, pl.x3, pl.split)) return x3_packed_bytes(d);
+    if (pl.x3 && x3_packed_ok(d, pl.x3, pl.split)) return d->b_packed ? 0 : x3_packed_bytes(d);
     const int64_t parts = acs_parts(d, pl);
     if (d->ep_mode == GT_EP_MLP_BWD)
         return (int64_t)pl.tiles_m * kCfgs[pl.cfg].wm * d->n_out * d->N * (int64_t)sizeof(float);
@@ -921,6 +921,25 @@ static bool width_split(const gt_gemm_desc* d, gt_gemm_desc* a, gt_gemm_desc* b)
 // Widths just above a multiple of 128 (the merged-head width h*(d_k+p) = 144 of the Darcy model) would
 // waste most of a second 128-wide tile column: run the aligned part and the remainder as two launches,
 // the remainder on a narrow-tile configuration.
+// > 0: gt_gemm(d) is ONE launch of the packed-B kernels and this is the size of its packed weight (the buffer a caller that
+// packs ahead -- gt_gemm_pack_b_many -- hands over in d->b_packed); 0: some other path, b_packed must stay NULL
+extern "C" int64_t gt_gemm_packed_b_bytes(const gt_gemm_desc* d) {
+    if (!d) return 0;
+    gt_gemm_desc a, b;
+    if (width_split(d, &a, &b)) return 0;
+    Plan pl;
+    if (!getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return 0;
+    if (make_plan(d, &pl) || !pl.x3 || !x3_packed_ok(d, pl.x3, pl.split)) return 0;
+    return x3_packed_bytes(d);
+}
+
+extern "C" int gt_gemm_pack_b_many(const gt_gemm_desc* descs, void* const* outs, int32_t n, void* stream) {
+    if (!descs || !outs) return GT_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (gt_gemm_packed_b_bytes(&descs[i]) <= 0) return GT_ENOTSUP;
+    return x3_pack_b_many(descs, outs, n, (hipStream_t)stream);
+}
+
 extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream) {
     if (!d) return GT_EINVAL;
     gt_gemm_desc a, b;

@@ -390,6 +390,7 @@ const char* x3_kernel_name(const GemmP& p, int layout_a, int layout_b, int plane
 // launch (fills ws, sets p.Bp / bp_NT / bp_KS)
 bool x3_packed_ok(const gt_gemm_desc* d, int planes, int split);
 int64_t x3_packed_bytes(const gt_gemm_desc* d);
+int x3_pack_b_many(const gt_gemm_desc* descs, void* const* outs, int n, hipStream_t st);
 int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipStream_t st);
 bool x3w_ok(const gt_gemm_desc* d, int split);
 

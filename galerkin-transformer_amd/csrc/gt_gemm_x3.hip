@@ -963,10 +963,10 @@ __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict_
 
 // GT_PREC_F16X2: the two fp16 planes of B in the same fragment order, one block per 32-column tile: pass 1 takes the tile's
 // amax (its exponent e: amax 2^e in [2^13, 2^14)), pass 2 splits the scaled values.  The exponents follow the planes as NT ints.
-__global__ __launch_bounds__(1024) void x3_pack_b16_kernel(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K,
-                                                           int NT, int KS, u32x4* __restrict__ out) {
+__device__ __forceinline__ void x3_pack_b16_tile(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K, int NT,
+                                                 int KS, u32x4* __restrict__ out, int nt) {
     __shared__ float red[16];
-    const int nt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = nt * 32 + (lane & 31);
     auto load8 = [&](int ks, float (&v)[8]) {        // this lane's eight k of stage ks (one row n, k contiguous or strided)
         const int k0 = ks * 16 + 8 * (lane >> 5);
@@ -1025,6 +1025,25 @@ __global__ __launch_bounds__(1024) void x3_pack_b16_kernel(const float* __restri
         store(ks, v);
     }
     if (tid == 0) reinterpret_cast<int*>(out + (int64_t)2 * NT * KS * 64)[nt] = e;
+}
+__global__ __launch_bounds__(1024) void x3_pack_b16_kernel(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K,
+                                                           int NT, int KS, u32x4* __restrict__ out) {
+    x3_pack_b16_tile(B, layout_b, ldb, N, K, NT, KS, out, blockIdx.x);
+}
+// All the step's weights in ONE launch (round 5, dispatch diet: a step packed 45 weights in 45 launches of 5 - 8 us): block b
+// works tile b - start[e] of entry e.
+constexpr int X3_PACK_MANY = 64;
+struct PackManyP {
+    const float* B[X3_PACK_MANY];
+    u32x4* out[X3_PACK_MANY];
+    int64_t ldb[X3_PACK_MANY];
+    int layout_b[X3_PACK_MANY], N[X3_PACK_MANY], K[X3_PACK_MANY], NT[X3_PACK_MANY], KS[X3_PACK_MANY], start[X3_PACK_MANY + 1];
+    int n;
+};
+__global__ __launch_bounds__(1024) void x3_pack_b16_many_kernel(const PackManyP p) {
+    int e = 0;
+    while (e + 1 < p.n && (int)blockIdx.x >= p.start[e + 1]) ++e;
+    x3_pack_b16_tile(p.B[e], p.layout_b[e], p.ldb[e], p.N[e], p.K[e], p.NT[e], p.KS[e], p.out[e], (int)blockIdx.x - p.start[e]);
 }
 
 #ifndef GT_X3P_BLOCKS                              // resident blocks per CU the general instances are compiled for
@@ -2006,6 +2025,12 @@ static inline int x3p_ks(int K) { return (K + X3_BK - 1) / X3_BK; }
 int64_t x3_packed_bytes(const gt_gemm_desc* d) { return (int64_t)3 * x3p_nt(d->N) * x3p_ks(d->K) * 1024; }
 
 int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipStream_t st) {
+    if (d->b_packed) {                             // the caller packed this weight already (gt_gemm_pack_b_many)
+        if (reinterpret_cast<uintptr_t>(d->b_packed) & 15) return GT_EALIGN;
+        p.bp_f16 = d->precision == GT_PREC_F16X2;
+        p.Bp = d->b_packed; p.bp_NT = x3p_nt(d->N); p.bp_KS = x3p_ks(d->K);
+        return 0;
+    }
     if (!ws || ws_bytes < x3_packed_bytes(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) return GT_EWS;
     const int NT = x3p_nt(d->N), KS = x3p_ks(d->K);
     const int threads = NT * KS * 64;
@@ -2018,6 +2043,25 @@ int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipSt
                            d->K, NT, KS, reinterpret_cast<u32x4*>(ws));
     GT_LAUNCH_CHECK();
     p.Bp = ws; p.bp_NT = NT; p.bp_KS = KS;
+    return 0;
+}
+
+int x3_pack_b_many(const gt_gemm_desc* descs, void* const* outs, int n, hipStream_t st) {
+    if (n <= 0 || n > X3_PACK_MANY) return GT_EINVAL;
+    PackManyP q{};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const gt_gemm_desc* d = &descs[i];
+        if (d->precision != GT_PREC_F16X2 || !d->B || !outs[i] || (reinterpret_cast<uintptr_t>(outs[i]) & 15)) return GT_ENOTSUP;
+        q.B[i] = d->B; q.out[i] = reinterpret_cast<u32x4*>(outs[i]); q.ldb[i] = d->ldb; q.layout_b[i] = d->layout_b;
+        q.N[i] = d->N; q.K[i] = d->K; q.NT[i] = x3p_nt(d->N); q.KS[i] = x3p_ks(d->K);
+        q.start[i] = blocks;
+        blocks += q.NT[i];
+    }
+    q.start[n] = blocks;
+    q.n = n;
+    hipLaunchKernelGGL(x3_pack_b16_many_kernel, dim3(blocks), dim3(1024), 0, st, q);
+    GT_LAUNCH_CHECK();
     return 0;
 }
 

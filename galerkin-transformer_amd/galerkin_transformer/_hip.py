@@ -66,6 +66,7 @@ class GtGemmDesc(C.Structure):
         ("precision", C.c_int32),
         ("cv_h", C.c_int32), ("cv_w", C.c_int32), ("cv_c", C.c_int32), ("cv_wgrad", C.c_int32),
         ("hn_skip_raw_mask", C.c_int32), ("hn_plain", C.c_int32),
+        ("b_packed", C.c_void_p),
     ]
 
 
@@ -79,6 +80,8 @@ _PROTOS = {
     "gt_gemm_desc_init": (None, [C.POINTER(GtGemmDesc)]),
     "gt_gemm_ws_bytes": (C.c_int64, [C.POINTER(GtGemmDesc)]),
     "gt_gemm": (C.c_int, [C.POINTER(GtGemmDesc), C.c_void_p, C.c_int64, C.c_void_p]),
+    "gt_gemm_packed_b_bytes": (C.c_int64, [C.POINTER(GtGemmDesc)]),
+    "gt_gemm_pack_b_many": (C.c_int, [C.POINTER(GtGemmDesc), C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "gt_gemm_plan": (C.c_int, [C.POINTER(GtGemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                C.POINTER(C.c_int32)]),
     "gt_gemm_kernel_name": (C.c_int, [C.POINTER(GtGemmDesc), C.c_char_p, C.c_int32]),
@@ -482,6 +485,72 @@ def dropout_desc(p: float, salt: int, device: torch.device) -> GtDropout:
     return d
 
 
+# ----------------------------------------------------------------------------------- weights packed ahead
+class _WeightPacks:
+    """One pack launch per step for the model's weights (dispatch diet): a token product whose B operand is flagged as a
+    model weight (`gemm(..., weight_b=True)`: a parameter at a stable address) registers (B, layout, N, K) on first sight;
+    `refresh()` -- called by the training step before its forward, i.e. after the optimizer last changed the weights --
+    packs every registered weight in ONE launch (gt_gemm_pack_b_many) into persistent buffers, and until `invalidate()`
+    the products take them through gt_gemm_desc.b_packed instead of packing per call.  Outside refresh() / invalidate()
+    brackets nothing changes (per-call packs).  GT_PACK_ALL=0 switches it off."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("GT_PACK_ALL", "1") != "0"
+        self.entries = {}          # key -> [desc copy, buffer or None, B (kept alive: its address is the key), last round seen]
+        self.ready = set()
+        self.round = 0
+
+    def use(self, d, B):
+        """b_packed for this product if it was packed in the current bracket.  A product is packed ahead only once it has
+        been seen in two different brackets with the same operand address (a weight that is re-materialised every step --
+        a torch.cat of parameters, a padded copy -- never qualifies and is forgotten)."""
+        if not self.enabled or self.round == 0 or d.precision != PREC_F16X2:     # round 0: nobody brackets steps with refresh()
+            return
+        key = (B.data_ptr(), d.layout_b, d.ldb, d.N, d.K, B.device.index)
+        ent = self.entries.get(key)
+        if ent is None:
+            need = int(lib().gt_gemm_packed_b_bytes(C.byref(d)))
+            if need > 0 and len(self.entries) < 512:
+                self.entries[key] = [GtGemmDesc.from_buffer_copy(d), None, B, self.round, need]
+            return
+        if ent[1] is None and ent[3] != self.round and not torch.cuda.is_current_stream_capturing():
+            ent[1] = torch.empty(ent[4], dtype=torch.uint8, device=B.device)      # second sight: packed from the next bracket on
+        ent[3] = self.round
+        if key in self.ready:
+            d.b_packed = ent[1].data_ptr()
+
+    def refresh(self):
+        self.ready = set()
+        if not self.enabled:
+            return
+        # forget what the last bracket did not use (transient operands); pack what has a buffer
+        for k in [k for k, e in self.entries.items() if e[3] < self.round - 1]:
+            del self.entries[k]
+        self.round += 1
+        items = [(k, e) for k, e in self.entries.items() if e[1] is not None]
+        for i0 in range(0, len(items), 64):
+            chunk = items[i0:i0 + 64]
+            descs = (GtGemmDesc * len(chunk))(*[e[0] for _, e in chunk])
+            outs = (C.c_void_p * len(chunk))(*[e[1].data_ptr() for _, e in chunk])
+            rc = _timed("gt_gemm_pack_b_many", 0.0, 0.0,
+                        lambda: lib().gt_gemm_pack_b_many(descs, outs, len(chunk), stream_ptr()), shape=(len(chunk),))
+            if rc == -4:               # GT_ENOTSUP (an entry no longer takes the packed path): per-call packs this bracket
+                self.ready = set()
+                return
+            check(rc, "gt_gemm_pack_b_many")
+            self.ready.update(k for k, _ in chunk)
+
+    def invalidate(self):
+        self.ready = set()
+
+    def clear(self):
+        self.entries.clear()
+        self.ready = set()
+
+
+weight_packs = _WeightPacks()
+
+
 # ----------------------------------------------------------------------------------- GEMM
 def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K: int, *,
          layout_a: int = 0, layout_b: int = 0, lda: int, ldb: int, ldc: int,
@@ -501,8 +570,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          dw2: Optional[torch.Tensor] = None,
          K2: int = 0, A2: Optional[torch.Tensor] = None, lda2: int = 0, a2_bs=(0, 0),
          B2: Optional[torch.Tensor] = None, ldb2: int = 0, b2_bs=(0, 0), hn: Optional[dict] = None,
-         precision: Optional[str] = None, conv: Optional[Tuple[int, int, int]] = None, conv_wgrad: bool = False):
-    """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics).  precision=None uses the module mode
+         precision: Optional[str] = None, conv: Optional[Tuple[int, int, int]] = None, conv_wgrad: bool = False,
+         weight_b: bool = False):
+    """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics).  weight_b: B is a model weight at a stable address
+    (eligible for the once-per-step pack, weight_packs).  precision=None uses the module mode
     (set_precision).  conv=(H, W, C): A is a channels-last [B, H, W, C] image and the product is the implicit 3x3
     convolution (K = 9*C; gt_hip.h: cv_*); with conv_wgrad, B is that image and the nine batch entries are the taps of the
     weight gradient.  Cout may be None for a GT_EP_HEADNORM launch that stores no raw projection (hn["skip_raw"] == 7)."""
@@ -564,6 +635,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if conv is not None:
         d.cv_h, d.cv_w, d.cv_c = conv
         d.cv_wgrad = int(conv_wgrad)
+    if weight_b:
+        weight_packs.use(d, B)
     need = L.gt_gemm_ws_bytes(C.byref(d))
     wsp, wsn = None, 0
     if need > 0:

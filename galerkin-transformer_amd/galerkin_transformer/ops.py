@@ -820,13 +820,13 @@ class FeedForwardFn(Function):
         hid = torch.empty(T, f, dtype=torch.float32, device=dev)
         pre = torch.empty(T, f, dtype=torch.float32, device=dev) if act == H.ACT_SILU else None
         H.gemm(xc, w1c, hid, T, f, d, lda=d, ldb=d, ldc=f, bias=b1, act=act, pre=pre, ldpre=f,
-               drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None)
+               drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None, weight_b=True)
         if _relu_mask_sink[0] is not None and act == H.ACT_RELU and p_h == 0:
             _relu_mask_sink[0].append(hid > 0)
         out = torch.empty(T, dout, dtype=torch.float32, device=dev)
         rc = None if res is None else _c(res).reshape(T, dout)
         H.gemm(hid, w2c, out, T, dout, f, lda=f, ldb=f, ldc=dout, bias=b2,
-               drop=H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None, res=rc, ldr=dout)
+               drop=H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None, res=rc, ldr=dout, weight_b=True)
         ctx.save_for_backward(xc, w1c, w2c, hid, pre)
         ctx.cfg = (act, p_h, p_out, salt, d, f, dout, b1 is not None, b2 is not None, res is not None,
                    x.shape)
@@ -853,18 +853,18 @@ class FeedForwardFn(Function):
                    a_colsum=db2)
         if act == H.ACT_RELU:
             H.gemm(gm, w2c, gh, T, f, dout, layout_b=1, lda=dout, ldb=f, ldc=f,
-                   aux_op=H.AUX_GT0, aux=hid, ldaux=f, aux_scale=1.0 / (1.0 - p_h))
+                   aux_op=H.AUX_GT0, aux=hid, ldaux=f, aux_scale=1.0 / (1.0 - p_h), weight_b=True)
         else:
             H.gemm(gm, w2c, gh, T, f, dout, layout_b=1, lda=dout, ldb=f, ldc=f,
                    aux_op=H.AUX_DSILU, aux=pre, ldaux=f,
-                   drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None)
+                   drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None, weight_b=True)
         dw1 = torch.empty(f, d, dtype=torch.float32, device=dev)
         db1 = torch.empty(f, dtype=torch.float32, device=dev) if hb1 else None
         dx = torch.empty(T, d, dtype=torch.float32, device=dev)
         with H.side_branch(dev, T):
             H.gemm(gh, xc, dw1, f, d, T, layout_a=1, layout_b=1, lda=f, ldb=d, ldc=d, split_k=0, a_colsum=db1)
         same = has_res and dout == d
-        H.gemm(gh, w1c, dx, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=g if same else None, ldr=d)
+        H.gemm(gh, w1c, dx, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=g if same else None, ldr=d, weight_b=True)
         H.join_side(dev)
         dx = dx.reshape(xshape)
         # the residual input is x itself: its gradient g is already folded into dx (res epilogue above), so the
@@ -916,7 +916,7 @@ class SimpleAttentionFn(Function):
                 qkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
             try:
                 # the raw projection is kept for the LayerNorm backward only: the normalised streams' blocks of qkv
-                H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv,
+                H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv, weight_b=True,
                        hn=dict(gamma=gamma, beta=beta, pos=posc, out=out3, stats=stats, h=h, dk=dk, p=p,
                                norm_mask=norm_mask, eps=eps, skip_raw=7 if plain else (~norm_mask) & 7, plain=plain))
             except H.GtNotSupported:                          # shapes / alignment the fused kernel does not take
@@ -924,7 +924,7 @@ class SimpleAttentionFn(Function):
         if out3 is None:
             plain = False
             qkv = torch.empty(T, 3 * d, dtype=torch.float32, device=dev)
-            H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
+            H.gemm(xc, wq, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=bqkv, weight_b=True)
             out3, stats = H.headnorm_fwd(qkv, posc, gamma, beta, T, h, dk, p, norm_mask, eps)
         Qp, Kp, Vp = out3[0], out3[1], out3[2]
         hD = h * DP
@@ -1101,7 +1101,7 @@ class SimpleAttentionFn(Function):
             H.gemm(dqkv, xc, dwqkv, 3 * d, d, T, layout_a=1, layout_b=1, lda=3 * d, ldb=d, ldc=d, split_k=0,
                    a_colsum=dbqkv)
         H.gemm(dqkv, wq, dx, T, d, 3 * d, layout_b=1, lda=3 * d, ldb=d, ldc=d, res=g_in if has_res else None,
-               ldr=d)
+               ldr=d, weight_b=True)
         H.join_side(dev)
         dres = None                                          # folded into dx (res is x): contributes nothing
         if not norm_mask:

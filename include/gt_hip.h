@@ -216,6 +216,11 @@ typedef struct gt_gemm_desc {
      * on load, gt_galerkin_dkv_ln_plain folded into dM), whose LayerNorm backward then needs no raw projection at all:
      * with hn_skip_raw_mask = 7 the launch writes nothing to C and C may be NULL. */
     int32_t hn_plain;
+
+    /* Pre-packed B (round 5, ABI v19): NULL, or the buffer gt_gemm_pack_b_many filled for exactly this product (same B,
+     * layout_b, ldb, N, K, precision = GT_PREC_F16X2) since B last changed -- gt_gemm then skips its own pack launch and
+     * needs no workspace.  Only where gt_gemm_packed_b_bytes(d) > 0. */
+    const void* b_packed;
 } gt_gemm_desc;
 
 #define GT_PREC_F32    0
@@ -232,6 +237,11 @@ typedef struct gt_gemm_desc {
 void    gt_gemm_desc_init(gt_gemm_desc* d);            /* zero + alpha=1, out_scale=1, batch=1 */
 int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d);
 int     gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream);
+/* Weights packed ahead, all in one launch (the model-API counterpart of "one pack launch per step": every nn.Linear weight of
+ * layers.py:811,823,964,976 feeds 2 token products per step).  gt_gemm_packed_b_bytes: size of d's packed weight if gt_gemm(d)
+ * is a single packed-B launch, else 0.  gt_gemm_pack_b_many: descs[i].B -> outs[i] for n <= 64 products (GT_PREC_F16X2). */
+int64_t gt_gemm_packed_b_bytes(const gt_gemm_desc* d);
+int     gt_gemm_pack_b_many(const gt_gemm_desc* descs, void* const* outs, int32_t n, void* stream);
 /* debugging/tests: which tile configuration and split the library picks */
 int     gt_gemm_plan(const gt_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* split);
 /* symbol of the kernel instance gt_gemm would launch for d, as a profiler prints it */

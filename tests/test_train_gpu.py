@@ -125,6 +125,48 @@ def test_packed_parameter_views_equal_the_copies(gpu_device):
     assert worst < 1e-6, worst
 
 
+def test_weights_packed_once_per_step_equal_per_call_packs(gpu_device):
+    """_hip.weight_packs: from the third step on the Trainer packs every Linear weight of the step in ONE launch
+    (gt_gemm_pack_b_many) and the token products take the buffers through gt_gemm_desc.b_packed; the parameters after five
+    steps must equal those of the per-call packs (GT_PACK_ALL=0 behaviour) bit for bit, and the per-call pack launches of
+    those products must be gone from the step."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip
+    outs, packs = [], []
+    try:
+        for enabled in (False, True):
+            _hip.weight_packs.clear()
+            _hip.weight_packs.enabled = enabled
+            torch.manual_seed(3)
+            model = gt.FourierTransformer2D(**bench.darcy_config()).to(gpu_device).train()
+            gt.set_attention_dropout("reference")
+            batch = bench.synthetic_batch(16, gpu_device, 5)           # 16 x 1849 token rows: the packed-B kernels
+            tr = bench.Trainer(model, batch, 1, use_graph=False)
+            _hip.set_seed(50, gpu_device)
+            _hip._salt[0] = 7
+            for _ in range(4):
+                tr.eager_step()
+            with _hip.Profile() as prof:
+                tr.eager_step()
+            torch.cuda.synchronize()
+            t = prof.table()
+            packs.append((t.get("gt_gemm_pack_b_many", {}).get("calls", 0),
+                          sum(1 for e in _hip.weight_packs.entries.values() if e[1] is not None),
+                          sum(v["calls"] for k, v in t.items() if k.startswith("gemm_x3h"))))
+            outs.append([p.detach().clone() for p in model.parameters()])
+    finally:
+        _hip.weight_packs.enabled = os.environ.get("GT_PACK_ALL", "1") != "0"
+        _hip.weight_packs.clear()
+    assert packs[0][:2] == (0, 0)
+    assert packs[1][0] == 1 and packs[1][1] >= 30, packs           # 6 layers x (QKV, FFN1, FFN2) x (forward, data gradient)
+    assert packs[0][2] == packs[1][2] > 0                          # the same products ran on the packed-B kernels
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
 def test_graph_step_equals_eager_step(gpu_device):
     """Same seed => the captured training step (fwd+bwd+clip+Adam, all dropouts on) updates the
     parameters exactly like the eager step."""

@@ -46,12 +46,12 @@ for step in "$@"; do
     prof)
       cd /tmp
       GT_DUAL_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o trace --output-format csv -- \
-          python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-f32-leg --no-accuracy > $O/prof.log 2>&1
+          python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-f32-leg --no-accuracy $arg > $O/prof.log 2>&1
       cd $R
       MS=$(grep '^{"metric' $O/prof.log | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step']*10)")
-      python tools/prof_csv_summary.py $O/prof 90 --last-ms $MS --by-grid > $O/kernel_stats_steady.txt 2>&1
+      python tools/prof_csv_summary.py $O/prof 90 --last-ms $MS --by-grid > $O/kernel_stats_steady${arg// /_}.txt 2>&1
       rm -rf $O/prof
-      head -30 $O/kernel_stats_steady.txt | cut -c1-150;;
+      head -30 $O/kernel_stats_steady${arg// /_}.txt | cut -c1-150;;
     pmc)
       cd /tmp
       for C in FETCH_SIZE WRITE_SIZE; do
