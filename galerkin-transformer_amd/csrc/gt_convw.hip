@@ -66,8 +66,9 @@ constexpr int CW_MAXW = 8 * CW_NQ;
 struct ConvWP {
     const float* gy; int64_t ldg;      // [B*H*W][>= Cout] pixel pitch ldg
     const float* x; int64_t ldx;       // [B*H*W][>= Cin]
-    float* slabs;                      // [B * chunks][9][Cin][Cout]
+    float* slabs;                      // [B * chunks * nseg][9][Cin][Cout]
     int B, H, W, Cin, Cout, chunks, rows_per_chunk;
+    int nseg, seg_w;                   // rows wider than 80 pixels are worked in nseg segments of seg_w x-pixels (round 5)
 };
 
 // channel c of a C-channel block sits at LDS position (c & 3) * (C / 4) + (c >> 2): the four channels of a staged float4
@@ -114,17 +115,23 @@ struct CwStage {
     int lds[NITEM];                                        // byte offset of (unit q, position g, dword pair mm) in plane 0, or -1
     int stride10;
 
-    __device__ __forceinline__ void init(int64_t ld, int W, int tid) {
+    // x0, S: the block's segment [x0, x0 + S) of the row (S <= 80).  The x operand (QOFF = 0) stages exactly those pixels; the
+    // gy operand (QOFF = -1) also its two neighbours x0 - 1 and x0 + S -- the halo units of the horizontal taps: real data
+    // where the neighbour is inside the picture (another block's segment), zero outside.
+    __device__ __forceinline__ void init(int64_t ld, int W, int tid, int x0, int S) {
         stride10 = (int)(10 * ld);
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
             const int idx = tid + it * NT;
             const int g = idx % G4, mm = (idx / G4) & 1, q = idx / (2 * G4);
             const int px0 = q + QOFF + 40 * mm;
-            off0[it] = px0 * (int)ld + 4 * g;
+            off0[it] = (x0 + px0) * (int)ld + 4 * g;
             int m = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) m |= (idx < ITEMS && px0 + 10 * e >= 0 && px0 + 10 * e < W) ? (1 << e) : 0;
+            for (int e = 0; e < 4; ++e) {
+                const int ps = px0 + 10 * e;               // position in the segment
+                m |= (idx < ITEMS && ps >= QOFF && ps < S - QOFF && x0 + ps >= 0 && x0 + ps < W) ? (1 << e) : 0;
+            }
             vm[it] = m;
             lds[it] = idx < ITEMS ? ((q * C + g) << 4) + 8 * mm : -1;
         }
@@ -202,13 +209,13 @@ extern __shared__ __attribute__((aligned(16))) char cw_smem[];
 // ROLE 0: the x rows (prologue rows y0 - 1 .. y0 + 1, then row y + 2 during the MFMAs of row y); ROLE 1: the gy rows (row y0,
 // then row y + 1).  `base`: pixel (0, 0) of the block's image with the channel block offset applied.
 template <int CIT, int COT, int F16, int ROLE>
-__device__ __noinline__ void cw_loader(const float* base, int64_t ld, int H, int W, int y0, int y1, int lt) {
+__device__ __noinline__ void cw_loader(const float* base, int64_t ld, int H, int W, int y0, int y1, int lt, int x0, int S) {
     using G = CwGeom<CIT, COT, F16>;
     char* buf = cw_smem + (ROLE == 0 ? G::XS : G::YS);
     int* exps = reinterpret_cast<int*>(cw_smem + G::ES) + (ROLE == 0 ? 0 : 4);   // exponent each slot / buffer was split with
     auto rowp = [&](int y) __attribute__((always_inline)) -> const float* { return (y >= 0 && y < H) ? base + (int64_t)y * W * ld : nullptr; };
     CwStage<(ROLE == 0 ? G::CI : G::CO), (ROLE == 0 ? CW_NQ : CW_NQ + 2), (ROLE == 0 ? 0 : -1), CW_LOADERS, G::PL> st;
-    st.init(ld, W, lt);
+    st.init(ld, W, lt, x0, S);
     int e = CWH_E0;                                        // F16: the block's running exponent of this operand
     // split + write the row in flight: the exponent first drops if this row's amax asks for it
     // (always_inline: left to its heuristics hipcc OUTLINED this lambda in the three-plane instances -- the staged row then
@@ -378,18 +385,19 @@ __global__ __launch_bounds__(CW_THREADS, 1) void convw_kernel(const ConvWP p) {
     using G = CwGeom<CIT, COT, F16>;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci0 = blockIdx.y * G::CI, co0 = blockIdx.z * G::CO;
-    const int bc = blockIdx.x, b = bc / p.chunks, chunk = bc - b * p.chunks;
+    const int bcs = blockIdx.x, bc = bcs / p.nseg, seg = bcs - bc * p.nseg, b = bc / p.chunks, chunk = bc - b * p.chunks;
     const int y0 = chunk * p.rows_per_chunk, y1 = min(p.H, y0 + p.rows_per_chunk);
+    const int x0 = seg * p.seg_w, S = min(p.seg_w, p.W - x0);
     for (int i = tid; i < G::ES / 16; i += CW_THREADS)
         reinterpret_cast<cw_u32x4*>(cw_smem)[i] = cw_u32x4{0u, 0u, 0u, 0u};
     if (tid < 8) reinterpret_cast<int*>(cw_smem + G::ES)[tid] = CWH_E0;
     __syncthreads();
     if (wave == 0)
-        cw_loader<CIT, COT, F16, 0>(p.x + (int64_t)b * p.H * p.W * p.ldx + ci0, p.ldx, p.H, p.W, y0, y1, tid & 63);
+        cw_loader<CIT, COT, F16, 0>(p.x + (int64_t)b * p.H * p.W * p.ldx + ci0, p.ldx, p.H, p.W, y0, y1, tid & 63, x0, S);
     else if (wave == 4)
-        cw_loader<CIT, COT, F16, 1>(p.gy + (int64_t)b * p.H * p.W * p.ldg + co0, p.ldg, p.H, p.W, y0, y1, tid & 63);
+        cw_loader<CIT, COT, F16, 1>(p.gy + (int64_t)b * p.H * p.W * p.ldg + co0, p.ldg, p.H, p.W, y0, y1, tid & 63, x0, S);
     else
-        cw_mfma<CIT, COT, F16>(p.slabs + (int64_t)bc * 9 * p.Cin * p.Cout, p.Cin, p.Cout, ci0, co0, y0, y1, wave - 2, tid & 63);
+        cw_mfma<CIT, COT, F16>(p.slabs + (int64_t)bcs * 9 * p.Cin * p.Cout, p.Cin, p.Cout, ci0, co0, y0, y1, wave - 2, tid & 63);
 }
 
 // dw[co][ci][tap] = alpha * sum_s slabs[s][tap][ci][co]
@@ -410,14 +418,16 @@ __global__ __launch_bounds__(256) void convw_reduce_kernel(const float* __restri
     dw[((int64_t)co * Cin + ci) * 9 + tap] = alpha * ((s0 + s1) + (s2 + s3));
 }
 
-struct CwPlan { int cit, cot, f16, ciblocks, coblocks, chunks, rows; size_t lds; };
+struct CwPlan { int cit, cot, f16, ciblocks, coblocks, chunks, rows, nseg, seg_w; size_t lds; };
 
 // Channel blocks of one thread block: outputs of 48 channels (the down-scaler's narrow convolutions, padded) in one piece,
 // wide outputs (the up-scaler's 128 -> 128 convolution) in blocks of 64; inputs in the widest block that divides Cin and fits
 // the LDS (two fp16 planes: up to 64 channels; three bf16 planes: 48 / 32).  One block per CU (ring of four x rows + two gy rows).
 static bool cw_plan(int B, int H, int W, int Cin, int Cout, int f16, CwPlan* pl) {
-    if (B <= 0 || H <= 0 || W <= 0 || W > CW_MAXW || Cin <= 0 || Cout <= 0 || (Cin & 15)) return false;
+    if (B <= 0 || H <= 0 || W <= 0 || W > 64 * CW_MAXW || Cin <= 0 || Cout <= 0 || (Cin & 15)) return false;
     pl->f16 = f16;
+    pl->nseg = (W + CW_MAXW - 1) / CW_MAXW;                 // rows wider than 80 pixels: equal segments (C3: 113 / 114 -> 2 x 57)
+    pl->seg_w = (W + pl->nseg - 1) / pl->nseg;
     if (Cout == 48) {
         pl->cot = 3;
         pl->cit = (f16 && Cin % 64 == 0) ? 4 : (Cin % 48 == 0) ? 3 : (Cin % 32 == 0) ? 2 : 1;
@@ -436,7 +446,7 @@ static bool cw_plan(int B, int H, int W, int Cin, int Cout, int f16, CwPlan* pl)
     }
     pl->ciblocks = Cin / (16 * pl->cit);
     pl->coblocks = Cout / (16 * pl->cot);
-    const int per_row = B * pl->ciblocks * pl->coblocks;
+    const int per_row = B * pl->ciblocks * pl->coblocks * pl->nseg;
     int chunks = std::max(1, (256 + per_row - 1) / per_row);
     chunks = std::min(chunks, std::max(1, H / 8));          // at least eight rows per block: the three-row prologue is paid once
     pl->rows = (H + chunks - 1) / chunks;
@@ -457,8 +467,8 @@ extern "C" int64_t gt_conv3x3_wgrad_nhwc_ws_bytes(int32_t B, int32_t H, int32_t 
     CwPlan p0, p1;
     const bool ok0 = cw_plan(B, H, W, Cin, Cout, 0, &p0), ok1 = cw_plan(B, H, W, Cin, Cout, 1, &p1);
     if (!ok0 && !ok1) return 0;
-    const int chunks = std::max(ok0 ? p0.chunks : 0, ok1 ? p1.chunks : 0);
-    return (int64_t)B * chunks * 9 * Cin * Cout * (int64_t)sizeof(float);
+    const int chunks = std::max(ok0 ? p0.chunks : 0, ok1 ? p1.chunks : 0), nseg = ok0 ? p0.nseg : p1.nseg;
+    return (int64_t)B * chunks * nseg * 9 * Cin * Cout * (int64_t)sizeof(float);
 }
 
 extern "C" int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* x, int64_t ldx, float* dw, int32_t B,
@@ -469,11 +479,12 @@ extern "C" int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* 
     CwPlan pl;
     if (!cw_plan(B, H, W, Cin, Cout, precision == GT_PREC_F16X2, &pl)) return GT_ENOTSUP;
     if (((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(x)) & 15) || (ldg & 3) || (ldx & 3)) return GT_EALIGN;
-    if (!ws || ws_bytes < (int64_t)B * pl.chunks * 9 * Cin * Cout * (int64_t)sizeof(float)) return GT_EWS;   // the plan launched
-    if ((int64_t)B * pl.chunks > 0x7fffffffLL) return GT_EINVAL;
-    ConvWP p{gy, ldg, x, ldx, reinterpret_cast<float*>(ws), B, H, W, Cin, Cout, pl.chunks, pl.rows};
+    const int64_t nslab = (int64_t)B * pl.chunks * pl.nseg;
+    if (!ws || ws_bytes < nslab * 9 * Cin * Cout * (int64_t)sizeof(float)) return GT_EWS;   // the plan launched
+    if (nslab > 0x7fffffffLL) return GT_EINVAL;
+    ConvWP p{gy, ldg, x, ldx, reinterpret_cast<float*>(ws), B, H, W, Cin, Cout, pl.chunks, pl.rows, pl.nseg, pl.seg_w};
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)(B * pl.chunks), (unsigned)pl.ciblocks, (unsigned)pl.coblocks);
+    const dim3 grid((unsigned)nslab, (unsigned)pl.ciblocks, (unsigned)pl.coblocks);
     // more than 64 KB of LDS per block: the limit is raised once per kernel instance
     // (the attribute is per device: one bit per device ordinal, set once; concurrent host threads at worst set it twice)
     static std::atomic<uint64_t> raised[16];
@@ -509,7 +520,7 @@ extern "C" int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* 
     if (rc) return rc;
     GT_LAUNCH_CHECK();
     const int n = 9 * Cin * Cout;
-    hipLaunchKernelGGL(convw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.slabs, B * pl.chunks, Cin, Cout, alpha,
+    hipLaunchKernelGGL(convw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.slabs, (int)nslab, Cin, Cout, alpha,
                        dw);
     GT_LAUNCH_CHECK();
     return 0;

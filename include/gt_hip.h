@@ -525,8 +525,10 @@ int64_t gt_conv3x3_resize_bits_bytes(int32_t B, int32_t Cout, int32_t Ho, int32_
  * place), 16-byte aligned, pitches multiples of 4.  dw: [Cout][Cin][3][3], the reference's layout.  precision: GT_PREC_BF16X3
  * (three bf16 planes, six products) or GT_PREC_F16X2 (two fp16 planes under one running power-of-two scale per operand and
  * block, three products); each operand value is split once per block (gt_convw.hip).
- * GT_ENOTSUP unless W <= 80 and (Cout == 48, Cin % 16 == 0: the down-scaler's padded narrow convolutions) or (Cout % 64 == 0,
- * Cin % 32 == 0: the up-scaler's 128 -> 128 convolution).  Deterministic: partial results per (image, row chunk) in ws
+ * GT_ENOTSUP unless (Cout == 48, Cin % 16 == 0: the down-scaler's padded narrow convolutions) or (Cout % 64 == 0,
+ * Cin % 32 == 0: the up-scaler's 128 -> 128 convolution).  Rows wider than 80 pixels are worked in equal x-segments of at
+ * most 80 (round 5: the 113 / 114-pixel rows of the 211 x 211 configuration).  Deterministic: partial results per (image, row
+ * chunk, segment) in ws
  * (>= gt_conv3x3_wgrad_nhwc_ws_bytes), summed in a fixed order.
  * ------------------------------------------------------------------------------------------- */
 int gt_conv3x3_wgrad_nhwc(const float* gy, int64_t ldg, const float* x, int64_t ldx, float* dw, int32_t B, int32_t H,

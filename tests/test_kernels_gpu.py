@@ -1465,6 +1465,10 @@ def test_conv3x3_resize_recorded_decisions(H, gpu_device, Cin, p_drop, n, scale)
     (5, 9, 80, 16, 16, 48, 1.0),            # one input tile, the widest row the LDS rows hold, few image rows
     (2, 20, 37, 32, 36, 48, -2.0),          # odd width, pitch > channels
     (1, 3, 5, 48, 48, 48, 1.0),             # tiny image: every row and column touches the zero padding
+    (2, 21, 114, 128, 128, 144, 1.0),       # C3 (211 x 211): the down-scaler's 114-pixel rows = two x-segments of 57
+    (1, 17, 113, 128, 128, -128, 1.0),      # C3: the up-scaler's 113 x 113, 128 -> 128
+    (1, 6, 243, 48, 48, 48, 1.0),           # four segments (61 pixels each), narrow chain
+    (2, 9, 81, 16, 16, 48, 1.0),            # one pixel over a segment: 41 + 40
 ])
 @pytest.mark.parametrize("prec", ["bf16x3", "f16x2"])
 def test_conv3x3_wgrad_nhwc_matches_conv2d(H, gpu_device, B, Hh, Ww, Cin, ldx, ldg, alpha, prec):
@@ -1510,8 +1514,8 @@ def test_conv3x3_wgrad_nhwc_rejects_what_it_does_not_cover(H, gpu_device):
     with pytest.raises(H.GtNotSupported):
         H.conv3x3_wgrad_nhwc(g, 48, x[:, :8], 16, 2, 8, 8, 8, 48)            # Cin % 16
     xw, gw = rnd(1 * 2 * 96, 16, dev=dev, seed=623), rnd(1 * 2 * 96, 48, dev=dev, seed=624)
-    with pytest.raises(H.GtNotSupported):
-        H.conv3x3_wgrad_nhwc(gw, 48, xw, 16, 1, 2, 96, 16, 48)               # W > 80
+    dw = H.conv3x3_wgrad_nhwc(gw, 48, xw, 16, 1, 2, 96, 16, 48)              # W > 80: two x-segments since round 5
+    assert tuple(dw.shape) == (48, 16, 3, 3) and bool(torch.isfinite(dw).all())
 
 
 @pytest.mark.parametrize("N,K", [(128, 128), (256, 128), (128, 384), (384, 128)])
