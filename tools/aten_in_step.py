@@ -26,7 +26,8 @@ from collections import Counter
 from torch.utils._python_dispatch import TorchDispatchMode
 
 WATCH = ("copy_", "fill_", "zero_", "cat", "stack", "clone", "flip", "add", "mul", "sub", "div", "mean", "pow", "_foreach_copy_",
-         "zeros", "zeros_like", "index_select", "sum", "neg", "where", "slice_backward", "select_backward", "constant_pad_nd")
+         "zeros", "zeros_like", "index_select", "sum", "neg", "where", "slice_backward", "select_backward", "constant_pad_nd",
+         "convolution", "convolution_backward", "miopen_convolution", "upsample_bilinear2d", "upsample_bilinear2d_backward", "silu", "silu_backward", "permute", "native_dropout")
 
 
 class Spy(TorchDispatchMode):
