@@ -603,13 +603,36 @@ def accuracy_leg(precision, n_seeds=10, first_seed=1000):
     return out
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the product sources -- csrc/*.hip, *.h, include/*.h, galerkin_transformer/*.py, bench.py --
+    the staleness key of the quoted records: .git does not travel to the GPU box, file contents do."""
+    import glob
+    import hashlib
+    pkg = os.path.join(ROOT, "galerkin-transformer_amd")
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(pkg, "galerkin_transformer", "*.py")) +
+                   [os.path.join(ROOT, "bench.py")])
+    hsh = hashlib.sha256()
+    for fn in files:
+        hsh.update(os.path.relpath(fn, ROOT).encode())
+        with open(fn, "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()[:16]
+
+
 def _profiles_commit():
-    """Commit the quoted profiles/ records were produced at (written by the measurement pass: profiles/SOURCE.json)."""
+    """Where the quoted profiles/ records come from (written by the measurement pass: profiles/SOURCE.json), and whether the
+    product sources are still the ones they were measured with (quoted records went stale silently)."""
     try:
         with open(os.path.join(ROOT, "profiles", "SOURCE.json")) as f:
-            return json.load(f)
+            rec = json.load(f)
     except (OSError, ValueError):
         return None
+    if isinstance(rec, dict):
+        rec = dict(rec)
+        rec["sources_now_sha16"] = source_hash()
+        rec["records_match_current_sources"] = rec.get("source_sha16") == rec["sources_now_sha16"]
+    return rec
 
 
 def parity_record():
@@ -620,12 +643,12 @@ def parity_record():
     the float64 one (same replayed decisions) is given next to it -- the down-scaler filters dominate both (float32
     interpolation coordinates, see the test's docstring) and are listed separately."""
     out = {}
-    for key, fn in (("trajectory_5_steps", "r05_parity_trajectory.json"),
-                    ("whole_model_replay", "r05_parity_whole_model_replay_relu.json"),
-                    ("whole_model_exact_math", "r05_parity_whole_model_off_silu.json"),
-                    ("full_size_C4_ex3_darcy_inv", "r05_parity_whole_model_full_ex3_darcy_inv.json"),
-                    ("full_size_C3_darcy211_fourier", "r05_parity_whole_model_full_ex2_darcy211_fourier.json"),
-                    ("full_size_C5_ns_rollout", "r05_parity_whole_model_full_ex4_ns.json")):
+    for key, fn in (("trajectory_5_steps", "r06_parity_trajectory.json"),
+                    ("whole_model_replay", "r06_parity_whole_model_replay_relu.json"),
+                    ("whole_model_exact_math", "r06_parity_whole_model_off_silu.json"),
+                    ("full_size_C4_ex3_darcy_inv", "r06_parity_whole_model_full_ex3_darcy_inv.json"),
+                    ("full_size_C3_darcy211_fourier", "r06_parity_whole_model_full_ex2_darcy211_fourier.json"),
+                    ("full_size_C5_ns_rollout", "r06_parity_whole_model_full_ex4_ns.json")):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 r = json.load(f)
@@ -651,7 +674,7 @@ def parity_record():
                             "downscaler_filters_hip_vs_oracle_f32": {k.split(".")[2]: v for k, v in
                                                                      r.get("hip_vs_oracle_f32", {}).items() if k.startswith("downscaler.")},
                             "precision": r.get("precision")}
-    out["source"] = ("profiles/r05_parity_*.json, written by tests/test_bench_kernels_gpu.py / test_fullsize_models_gpu.py on "
+    out["source"] = ("profiles/r06_parity_*.json, written by tests/test_bench_kernels_gpu.py / test_fullsize_models_gpu.py on "
                      "MI355X")
     out["recorded_at"] = _profiles_commit()
     return out if len(out) > 2 else None
