@@ -413,6 +413,8 @@ def roofline_leg(trainer, precision, workload="ex2_darcy141"):
             Ms, Ns = best[6][0], best[6][1]
             grid = -(-Ms // 128) * -(-Ns // 128) * 256 * best[6][3]
             rec = pj.get("_by_grid", {}).get(f"gt::{dom.replace('+splitk', '')}|{grid}")
+        if rec is None and kernel_symbol in pj and len([k for k in pj.get("_by_grid", {}) if k.startswith(kernel_symbol + "|")]) == 1:
+            rec = pj[kernel_symbol]                  # a symbol with ONE launch geometry in the profiled steps: its average is this launch
         if rec and "read_bytes" in rec and "write_bytes" in rec:
             traffic = int(rec["read_bytes"] + rec["write_bytes"])
             tsrc = (pj.get("_source", "") + f"; the {rec['calls_seen']} launches of this symbol" +
