@@ -1870,7 +1870,7 @@ bool x3_shape_ok(const gt_gemm_desc* d) {
     // whole 128 x 128 tiles dominate (the padding of a partial edge tile is bounded by the sizes below)
     if (d->ep_mode != GT_EP_NORMAL && d->ep_mode != GT_EP_HEADNORM) return false;
     // narrow implicit convolutions (N >= 32) ride on the 64-wide tile of the packed-B kernel
-    if (d->cv_c > 0 && !d->cv_wgrad && d->N >= 32 && d->N < 96 && d->M >= 16384 && d->K >= 16) return true;
+    if (d->cv_c > 0 && !d->cv_wgrad && d->N >= 32 && d->N < 96 && d->M >= 1024 && d->K >= 16) return true;
     return d->M >= 96 && d->N >= 96 && d->K >= 16;
 }
 
@@ -2012,7 +2012,9 @@ bool x3_packed_ok(const gt_gemm_desc* d, int planes, int split) {
     static const int on = [] { const char* e = getenv("GT_X3_PACKED"); return e ? atoi(e) : 1; }();
     if (!on || planes != 3 || split != 1 || d->batch0 * d->batch1 != 1 || d->K2 > 0 || d->a_colsum) return false;
     if (d->cv_c > 0 && d->cv_wgrad) return false;
-    if (d->M < 16384 || d->M < 8 * (int64_t)d->N) return false;       // below that the extra (pack) launch is not paid back
+    // below 16384 rows the extra (pack) launch is not paid back -- except for the implicit convolutions, whose K = 9 C makes
+    // the product long enough (round 5: the down-scaler chain runs at every batch, no library convolution below B = 3)
+    if (d->M < (d->cv_c > 0 ? 1024 : 16384) || d->M < 8 * (int64_t)d->N) return false;
     const bool a16 = (reinterpret_cast<uintptr_t>(d->A) & 15) == 0;
     if (d->cv_c > 0) return a16 && d->layout_a == 0 && (d->cv_c & 15) == 0 && (d->lda <= d->cv_c || (d->lda & 3) == 0);
     if (!a16 || (d->lda & 3)) return false;

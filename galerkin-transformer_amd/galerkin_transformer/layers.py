@@ -198,7 +198,7 @@ class Interp2dEncoder(nn.Module):
             h1, w1 = int(s0[0]), int(s0[1])
         else:
             return False
-        if x.shape[0] * h1 * w1 < 16384 or w1 < 3 or h1 < 3:      # the narrow implicit convolutions want token-row sizes
+        if x.shape[0] * h1 * w1 < 1024 or w1 < 3 or h1 < 3:       # (16 384 until round 5: C2 at B <= 2 fell back to the library)
             return False
         convs = [c.conv[0] for c in cs]
         widths = [c.out_channels for c in convs]

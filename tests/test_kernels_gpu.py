@@ -1297,15 +1297,16 @@ def test_conv3x3_narrow_tile_and_pixel_pitch(H, gpu_device, B, Hh, Ww, Cin, Cout
     assert torch.isnan(out[:, CP:]).all()                                                # nothing written past the segment
 
 
+@pytest.mark.parametrize("B", [3, 1])          # 18 252 / 6 084 pixel rows (round 5: the chain runs from 1 024 rows; a partial last tile)
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
-def test_scaler_conv_chain_matches_conv2d(H, gpu_device, p_drop):
+def test_scaler_conv_chain_matches_conv2d(H, gpu_device, p_drop, B):
     """ops.scaler_conv_chain (three implicit GEMMs into one padded buffer, ReLU + dropout on the epilogue, in-place
     gradient accumulation through the chain) == relu(drop(conv)) x 3 + cat with torch's conv2d in fp64 (p = 0); with
     dropout on, the kept entries equal the scaled reference, ~p of the positive entries are dropped, and the backward
     is the gradient of exactly that masked function."""
     from galerkin_transformer import ops
     dev = gpu_device
-    B, Hh, Ww, C0 = 3, 78, 78, 128
+    Hh, Ww, C0 = 78, 78, 128
     widths = (42, 42, 44)
     x0 = rnd(B, Hh, Ww, C0, dev=dev, seed=411).requires_grad_(True)
     ws = [rnd(co, ci, 3, 3, dev=dev, seed=412 + i, scale=0.1).requires_grad_(True)
@@ -1335,7 +1336,7 @@ def test_scaler_conv_chain_matches_conv2d(H, gpu_device, p_drop):
         if p_drop > 0:
             pos = pre > 1e-6
             frac = 1.0 - float((got[i][pos] > 0).double().mean())
-            assert abs(frac - p_drop) < 0.01, frac
+            assert abs(frac - p_drop) < (0.01 if B > 1 else 0.02), frac
     rcat = torch.cat(refs, -1)
     rcot = torch.cat([cot[..., i * CP:i * CP + widths[i]] for i in range(3)], -1).double()
     rcat.backward(rcot)
