@@ -1668,7 +1668,15 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
     // fifth of the split phase this kernel is bound by: tools/x3w_prof.py)
     const uint32_t voff = (uint32_t)((8 * kg * ldo + (isB ? n0 : m0) + 4 * r4) * (int64_t)sizeof(float));
     const char* rowbase = reinterpret_cast<const char*>(isB ? p.B : p.A);
+    // round 5: partial edge tiles (M, N multiples of 32, e.g. ex3's 192 / 384 / 576): a thread whose four rows lie beyond the
+    // operand's width stages zeros (its rows would be the NEXT token's values)
+    const bool live = (isB ? n0 : m0) + 4 * r4 < (isB ? p.N : p.M);
     auto fetch = [&](f32x4 (&v)[8], int k0) __attribute__((always_inline)) {
+        if (!live) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
         if (k0 + 32 <= kend) {
             const char* b = rowbase + (int64_t)k0 * ldo * (int64_t)sizeof(float);
 #pragma unroll
@@ -1847,12 +1855,13 @@ static int x3w_prefetch() {                          // GT_X3W_PF = 1: the singl
     return pf;
 }
 
-// the launches gemm_x3w_kernel takes: GT_PREC_F16X2, both operands x-contiguous and 16-byte aligned, whole 128 x 128 tiles,
+// the launches gemm_x3w_kernel takes: GT_PREC_F16X2, both operands x-contiguous and 16-byte aligned, M / N multiples of 32 (partial
+// edge tiles stage zeros: round 5, ex3's 192 / 384 / 576-wide weights),
 // a long token contraction cut into split-K slabs (raw epilogue), no batching / dropout / second product
 bool x3w_ok(const gt_gemm_desc* d, int split) {
     static const int on = [] { const char* e = getenv("GT_X3W"); return e ? atoi(e) : 1; }();
     return on && d->precision == GT_PREC_F16X2 && d->layout_a == 1 && d->layout_b == 1 && split > 1 && d->K >= 16384 &&
-           (d->M & 127) == 0 && (d->N & 127) == 0 && d->batch0 * d->batch1 == 1 && d->K2 == 0 && d->cv_c == 0 &&
+           (d->M & 31) == 0 && (d->N & 31) == 0 && d->M >= 96 && d->N >= 96 && d->batch0 * d->batch1 == 1 && d->K2 == 0 && d->cv_c == 0 &&
            !(d->a_drop.p > 0.f) && ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B)) & 15) == 0 &&
            (d->lda & 3) == 0 && (d->ldb & 3) == 0;
 }
