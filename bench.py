@@ -691,8 +691,9 @@ DTYPE_TEXT = {
     "bf16x3": "f32 (operands split exactly into 3 bf16 terms, 6 plane products on the bf16 MFMA pipe, f32 accumulate; "
               "fp32-class results: the 1e-5 parity gate is tested in this mode)",
     "f16x2": "f32 (operands split into 2 fp16 terms under a running per-row / per-tile power-of-two scale, 3 products on the "
-             "f16 MFMA pipe, f32 accumulate; fp32-class results: the 1e-5 parity suite passes in this mode; launches outside the "
-             "packed-B kernels run bf16x3)",
+             "f16 MFMA pipe, f32 accumulate; fp32-class results: the 1e-5 parity suite passes in this mode; packed-B token GEMMs, "
+             "convolutions, weight gradients, regression head and the Fourier attention run it, the batched per-sample products "
+             "(gemm_x3r: Q'P, dQ, dP^T) run bf16x3 = 3 bf16 terms, 6 products)",
     "bf16x2": "f32 storage / bf16x2 split MFMA (~2^-16 relative; throughput mode, own gate)",
     "bf16": "f32 storage / bf16-rounded MFMA operands, f32 accumulate (throughput mode, own 3e-3 gate)",
 }
