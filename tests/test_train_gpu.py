@@ -136,6 +136,8 @@ def test_weights_packed_once_per_step_equal_per_call_packs(gpu_device):
     import bench
     import galerkin_transformer as gt
     from galerkin_transformer import _hip
+    if gt.get_precision() != "f16x2":
+        pytest.skip("weights are packed ahead in the two-term fp16 arithmetic only")
     outs, packs = [], []
     try:
         for enabled in (False, True):
