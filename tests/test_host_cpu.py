@@ -283,7 +283,7 @@ def test_scaler_chain_eligibility_mirrors_the_segment_kernels_cpu():
     assert not ok(112, (43, 43)) and not ok(160, (43, 43))
     assert ok(128, (150, 150)) and not ok(128, (240, 240))       # 2 (no - 1)/(ni - 1) + 2 <= 6  <=>  no <= 155 from 78
     assert ok(128, 0.555) and not ok(128, 3.5)
-    assert not ok(128, (43, 43), B=2)                            # below the token-row size of the narrow implicit GEMMs
+    assert ok(128, (43, 43), B=2) and ok(128, (43, 43), B=1)     # round 5: the chain runs from 1 024 pixel rows (was 16 384: B <= 2 fell back)
 
 
 def _bench_record(tag="r06"):

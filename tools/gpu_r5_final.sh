@@ -13,9 +13,17 @@ PARTS="${@:-tests head work fourier}"
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 export TMPDIR=/tmp
+# the records of this pass belong to THESE sources: stamp the hash before any line quotes it (bench.py compares it with the sources it runs)
 python - <<'PY' > $O/source_hash.txt
-import bench
-print(bench.source_hash())
+import json, bench
+h = bench.source_hash()
+try:
+    rec = json.load(open("profiles/SOURCE.json"))
+except Exception:
+    rec = {}
+rec["source_sha16"] = h
+json.dump(rec, open("profiles/SOURCE.json", "w"), indent=1)
+print(h)
 PY
 for part in $PARTS; do
   case $part in
