@@ -851,3 +851,184 @@ def test_x3w_kernel_lane_map(K, with_acs):
     assert np.allclose(C, A.T @ B, atol=1e-9)
     if with_acs:
         assert np.allclose(asum, A.sum(0), atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ gt_fourier16.hip
+def _f16_geom(DP):
+    NM = DP // 32; TC = DP - 32 * NM; TG = (TC + 7) // 8; ND = (DP + 15) // 16
+    MAIN_G, TAIL_G = 128 * NM, 32 * TG
+    return dict(NM=NM, TG=TG, NS=NM + 1, ND=ND, MAIN_G=MAIN_G, TAIL_G=TAIL_G, RM_G=MAIN_G + TAIL_G, TR_G=64 * ND)
+
+
+def _f16_presplit(X, tile, DP):
+    """fourier16_presplit_kernel: the image of one 32-row tile as granules of 8 values, (exponent, norm bound).  The fp16
+    planes are kept as float64 holding fp16-representable values."""
+    g = _f16_geom(DP)
+    NM, TG, MAIN_G, TAIL_G, RM_G, TR_G = g["NM"], g["TG"], g["MAIN_G"], g["TAIL_G"], g["RM_G"], g["TR_G"]
+    s = np.zeros((32, DP))
+    rows = X[32 * tile:32 * tile + 32]
+    s[:len(rows)] = rows
+    amax = np.abs(s).max()
+    ex = 0 if amax == 0 else 13 - int(np.floor(np.log2(amax)))           # amax 2^ex in [2^13, 2^14)
+    sc = np.exp2(ex)
+    nrm = np.sqrt(((s * sc) ** 2).sum(1).max()) * 1.0001
+    ln = max(int(np.floor(np.log2(nrm))) + 1, -40) if nrm > 0 else -40   # nrm < 2^ln
+    img = np.zeros((2 * RM_G + 2 * TR_G, 8))
+    for gi in range(RM_G + TR_G):
+        v = np.zeros(8)
+        if gi < MAIN_G:
+            row, q = gi // (4 * NM), gi % (4 * NM)
+            v = s[row, 8 * q:8 * q + 8].copy()
+            d0, d1 = gi, MAIN_G + gi
+        elif gi < RM_G:
+            gt_ = gi - MAIN_G
+            row, q = gt_ // TG, gt_ % TG
+            c0 = 32 * NM + 8 * q
+            for e in range(8):
+                v[e] = s[row, c0 + e] if c0 + e < DP else 0.0
+            d0, d1 = 2 * MAIN_G + gt_, 2 * MAIN_G + TAIL_G + gt_
+        else:
+            gr = gi - RM_G
+            kq, m, dt = gr & 3, (gr >> 2) & 15, gr >> 6
+            col = 16 * dt + m
+            sg = -1.0 if (col & 1) else 1.0
+            for e in range(8):
+                row = 16 * (e >> 2) + 4 * kq + (e & 3)
+                v[e] = sg * s[row, col] if col < DP else 0.0
+            d0, d1 = 2 * RM_G + gr, 2 * RM_G + TR_G + gr
+        h0 = (v * sc).astype(np.float16).astype(np.float64)
+        h1 = (v * sc - h0).astype(np.float16).astype(np.float64)
+        img[d0], img[d1] = h0, h1
+    return img, ex, ln
+
+
+def _fmix_top(x):
+    """fmix32 without its last xorshift (bits 16..31 do not depend on it), uint32 arithmetic."""
+    x = np.asarray(x, dtype=np.uint64) & 0xffffffff
+    x ^= x >> 16; x = (x * 0x85ebca6b) & 0xffffffff
+    x ^= x >> 13; x = (x * 0xc2b2ae35) & 0xffffffff
+    return x
+
+
+def _block16_keep(zn4, nq4, q, k, key):
+    """gt_hip.h gt_dropout_block16: element (q, k) keeps iff bit 16 + 4 (q & 3) + (k & 3) of the hash of its 4 x 4 block."""
+    blk = ((zn4 + (q >> 2)) * nq4 + (k >> 2)) & 0xffffffff
+    x = _fmix_top((blk * 0x9e3779b1 + key) & 0xffffffff)
+    return (int(x) >> (16 + 4 * (q & 3) + (k & 3))) & 1
+
+
+@pytest.mark.parametrize("DP,n,mode", [(20, 75, "plain"), (36, 75, "plain"), (52, 40, "plain"), (36, 75, "block_key"),
+                                       (20, 44, "block_query")])
+def test_fourier16_lane_map(DP, n, mode):
+    """fourier16_kernel<DP, false, PLAIN / DROPB> (gt_fourier16.hip), every owner wave of one (batch, head): the images the
+    pre-split writes, the fragment offsets the kernel reads them at, the D-layout -> B-layout register hand-over between the
+    two products (contraction slot 8 kq + 4 mt + r = stream row 16 mt + 4 kq + r), the running exponent, the chain sign
+    (-1)^(dim + owner), and the per-block dropout bookkeeping (hw / hstep / bpos) against the definition in gt_hip.h.
+    O[o][d] = scale sum_s keep(s, o) T2[s][d] (T1[s] . F1[o]); two-term fp16 planes, fp32 accumulation."""
+    g = _f16_geom(DP)
+    NM, TG, NS, ND, MAIN_G, TAIL_G, RM_G, TR_G = (g[k] for k in ("NM", "TG", "NS", "ND", "MAIN_G", "TAIL_G", "RM_G", "TR_G"))
+    rng = np.random.default_rng(DP + n)
+    mag = np.exp2(rng.integers(-5, 6, size=(3, n, 1)))                    # rows of very different magnitude
+    F1, T1, T2 = (rng.standard_normal((n, DP)) * mag[i] for i in range(3))
+    ntile = (n + 31) // 32
+    imgs = {nm: [_f16_presplit(Xt, t, DP) for t in range(ntile)] for nm, Xt in (("F1", F1), ("T1", T1), ("T2", T2))}
+    j, kq = J, KQ
+    scale, key, zn4, nq4 = 1.0 / n, 0x1234abcd, 5 * ((n + 3) >> 2), (n + 3) >> 2
+    owner_is_key = mode == "block_key"
+    keep = np.ones((n, n))                                                # [query][key]
+    if mode != "plain":
+        for q in range(n):
+            for k in range(n):
+                keep[q, k] = _block16_keep(zn4, nq4, q, k, key)
+
+    def mma3(ah, al, bh, bl, acc):
+        for a, b in ((al, bh), (ah, bl), (ah, bh)):
+            acc = _mfma_16x16x32(a, b, acc).astype(np.float32).astype(np.float64)
+        return acc
+
+    O = np.full((n, DP), np.nan)
+    for ot in range(ntile):
+        o0 = 32 * ot
+        fimg, ef1, lf1 = imgs["F1"][ot]
+        f1h, f1l = {}, {}
+        for nt in range(2):
+            for s in range(NS):
+                ok = (kq < TG) if s == NM else np.ones(64, bool)
+                g0 = (16 * nt + j) * 4 * NM + 4 * s + kq if s < NM else 2 * MAIN_G + (16 * nt + j) * TG + kq
+                g1 = g0 + (MAIN_G if s < NM else TAIL_G)
+                f1h[nt, s] = np.where(ok[:, None], fimg[np.minimum(g0, len(fimg) - 1)], 0.0)
+                f1l[nt, s] = np.where(ok[:, None], fimg[np.minimum(g1, len(fimg) - 1)], 0.0)
+        hw = {}
+        for nt in range(2):
+            own4 = (o0 + 16 * nt + j) >> 2
+            blk = (zn4 + kq) * nq4 + own4 if owner_is_key else (zn4 + own4) * nq4 + kq
+            hw[nt] = (blk * 0x9e3779b1 + key) & 0xffffffff
+        hstep = (nq4 if owner_is_key else 1) * 0x9e3779b1
+        bpos = [16 + (4 * r + (j & 3) if owner_is_key else 4 * (j & 3) + r) for r in range(4)]
+        osign = np.where(j & 1, -1.0, 1.0)
+        acc1 = {(dt, nt): np.zeros((64, 4)) for dt in range(ND) for nt in range(2)}
+        EA = 1 << 20
+        for t in range(ntile):
+            (i1, e1, l1), (i2, e2, l2) = imgs["T1"][t], imgs["T2"][t]
+            cap = 15 - l1 - lf1 + e1 + ef1 + e2
+            if cap < EA:
+                if t > 0:
+                    for kk in acc1:
+                        acc1[kk] = acc1[kk] * np.exp2(cap - EA)
+                EA = cap
+            sigA = osign * np.exp2(EA - e1 - ef1 - e2)
+            km = np.ones((2, 8, 64))
+            if mode != "plain":
+                for nt in range(2):
+                    hk = hw[nt]
+                    for mt in range(2):
+                        xb = _fmix_top(hk)
+                        hk = (hk + 4 * hstep) & 0xffffffff
+                        for r in range(4):
+                            km[nt, 4 * mt + r] = (xb >> np.asarray(bpos[r], dtype=np.uint64)) & 1
+                    hw[nt] = hk
+            sa = {}
+            for mt in range(2):
+                for nt in range(2):
+                    sa[mt, nt] = np.zeros((64, 4))
+                for s in range(NS):
+                    if s < NM:
+                        a0, pl = (16 * mt + j) * 4 * NM + 4 * s + kq, MAIN_G
+                        ok = np.ones(64, bool)
+                    else:
+                        a0, pl = 2 * MAIN_G + (16 * mt + j) * TG + kq, TAIL_G
+                        ok = kq < TG
+                    ah = np.where(ok[:, None], i1[np.minimum(a0, len(i1) - 1)], 0.0)
+                    al = np.where(ok[:, None], i1[np.minimum(a0 + pl, len(i1) - 1)], 0.0)
+                    for nt in range(2):
+                        sa[mt, nt] = mma3(ah, al, f1h[nt, s], f1l[nt, s], sa[mt, nt])
+            ph, pl_ = {}, {}
+            for nt in range(2):
+                v = np.zeros((64, 8))
+                for mt in range(2):
+                    for r in range(4):
+                        v[:, 4 * mt + r] = sa[mt, nt][:, r] * sigA * km[nt, 4 * mt + r]
+                assert np.abs(v).max() < 65504.0                            # the Cauchy-Schwarz bound behind `cap`
+                ph[nt] = v.astype(np.float32).astype(np.float16).astype(np.float64)
+                pl_[nt] = (v.astype(np.float32) - ph[nt].astype(np.float32)).astype(np.float16).astype(np.float64)
+            for dt in range(ND):
+                a0 = 2 * RM_G + j * 4 + kq + 64 * dt
+                for nt in range(2):
+                    acc1[dt, nt] = mma3(i2[a0], i2[a0 + TR_G], ph[nt], pl_[nt], acc1[dt, nt])
+        fs = scale * (2.0 if mode != "plain" else 1.0)
+        for nt in range(2):
+            ow = o0 + 16 * nt + j
+            for dt in range(ND):
+                dim = 16 * dt + 4 * kq
+                for l in range(64):
+                    if ow[l] < n and dim[l] < DP:
+                        for r in range(4):
+                            sg = -fs if ((r + j[l]) & 1) else fs
+                            O[ow[l], dim[l] + r] = acc1[dt, nt][l, r] * sg * np.exp2(-EA)
+    Sc = T1 @ F1.T                                                          # [stream][owner]
+    # keep is [query][key]; the score matrix here is [stream][owner]: stream = query when the owner is the key
+    kso = keep if owner_is_key else keep.T
+    ref = scale * (2.0 if mode != "plain" else 1.0) * (Sc * kso).T @ T2
+    assert not np.isnan(O).any()
+    err = np.linalg.norm(O - ref) / np.linalg.norm(ref)
+    assert err < 2e-6, err
