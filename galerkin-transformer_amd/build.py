@@ -45,7 +45,7 @@ def build(emu=False, verbose=False, force=False, tag=None, defines=(), only=None
     if emu:
         flags.append("-DGT_EMULATE_MFMA=1")
     flags += ["-D" + d for d in defines]
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -53,11 +53,17 @@ def build(emu=False, verbose=False, force=False, tag=None, defines=(), only=None
             objs.append(os.path.join(CSRC, ".obj", src.replace(".hip", ".o")))
             continue
         if force or _stale(o, [s] + HEADERS):
-            cmd = [_hipcc()] + flags + ["-c", s, "-o", o]
+            jobs.append([_hipcc()] + flags + ["-c", s, "-o", o])
+        objs.append(o)
+    if jobs:        # one hipcc per source, a few at a time (the big translation units take minutes each)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-        objs.append(o)
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("GT_BUILD_JOBS", "6"))) as ex:
+            list(ex.map(run, jobs))
     lib = os.path.join(OUT_DIR, f"libgt_hip{tag}.so")
     if force or _stale(lib, objs):
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", lib]

@@ -511,7 +511,7 @@ static int x3_planes(const gt_gemm_desc* d) {
 static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     if (d->M <= 0 || d->N <= 0 || d->K < 0 || d->batch0 <= 0 || d->batch1 <= 0) return GT_EINVAL;
     if (d->precision < GT_PREC_F32 || d->precision > GT_PREC_F16X2) return GT_EINVAL;
-    if (d->act < GT_ACT_NONE || d->act > GT_ACT_SILU) return GT_EINVAL;      // GT_ACT_GELU: elementwise entry points only
+    if (d->act < GT_ACT_NONE || (d->act > GT_ACT_SILU && d->act != GT_ACT_DROP_SILU)) return GT_EINVAL;   // GT_ACT_GELU: elementwise entry points only
     const int64_t batch = (int64_t)d->batch0 * d->batch1;
     if (batch > 65535) return GT_EINVAL;
     pl->x3 = x3_planes(d);
@@ -706,7 +706,7 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
                 return GT_ENOTSUP;
         }
     }
-    if (d->C && !getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return tsmm_run(d, ws, ws_bytes, stream);
+    if (d->C && !getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return d->b_packed ? GT_EINVAL : tsmm_run(d, ws, ws_bytes, stream);
     if (d->rp < 0 || d->rp > 8) return GT_EINVAL;
     if ((d->a_drop.p > 0.f && !d->a_drop.seed) || (d->drop.p > 0.f && !d->drop.seed)) return GT_EINVAL;
     if (d->a_drop.p >= 1.f || d->drop.p >= 1.f || d->a_drop.p < 0.f || d->drop.p < 0.f) return GT_EINVAL;
@@ -819,6 +819,7 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
 
     dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split, (unsigned)batch);
     const int lay = d->layout_a * 2 + d->layout_b;
+    if (d->b_packed && !(pl.x3 && x3_packed_ok(d, pl.x3, pl.split))) return GT_EINVAL;   // not a packed-B launch: see gt_hip.h
     if (pl.x3) {
         if (x3_packed_ok(d, pl.x3, pl.split)) {
             int rcp = x3_pack_b(d, p, ws, ws_bytes, st);
@@ -944,6 +945,9 @@ extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* 
     if (!d) return GT_EINVAL;
     gt_gemm_desc a, b;
     if (width_split(d, &a, &b)) {
+        // a weight packed ahead describes ONE packed-B launch over the full width (gt_gemm_packed_b_bytes(d) > 0): the two
+        // column ranges would both read it with the wrong tile geometry
+        if (d->b_packed) return GT_EINVAL;
         int rc = gemm_one(&a, d->N, 0, ws, ws_bytes, stream);
         if (rc) return rc;
         return gemm_one(&b, d->N, a.N, ws, ws_bytes, stream);      // same stream: the scratch is free again

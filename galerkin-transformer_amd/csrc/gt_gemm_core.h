@@ -188,14 +188,32 @@ __device__ __forceinline__ void ep_row(const GemmP& p, float (&v)[NT], const flo
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] += ad[t];
     }
+    float dfac[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dfac[t] = 0.f;
+    if (p.act == GT_ACT_DROP_SILU) {
+        // dropout in FRONT of the activation (gt_hip.h): u = keepscale * v, result silu(u); `pre` takes the factor the
+        // backward multiplies the output gradient with, keepscale * silu'(u), in place of the pre-activation
+        const uint32_t di = (uint32_t)(((int64_t)z * p.M + m) * p.drop_ld + p.n_off + nb);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float ks = p.drop.thresh ? drop_mul(p.drop, dkey, di + t) : 1.f;
+            float a, da;
+            silu_both(v[t] * ks, a, da);
+            v[t] = a;
+            dfac[t] = ks * da;
+        }
+    }
     if (p.pre) {
         float* pp = p.pre + ((int64_t)z * p.M + m) * p.ldpre + nb;
+        const bool df = p.act == GT_ACT_DROP_SILU;
         if (vec4) {
-            *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1 % NT], v[2 % NT], v[3 % NT]};
+            *reinterpret_cast<f32x4*>(pp) = df ? f32x4{dfac[0], dfac[1 % NT], dfac[2 % NT], dfac[3 % NT]}
+                                               : f32x4{v[0], v[1 % NT], v[2 % NT], v[3 % NT]};
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                if (nb + t < p.N) pp[t] = v[t];
+                if (nb + t < p.N) pp[t] = df ? dfac[t] : v[t];
         }
     }
     if (p.act == GT_ACT_RELU) {
@@ -216,7 +234,7 @@ __device__ __forceinline__ void ep_row(const GemmP& p, float (&v)[NT], const flo
                                                  : a * p.aux_scale;
         }
     }
-    if (p.drop.thresh) {
+    if (p.drop.thresh && p.act != GT_ACT_DROP_SILU) {
         const uint32_t di = (uint32_t)(((int64_t)z * p.M + m) * p.drop_ld + p.n_off + nb);
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] *= drop_mul(p.drop, dkey, di + t);

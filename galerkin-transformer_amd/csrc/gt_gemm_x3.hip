@@ -259,7 +259,22 @@ __device__ __forceinline__ void x3_epilogue_fast(const GemmP& p, const f32x16 (&
         for (int k = 0; k < HB; ++k)
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[k][t] = p.alpha * v[k][t] + biasv[t];
-        if (p.pre) {
+        if (p.act == GT_ACT_DROP_SILU) {     // dropout in front of the SiLU; `pre` = keepscale * silu'(u) (gt_hip.h, ep_row)
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const uint32_t di = (uint32_t)(((int64_t)z * p.M + m0b + 4 * k) * p.drop_ld + p.n_off + nb);
+                f32x4 df;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float ks = p.drop.thresh ? drop_mul(p.drop, dkey, di + t) : 1.f;
+                    float a, da;
+                    silu_both(v[k][t] * ks, a, da);
+                    v[k][t] = a;
+                    df[t] = ks * da;
+                }
+                if (p.pre) *reinterpret_cast<f32x4*>(p.pre + ((int64_t)z * p.M + m0b + 4 * k) * p.ldpre + nb) = df;
+            }
+        } else if (p.pre) {
 #pragma unroll
             for (int k = 0; k < HB; ++k)
                 *reinterpret_cast<f32x4*>(p.pre + ((int64_t)z * p.M + m0b + 4 * k) * p.ldpre + nb) = v[k];
@@ -294,7 +309,7 @@ __device__ __forceinline__ void x3_epilogue_fast(const GemmP& p, const f32x16 (&
                     for (int t = 0; t < 4; ++t) v[k][t] *= a[k][t] * p.aux_scale;
             }
         }
-        if (p.drop.thresh) {
+        if (p.drop.thresh && p.act != GT_ACT_DROP_SILU) {
 #pragma unroll
             for (int k = 0; k < HB; ++k) {
                 const uint32_t di = (uint32_t)(((int64_t)z * p.M + m0b + 4 * k) * p.drop_ld + p.n_off + nb);

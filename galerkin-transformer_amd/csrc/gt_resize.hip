@@ -62,6 +62,9 @@ struct ResizeP {
     // backward with segments only: the forward input itself (padded layout, the output of a ReLU): dx is zeroed where it
     // is not positive, which is the first step of its producer's backward (ops.ScalerConvChainFn) done on the way out
     const float* in_gate;
+    // act == GT_ACT_SILU (channels-last kernels): fwd writes silu'(resized value) here, bwd reads it through `gate` as a factor
+    float* dact;
+    int gate_mul;               // bwd: in_gate is a factor (dx *= in_gate) instead of the ReLU test
 };
 
 // padded column of real channel c
@@ -506,7 +509,7 @@ __device__ __forceinline__ void load_patch_clamped(const float* __restrict__ xp,
 // the caller initialised them).  One pointer load per thread when unset.
 __device__ unsigned char* g_conv0_mask = nullptr;
 
-template <int CIN>
+template <int CIN, int ACT = GT_ACT_RELU>
 __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP p) {
     __shared__ float sw[CR_CH * CIN * 9];
     // channels-last output: the channel groups of a pixel strip are neighbouring blocks (they complete the strip's
@@ -559,11 +562,15 @@ __global__ __launch_bounds__(256) void conv_resize_fwd_kernel(const ConvResizeP 
 #pragma unroll                                                                                // stand-alone dropout
             for (int t = 0; t < 4; ++t) {
                 const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
-                cv[t] = fmaxf(cv[t] * m, 0.f);
-                if (dbg_mask && c < p.Cout) dbg_mask[cbase + toff[t]] = cv[t] > 0.f ? 1 : 0;
+                if (ACT == GT_ACT_SILU) cv[t] = silu_f(cv[t] * m);
+                else {
+                    cv[t] = fmaxf(cv[t] * m, 0.f);
+                    if (dbg_mask && c < p.Cout) dbg_mask[cbase + toff[t]] = cv[t] > 0.f ? 1 : 0;
+                }
             }
             // same association as the stand-alone resize: l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
-            r4[jj] = fmaxf(ay.l0 * (ax.l0 * cv[0] + ax.l1 * cv[1]) + ay.l1 * (ax.l0 * cv[2] + ax.l1 * cv[3]), 0.f);
+            const float rz = ay.l0 * (ax.l0 * cv[0] + ax.l1 * cv[1]) + ay.l1 * (ax.l0 * cv[2] + ax.l1 * cv[3]);
+            r4[jj] = ACT == GT_ACT_SILU ? silu_f(rz) : fmaxf(rz, 0.f);
             const unsigned d4 = (cv[0] > 0.f ? 1u : 0u) | (cv[1] > 0.f ? 2u : 0u) | (cv[2] > 0.f ? 4u : 0u) | (cv[3] > 0.f ? 8u : 0u);
             n16 |= (r4[jj] > 0.f ? d4 : 0u) << (4 * jj);
         }
@@ -596,9 +603,10 @@ static_assert(CRB_CG % 4 == 0 && CRB_CG >= 4, "the channels-last paths read a pi
 #ifndef GT_CRB_WAVES                               // resident waves per SIMD the one-channel instance is compiled for
 #define GT_CRB_WAVES 2
 #endif
-template <int CIN, bool BITS = false>
+template <int CIN, bool BITS = false, int ACT = GT_ACT_RELU>
 __global__ __launch_bounds__(256, (CIN == 1 ? GT_CRB_WAVES : 1)) void conv_resize_bwd_kernel(const ConvResizeP p) {
     static_assert(!BITS || CRB_CG == 8, "the recorded decisions are read as one 32-bit half word: eight channels per thread");
+    static_assert(!BITS || ACT == GT_ACT_RELU, "decision bits describe ReLUs");
     __shared__ float sw[BITS ? 1 : CRB_CG * CIN * 9];
     __shared__ float red[4][CRB_CG * CIN * 9];
     // channels-first: blockIdx = (pixel strip, channel group).  channels-last: a strip's channel groups read the same
@@ -691,7 +699,7 @@ __global__ __launch_bounds__(256, (CIN == 1 ? GT_CRB_WAVES : 1)) void conv_resiz
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.g + o8 + 4 * h);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) gl[4 * h + t] = g4[t];
-                if (!BITS) {
+                if (!BITS && ACT == GT_ACT_RELU) {
                     const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.y + o8 + 4 * h);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) yl[4 * h + t] = y4[t];
@@ -712,7 +720,8 @@ __global__ __launch_bounds__(256, (CIN == 1 ? GT_CRB_WAVES : 1)) void conv_resiz
 #pragma unroll
                 for (int t = 0; t < 4; ++t) coef[t] = (dec & (1u << (4 * j + t))) ? wt[t] * go : 0.f;
             } else {
-                if (p.y_nhwc) go = (yl[j] > 0.f) ? gl[j] : 0.f;
+                if (ACT == GT_ACT_SILU) go = p.y_nhwc ? gl[j] : p.g[((int64_t)b * p.Cout + c) * oplane + e];
+                else if (p.y_nhwc) go = (yl[j] > 0.f) ? gl[j] : 0.f;
                 else {
                     const int64_t o = ((int64_t)b * p.Cout + c) * oplane + e;
                     go = (p.y[o] > 0.f) ? p.g[o] : 0.f;
@@ -727,10 +736,25 @@ __global__ __launch_bounds__(256, (CIN == 1 ? GT_CRB_WAVES : 1)) void conv_resiz
                         for (int t = 0; t < 4; ++t) cv[t] = fmaf(wv, pt[ci][t][k], cv[t]);
                     }
                 const uint32_t cbase = ((uint32_t)b * (uint32_t)p.Cout + (uint32_t)c) * plane;
+                if (ACT == GT_ACT_SILU) {
+                    // both SiLUs re-evaluated: a_t = silu(m_t conv_t), r = bilinear(a), d out / d conv_t = silu'(r) w_t m_t silu'(m_t conv_t)
+                    float av[4], dav[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
-                    coef[t] = (cv[t] * m > 0.f) ? wt[t] * m * go : 0.f;
+                    for (int t = 0; t < 4; ++t) {
+                        const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
+                        silu_both(cv[t] * m, av[t], dav[t]);
+                        dav[t] *= m;
+                    }
+                    const float rz = ay.l0 * (ax.l0 * av[0] + ax.l1 * av[1]) + ay.l1 * (ax.l0 * av[2] + ax.l1 * av[3]);
+                    go *= dsilu_f(rz);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) coef[t] = wt[t] * dav[t] * go;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float m = p.drop.thresh ? drop_mul(p.drop, key, cbase + toff[t]) : p.drop.scale;
+                        coef[t] = (cv[t] * m > 0.f) ? wt[t] * m * go : 0.f;
+                    }
                 }
             }
 #pragma unroll
@@ -812,6 +836,15 @@ __global__ __launch_bounds__(256) void resize_nhwc_fwd_kernel(const ResizeP p) {
             if (p.act == GT_ACT_RELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+            } else if (p.act == GT_ACT_SILU) {          // + the derivative the backward multiplies g with
+                f32x4 d;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a, da;
+                    silu_both(o[j], a, da);
+                    o[j] = a; d[j] = da;
+                }
+                if (p.dact) *reinterpret_cast<f32x4*>(p.dact + addr<true>(b, c, oy, ox, p.C, p.Ho, p.Wo)) = d;
             }
             *reinterpret_cast<f32x4*>(p.y + addr<true>(b, c, oy, ox, p.C, p.Ho, p.Wo)) = o;
         }
@@ -858,8 +891,11 @@ __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
                                 gv = *reinterpret_cast<const f32x2*>(p.x + o + cr[2 * h]);
                                 if (p.gate) {
                                     const f32x2 y = *reinterpret_cast<const f32x2*>(p.gate + o + cr[2 * h]);
-                                    if (!(y[0] > 0.f)) gv[0] = 0.f;
-                                    if (!(y[1] > 0.f)) gv[1] = 0.f;
+                                    if (p.act == GT_ACT_SILU) { gv[0] *= y[0]; gv[1] *= y[1]; }      // y = silu'(resized)
+                                    else {
+                                        if (!(y[0] > 0.f)) gv[0] = 0.f;
+                                        if (!(y[1] > 0.f)) gv[1] = 0.f;
+                                    }
                                 }
                             }
                             g[2 * h] = gv[0]; g[2 * h + 1] = gv[1];
@@ -869,8 +905,11 @@ __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
                         g = *reinterpret_cast<const f32x4*>(p.x + o);
                         if (p.gate) {
                             const f32x4 y = *reinterpret_cast<const f32x4*>(p.gate + o);
+                            if (p.act == GT_ACT_SILU) g *= y;
+                            else {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) g[j] = 0.f;
+                                for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) g[j] = 0.f;
+                            }
                         }
                     }
                     racc += tx.w[jx] * g;
@@ -882,8 +921,11 @@ __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
     const int64_t od = addr<true>(b, c, iy, ix, CX, p.Hi, p.Wi);
     if (p.in_gate) {
         const f32x4 xin = *reinterpret_cast<const f32x4*>(p.in_gate + od);
+        if (p.gate_mul) acc *= xin;
+        else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (!(xin[j] > 0.f)) acc[j] = 0.f;
+            for (int j = 0; j < 4; ++j) if (!(xin[j] > 0.f)) acc[j] = 0.f;
+        }
     }
     *reinterpret_cast<f32x4*>(p.y + od) = acc;
 }
@@ -967,13 +1009,14 @@ static int check_seg(int C, int seg, int segp) {
 }
 
 extern "C" int gt_bilinear2d_seg_fwd(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
-                                     int32_t Wo, int32_t act, int32_t seg, int32_t segp, void* stream) {
+                                     int32_t Wo, int32_t act, int32_t seg, int32_t segp, float* dact, void* stream) {
     if (int rc = check_resize(x, y, B, C, Hi, Wi, Ho, Wo, 1, 1)) return rc;
     if (int rc = check_seg(C, seg, segp)) return rc;
-    if (act != GT_ACT_NONE && act != GT_ACT_RELU) return GT_ENOTSUP;
+    if (act != GT_ACT_NONE && act != GT_ACT_RELU && act != GT_ACT_SILU) return GT_ENOTSUP;
+    if (dact && (act != GT_ACT_SILU || (reinterpret_cast<uintptr_t>(dact) & 15))) return GT_EINVAL;
     if (ceil_div(Ho, RN_RPT) > 65535) return GT_EINVAL;
     ResizeP p{x, y, nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho), scale_of(Wi, Wo), act, ceil_div(Wo, RS_TX),
-              nullptr, 0, nullptr, 0, nullptr, 0, seg, segp, nullptr};
+              nullptr, 0, nullptr, 0, nullptr, 0, seg, segp, nullptr, dact, 0};
     dim3 ng((unsigned)ceil_div((int64_t)Wo * (C / 4), 256), (unsigned)ceil_div(Ho, RN_RPT), (unsigned)B);
     hipLaunchKernelGGL(resize_nhwc_fwd_kernel, ng, dim3(256), 0, (hipStream_t)stream, p);
     GT_LAUNCH_CHECK();
@@ -982,14 +1025,16 @@ extern "C" int gt_bilinear2d_seg_fwd(const float* x, float* y, int32_t B, int32_
 
 extern "C" int gt_bilinear2d_seg_bwd(const float* g, const float* y_saved, float* dx, int32_t B, int32_t C, int32_t Hi,
                                      int32_t Wi, int32_t Ho, int32_t Wo, int32_t act, int32_t seg, int32_t segp,
-                                     const float* x_gate, void* stream) {
+                                     const float* x_gate, int32_t gate_mul, void* stream) {
     if (int rc = check_resize(dx, g, B, C, Hi, Wi, Ho, Wo, 1, 1)) return rc;
     if (int rc = check_seg(C, seg, segp)) return rc;
-    if (act != GT_ACT_NONE && act != GT_ACT_RELU) return GT_ENOTSUP;
-    if (act == GT_ACT_RELU && !y_saved) return GT_EINVAL;
+    if (act != GT_ACT_NONE && act != GT_ACT_RELU && act != GT_ACT_SILU) return GT_ENOTSUP;
+    if (act != GT_ACT_NONE && !y_saved) return GT_EINVAL;          // ReLU: the activated output; SiLU: the forward's dact
+    if (y_saved && (reinterpret_cast<uintptr_t>(y_saved) & 15)) return GT_EALIGN;
     if (!taps_fit(Hi, Ho) || !taps_fit(Wi, Wo)) return GT_ENOTSUP;
-    ResizeP p{g, dx, act == GT_ACT_RELU ? y_saved : nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho),
-              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX), nullptr, 0, nullptr, 0, nullptr, 0, seg, segp, x_gate};
+    ResizeP p{g, dx, act != GT_ACT_NONE ? y_saved : nullptr, B, C, Hi, Wi, Ho, Wo, scale_of(Hi, Ho),
+              scale_of(Wi, Wo), act, ceil_div(Wi, RS_TX), nullptr, 0, nullptr, 0, nullptr, 0, seg, segp, x_gate, nullptr,
+              gate_mul != 0};
     if (x_gate && (reinterpret_cast<uintptr_t>(x_gate) & 15)) return GT_EALIGN;
     dim3 ng((unsigned)ceil_div((int64_t)Wi * (3 * segp / 4), 256), (unsigned)Hi, (unsigned)B);
     hipLaunchKernelGGL(resize_nhwc_bwd_kernel, ng, dim3(256), 0, (hipStream_t)stream, p);
@@ -1000,7 +1045,7 @@ extern "C" int gt_bilinear2d_seg_bwd(const float* g, const float* y_saved, float
 static int check_conv_resize(const void* x, const void* w, const void* y, int B, int Cin, int Cout, int H, int W,
                              int Ho, int Wo, const gt_dropout* drop, int act) {
     if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return GT_EINVAL;
-    if (Cin > CR_MAXCI || act != GT_ACT_RELU) return GT_ENOTSUP;
+    if (Cin > CR_MAXCI || (act != GT_ACT_RELU && act != GT_ACT_SILU)) return GT_ENOTSUP;
     if (B > 65535) return GT_EINVAL;
     if (drop && drop->p > 0.f && !drop->seed) return GT_EINVAL;
     if (drop && (drop->p < 0.f || drop->p >= 1.f)) return GT_EINVAL;
@@ -1012,13 +1057,18 @@ static int conv_resize_fwd(const float* x, const float* w, float* y, int32_t B, 
                            const gt_dropout* drop, int32_t act, int y_nhwc, void* bits, void* stream) {
     if (int rc = check_conv_resize(x, w, y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
     if (y_nhwc && ((Cout & 7) || (reinterpret_cast<uintptr_t>(y) & 15))) return GT_ENOTSUP;
-    if (bits && (!y_nhwc || (Cout & 15) || (reinterpret_cast<uintptr_t>(bits) & 7))) return GT_ENOTSUP;
+    if (bits && (!y_nhwc || (Cout & 15) || (reinterpret_cast<uintptr_t>(bits) & 7) || act != GT_ACT_RELU)) return GT_ENOTSUP;
     ConvResizeP p{x, w, y, nullptr, nullptr, B, Cin, Cout, H, W, Ho, Wo, scale_of(H, Ho), scale_of(W, Wo),
                   make_drop(drop), y_nhwc, 0, reinterpret_cast<unsigned long long*>(bits)};
     dim3 grid((unsigned)ceil_div((int64_t)Ho * Wo, 256), (unsigned)ceil_div(Cout, CR_CH), (unsigned)B);
     if (y_nhwc) std::swap(grid.x, grid.y);
     hipStream_t st = (hipStream_t)stream;
-    switch (Cin) {
+    if (act == GT_ACT_SILU) switch (Cin) {
+        case 1: hipLaunchKernelGGL((conv_resize_fwd_kernel<1, GT_ACT_SILU>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((conv_resize_fwd_kernel<2, GT_ACT_SILU>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((conv_resize_fwd_kernel<3, GT_ACT_SILU>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((conv_resize_fwd_kernel<4, GT_ACT_SILU>), grid, dim3(256), 0, st, p); break;
+    } else switch (Cin) {
         case 1: hipLaunchKernelGGL(conv_resize_fwd_kernel<1>, grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL(conv_resize_fwd_kernel<2>, grid, dim3(256), 0, st, p); break;
         case 3: hipLaunchKernelGGL(conv_resize_fwd_kernel<3>, grid, dim3(256), 0, st, p); break;
@@ -1058,10 +1108,12 @@ static int conv_resize_bwd(const float* g, const float* y, const float* x, const
                            int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                            const gt_dropout* drop, int32_t act, float* dw, void* ws, int64_t ws_bytes, int y_nhwc,
                            const void* bits, void* stream) {
-    if (bits && (!y_nhwc || (Cout & 15) || CRB_CG != 8 || (reinterpret_cast<uintptr_t>(bits) & 7))) return GT_ENOTSUP;
-    if (int rc = check_conv_resize(x, w, bits ? (const void*)g : (const void*)y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
+    if (bits && (!y_nhwc || (Cout & 15) || CRB_CG != 8 || (reinterpret_cast<uintptr_t>(bits) & 7) || act != GT_ACT_RELU))
+        return GT_ENOTSUP;
+    const bool no_y = bits || act == GT_ACT_SILU;    // the SiLU backward re-evaluates both activations: y is not read
+    if (int rc = check_conv_resize(x, w, no_y ? (const void*)g : (const void*)y, B, Cin, Cout, H, W, Ho, Wo, drop, act)) return rc;
     if (!g || !dw) return GT_EINVAL;
-    if (bits && !y) y = g;                           // not read (alignment checks below see a valid pointer)
+    if (no_y && !y) y = g;                           // not read (alignment checks below see a valid pointer)
     // channels-last: a block walks whole channel groups of CRB_CG (a build-time constant) as aligned float4s
     if (y_nhwc && ((Cout & 7) || (Cout % CRB_CG) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(g)) & 15)))
         return GT_ENOTSUP;
@@ -1084,6 +1136,11 @@ static int conv_resize_bwd(const float* g, const float* y, const float* x, const
             case 3: hipLaunchKernelGGL((conv_resize_bwd_kernel<3, true>), grid, dim3(256), 0, st, p); break;
             default: hipLaunchKernelGGL((conv_resize_bwd_kernel<4, true>), grid, dim3(256), 0, st, p); break;
         }
+    } else if (act == GT_ACT_SILU) switch (Cin) {
+        case 1: hipLaunchKernelGGL((conv_resize_bwd_kernel<1, false, GT_ACT_SILU>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((conv_resize_bwd_kernel<2, false, GT_ACT_SILU>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((conv_resize_bwd_kernel<3, false, GT_ACT_SILU>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((conv_resize_bwd_kernel<4, false, GT_ACT_SILU>), grid, dim3(256), 0, st, p); break;
     } else switch (Cin) {
         case 1: hipLaunchKernelGGL(conv_resize_bwd_kernel<1>, grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL(conv_resize_bwd_kernel<2>, grid, dim3(256), 0, st, p); break;

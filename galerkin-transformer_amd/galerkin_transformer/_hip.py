@@ -15,8 +15,9 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 19          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 20          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
+ACT_DROP_SILU = 4          # gt_gemm only: dropout in front of the SiLU, `pre` = keepscale * silu' (gt_hip.h)
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3, PREC_BF16X2, PREC_BF16 = 0, 1, 2, 3
@@ -156,8 +157,8 @@ _PROTOS = {
     "gt_conv3x3_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 5 +
                               [C.c_float, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "gt_conv3x3_wgrad_nhwc_ws_bytes": (C.c_int64, [C.c_int32] * 5),
-    "gt_bilinear2d_seg_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p]),
-    "gt_bilinear2d_seg_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p, C.c_void_p]),
+    "gt_bilinear2d_seg_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p, C.c_void_p]),
+    "gt_bilinear2d_seg_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p, C.c_int32, C.c_void_p]),
     "gt_bilinear2d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
     "gt_grad_sqnorm_ws_bytes": (C.c_int64, []),
     "gt_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -506,7 +507,10 @@ class _WeightPacks:
         a torch.cat of parameters, a padded copy -- never qualifies and is forgotten)."""
         if not self.enabled or self.round == 0 or d.precision != PREC_F16X2:     # round 0: nobody brackets steps with refresh()
             return
-        key = (B.data_ptr(), d.layout_b, d.ldb, d.N, d.K, B.device.index)
+        # M is part of the key: whether gt_gemm(d) is ONE packed-B launch (and so whether b_packed may be set at all) depends
+        # on it -- the packed kernels want M >= 16384 and M >= 8 N, and a wide product is cut in two launches once its
+        # aligned part fills the chip (gt_gemm_packed_b_bytes is asked per (weight, M); ADVICE r5)
+        key = (B.data_ptr(), d.layout_b, d.ldb, d.N, d.K, d.M, B.device.index)
         ent = self.entries.get(key)
         if ent is None:
             need = int(lib().gt_gemm_packed_b_bytes(C.byref(d)))
@@ -898,7 +902,7 @@ def bilinear2d_bwd(g: torch.Tensor, y_saved: Optional[torch.Tensor], in_size, in
 
 
 def conv3x3_resize_fwd(x: torch.Tensor, w: torch.Tensor, size, drop: Optional[GtDropout], out_nhwc: bool = False,
-                       want_bits: bool = False):
+                       want_bits: bool = False, act: int = ACT_RELU):
     """relu(resize(relu(dropout(conv3x3(x, w, padding=1))))) -- x [B,Cin,H,W], w [Cout,Cin,3,3] -> [B,Cout,Ho,Wo], or
     channels-last [B,Ho,Wo,Cout] with ``out_nhwc``.  want_bits (channels-last, Cout % 16 == 0): also returns the byte buffer
     of the forward's decisions (gt_hip.h: relu_bits) for conv3x3_resize_bwd -> (y, bits); bits is None when not recorded."""
@@ -908,18 +912,18 @@ def conv3x3_resize_fwd(x: torch.Tensor, w: torch.Tensor, size, drop: Optional[Gt
     y = torch.empty((B, Ho, Wo, Cout) if out_nhwc else (B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
     bits = None
-    if want_bits and out_nhwc:
+    if want_bits and out_nhwc and act == ACT_RELU:           # (the SiLU form re-evaluates in its backward: nothing to record)
         nb = lib().gt_conv3x3_resize_bits_bytes(B, Cout, Ho, Wo)
         if nb > 0:
             bits = torch.empty(nb, dtype=torch.uint8, device=x.device)
     if out_nhwc:
         call = lambda: lib().gt_conv3x3_resize_fwd_nhwc(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, Cout, Hh, Ww, Ho,
-                                                        Wo, dp, ACT_RELU, ptr(bits), stream_ptr())
+                                                        Wo, dp, act, ptr(bits), stream_ptr())
     else:
         call = lambda: lib().gt_conv3x3_resize_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cin, Cout, Hh, Ww, Ho, Wo,
-                                                   dp, ACT_RELU, stream_ptr())
+                                                   dp, act, stream_ptr())
     check(_timed("gt_conv3x3_resize_fwd", 2.0 * 36 * Cin * y.numel(), 4.0 * (x.numel() + y.numel()) + (bits.numel() if bits is not None else 0),
-                 call, shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_fwd")
+                 call, shape=(B, Cin, Cout, Hh, Ho, act)), "gt_conv3x3_resize_fwd")
     return (y, bits) if want_bits else y
 
 
@@ -951,53 +955,61 @@ def debug_conv0_mask(mask: Optional[torch.Tensor]):
     check(lib().gt_debug_conv0_mask(ptr(mask), stream_ptr()), "gt_debug_conv0_mask")
 
 
-def conv3x3_resize_bwd(g: torch.Tensor, y: torch.Tensor, x: torch.Tensor, w: torch.Tensor,
-                       drop: Optional[GtDropout], out_nhwc: bool = False, bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+def conv3x3_resize_bwd(g: torch.Tensor, y: Optional[torch.Tensor], x: torch.Tensor, w: torch.Tensor,
+                       drop: Optional[GtDropout], out_nhwc: bool = False, bits: Optional[torch.Tensor] = None,
+                       act: int = ACT_RELU) -> torch.Tensor:
     """out_nhwc: g and y are channels-last [B,Ho,Wo,Cout] (what conv3x3_resize_fwd(out_nhwc=True) returned).  bits: the
-    decision buffer the forward recorded (want_bits): the backward then re-evaluates nothing and does not read y."""
+    decision buffer the forward recorded (want_bits): the backward then re-evaluates nothing and does not read y.
+    act = ACT_SILU: both activations are re-evaluated from x, y is not read (may be None)."""
     need_f32_cuda(g, y, x, w)
     B, Cin, Hh, Ww = x.shape
     Cout = w.shape[0]
-    Ho, Wo = (y.shape[1], y.shape[2]) if out_nhwc else (y.shape[2], y.shape[3])
+    Ho, Wo = (g.shape[1], g.shape[2]) if out_nhwc else (g.shape[2], g.shape[3])
     dw = torch.empty_like(w)
     ws = workspace(x.device, lib().gt_conv3x3_resize_bwd_ws_bytes(B, Cin, Cout, Hh, Ww))
     dp = C.byref(drop) if (drop is not None and drop.p > 0) else None
     if out_nhwc:
-        call = lambda: lib().gt_conv3x3_resize_bwd_nhwc(g.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), B, Cin, Cout,
-                                                        Hh, Ww, Ho, Wo, dp, ACT_RELU, ptr(bits), dw.data_ptr(),
+        call = lambda: lib().gt_conv3x3_resize_bwd_nhwc(g.data_ptr(), ptr(y), x.data_ptr(), w.data_ptr(), B, Cin, Cout,
+                                                        Hh, Ww, Ho, Wo, dp, act, ptr(bits), dw.data_ptr(),
                                                         ws.data_ptr(), ws.numel(), stream_ptr())
     else:
-        call = lambda: lib().gt_conv3x3_resize_bwd(g.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), B, Cin, Cout, Hh,
-                                                   Ww, Ho, Wo, dp, ACT_RELU, dw.data_ptr(), ws.data_ptr(), ws.numel(),
+        call = lambda: lib().gt_conv3x3_resize_bwd(g.data_ptr(), ptr(y), x.data_ptr(), w.data_ptr(), B, Cin, Cout, Hh,
+                                                   Ww, Ho, Wo, dp, act, dw.data_ptr(), ws.data_ptr(), ws.numel(),
                                                    stream_ptr())
-    nbytes = 4.0 * (x.numel() + y.numel()) + bits.numel() if bits is not None else 4.0 * (x.numel() + 2 * y.numel())
-    check(_timed("gt_conv3x3_resize_bwd", 0, nbytes, call, shape=(B, Cin, Cout, Hh, Ho)), "gt_conv3x3_resize_bwd")
+    reads_y = bits is None and act == ACT_RELU
+    nbytes = 4.0 * (x.numel() + g.numel() * (2 if reads_y else 1)) + (bits.numel() if bits is not None else 0)
+    check(_timed("gt_conv3x3_resize_bwd", 0, nbytes, call, shape=(B, Cin, Cout, Hh, Ho, act)), "gt_conv3x3_resize_bwd")
     return dw
 
 
-def bilinear2d_seg_fwd(x: torch.Tensor, Cc: int, size, seg: int, segp: int, act: int = ACT_NONE) -> torch.Tensor:
-    """x [B,Hi,Wi,3*segp] (the padded three-segment buffer of ops.scaler_conv_chain) -> dense [B,Ho,Wo,Cc]."""
+def bilinear2d_seg_fwd(x: torch.Tensor, Cc: int, size, seg: int, segp: int, act: int = ACT_NONE, want_dact: bool = False):
+    """x [B,Hi,Wi,3*segp] (the padded three-segment buffer of ops.scaler_conv_chain) -> dense [B,Ho,Wo,Cc].
+    act = ACT_SILU with want_dact: returns (y, dact), dact = silu'(resized value) -- what bilinear2d_seg_bwd takes as y_saved."""
     need_f32_cuda(x)
     B, Hi, Wi, cp3 = x.shape
     assert cp3 == 3 * segp
     Ho, Wo = int(size[0]), int(size[1])
     y = torch.empty(B, Ho, Wo, Cc, dtype=torch.float32, device=x.device)
-    check(_timed("gt_bilinear2d_seg_fwd", 0, 4.0 * B * Cc * (Hi * Wi + Ho * Wo),
+    dact = torch.empty_like(y) if (want_dact and act == ACT_SILU) else None
+    check(_timed("gt_bilinear2d_seg_fwd", 0, 4.0 * B * Cc * (Hi * Wi + Ho * Wo * (2 if dact is not None else 1)),
                  lambda: lib().gt_bilinear2d_seg_fwd(x.data_ptr(), y.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, act, seg, segp,
-                                                     stream_ptr()), shape=(B, Cc, Hi, Ho)), "gt_bilinear2d_seg_fwd")
-    return y
+                                                     ptr(dact), stream_ptr()), shape=(B, Cc, Hi, Ho, act)),
+          "gt_bilinear2d_seg_fwd")
+    return (y, dact) if want_dact else y
 
 
 def bilinear2d_seg_bwd(g: torch.Tensor, y_saved: Optional[torch.Tensor], in_size, seg: int, segp: int,
-                       act: int = ACT_NONE, x_gate: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x_gate: the forward input (padded layout) when it came out of a ReLU -- dx is zeroed where it is not positive."""
+                       act: int = ACT_NONE, x_gate: Optional[torch.Tensor] = None, gate_mul: bool = False) -> torch.Tensor:
+    """x_gate: the forward input (padded layout) when it came out of a ReLU -- dx is zeroed where it is not positive; with
+    gate_mul a buffer of factors in the same layout (dx *= x_gate).  act = ACT_SILU: y_saved is the forward's dact."""
     need_f32_cuda(g, y_saved, x_gate)
     B, Ho, Wo, Cc = g.shape
     Hi, Wi = int(in_size[0]), int(in_size[1])
     dx = torch.empty(B, Hi, Wi, 3 * segp, dtype=torch.float32, device=g.device)
     check(_timed("gt_bilinear2d_seg_bwd", 0, 4.0 * B * Cc * (Hi * Wi + 2 * Ho * Wo),
                  lambda: lib().gt_bilinear2d_seg_bwd(g.data_ptr(), ptr(y_saved), dx.data_ptr(), B, Cc, Hi, Wi, Ho, Wo,
-                                                     act, seg, segp, ptr(x_gate), stream_ptr()), shape=(B, Cc, Hi, Ho)),
+                                                     act, seg, segp, ptr(x_gate), int(bool(gate_mul)), stream_ptr()),
+                 shape=(B, Cc, Hi, Ho, act)),
           "gt_bilinear2d_seg_bwd")
     return dx
 

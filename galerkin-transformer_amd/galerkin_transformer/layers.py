@@ -171,24 +171,33 @@ class Interp2dEncoder(nn.Module):
         self.add_res = residual
         self.debug = debug
 
+    def _fused_act(self, blocks):
+        """'relu' / 'silu' when the encoder's own activation and every given block's are that one type, else None
+        (Interp2dEncoder builds them all from one activation_type, layers.py:446-482)."""
+        for name, cls in (("relu", nn.ReLU), ("silu", nn.SiLU)):
+            if isinstance(self.activation, cls) and all(isinstance(c.activation, cls) for c in blocks):
+                return name
+        return None
+
     def _conv0_fusable(self, x) -> bool:
         """conv0 is the plain 3x3 / padding-1 / bias-free block on a <= 4-channel input that needs no
-        gradient, with ReLU on both sides of the resize: the case gt_conv3x3_resize_* implements."""
+        gradient, with ReLU (or SiLU, round 6) on both sides of the resize: the case gt_conv3x3_resize_* implements."""
         c = self.conv0
         cv = c.conv[0]
         size = self.interp_size[0]
         size_ok = isinstance(size, float) or (isinstance(size, (tuple, list)) and not isinstance(size[0], float))
-        return (size_ok and isinstance(self.activation, nn.ReLU) and isinstance(c.activation, nn.ReLU)
+        return (size_ok and self._fused_act((c,)) is not None
                 and not c.add_res and not c.basic_block and cv.kernel_size == (3, 3) and cv.padding == (1, 1)
                 and cv.stride == (1, 1) and cv.dilation == (1, 1) and cv.groups == 1 and cv.bias is None
                 and cv.in_channels <= 4 and x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad))
 
     def _chain_ok(self, x, out_nhwc) -> bool:
-        """conv1 / conv2 / conv3 as ops.scaler_conv_chain: channels-last output wanted, plain ReLU blocks without
+        """conv1 / conv2 / conv3 as ops.scaler_conv_chain: channels-last output wanted, plain ReLU (or SiLU) blocks without
         residual, equal dropout, widths [c, c, <= padded c] that the segment layout of the last resize describes."""
         cs = (self.conv1, self.conv2, self.conv3)
-        if not (out_nhwc and x.is_cuda and not self.add_res and isinstance(self.activation, nn.ReLU)
-                and all(c.plain() and isinstance(c.activation, nn.ReLU) for c in cs)
+        act = self._fused_act(cs)
+        if not (out_nhwc and x.is_cuda and not self.add_res and act is not None
+                and all(c.plain() for c in cs)
                 and len({c.conv[1].p for c in cs}) == 1):
             return False
         s0 = self.interp_size[0]
@@ -216,16 +225,16 @@ class Interp2dEncoder(nn.Module):
         def taps_fit(ni, no):
             return no <= 6 if ni <= 1 else 2.0 * (no - 1) / (ni - 1) + 2.0 <= 6.0
         return (widths[0] == widths[1] and widths[0] % 2 == 0 and 0 < widths[2] <= cp and sum(widths) % 4 == 0
-                and h2 > 0 and w2 > 0 and taps_fit(h1, h2) and taps_fit(w1, w2) and ops.scaler_chain_ok(convs, "relu"))
+                and h2 > 0 and w2 > 0 and taps_fit(h1, h2) and taps_fit(w1, w2) and ops.scaler_chain_ok(convs, act))
 
     def forward(self, x, out_nhwc=False):
         """x (B, C, H, W).  ``out_nhwc`` returns (B, H', W', C') with the layout change fused into the
         last resize (what DownScaler feeds the encoder)."""
         chain = self._chain_ok(x, out_nhwc)
         if self._conv0_fusable(x):
-            # conv0 -> dropout -> relu -> resize -> relu in one pass; the out_dim-channel fine map never exists
+            # conv0 -> dropout -> act -> resize -> act in one pass; the out_dim-channel fine map never exists
             x = ops.conv3x3_resize(x, self.conv0.conv[0].weight, self.interp_size[0], self.conv0.conv[1].p,
-                                   self.training, out_nhwc=chain)
+                                   self.training, out_nhwc=chain, act=self._fused_act((self.conv0,)))
         else:
             x = _resize(self.conv0(x), self.interp_size[0], self.activation, out_nhwc=chain)
         if chain:
@@ -234,8 +243,13 @@ class Interp2dEncoder(nn.Module):
             cs = (self.conv1, self.conv2, self.conv3)
             seg = cs[0].conv[0].out_channels
             n_out = sum(c.conv[0].out_channels for c in cs)
+            act = self._fused_act(cs)
             buf = ops.scaler_conv_chain(x, *(c.conv[0].weight for c in cs), p_drop=cs[0].conv[1].p, training=self.training,
-                                        grad_masked=True)
+                                        grad_masked=True, act=act)
+            if act == "silu":       # + the factor (dropout scale x silu') the last resize hands the gradient back through
+                buf, fac = buf
+                return ops.bilinear_resize_seg(buf, n_out, self.interp_size[1], seg, buf.shape[-1] // 3, act="silu",
+                                               in_factor=fac)
             return ops.bilinear_resize_seg(buf, n_out, self.interp_size[1], seg, buf.shape[-1] // 3, act="relu",
                                            relu_input=True)
         x1 = self.conv1(x)

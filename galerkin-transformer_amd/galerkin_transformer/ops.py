@@ -158,40 +158,44 @@ _crb_bits = [os.environ.get("GT_CRB_BITS", "1") != "0"]
 
 
 class Conv3x3ResizeFn(Function):
-    """relu(resize(relu(dropout(conv3x3(x))))) in one pass -- the head of Interp2dEncoder (layers.py:483-495)
-    when the input carries few channels and needs no gradient.  See gt_conv3x3_resize_fwd."""
+    """act(resize(act(dropout(conv3x3(x))))) in one pass, act = ReLU or SiLU -- the head of Interp2dEncoder
+    (layers.py:483-495) when the input carries few channels and needs no gradient.  See gt_conv3x3_resize_fwd."""
 
     @staticmethod
-    def forward(ctx, x, weight, size, p_drop: float, out_nhwc: bool = False):
+    def forward(ctx, x, weight, size, p_drop: float, out_nhwc: bool = False, act: int = H.ACT_RELU):
         xc, wc = _c(x), _c(weight)
         salt = _next_salt(1)                     # the salt the stand-alone dropout would have drawn
         drop = H.dropout_desc(p_drop, salt, x.device) if p_drop > 0 else None
-        # channels-last: the forward records its four ReLU / dropout decisions per (output pixel, channel) (4 bits each,
-        # 1/8 of y), and the backward takes them from there instead of re-evaluating the convolution (GT_CRB_BITS=0: off)
-        want = bool(out_nhwc and _crb_bits[0] and ctx.needs_input_grad[1])     # nothing to record for an inference pass
-        r = H.conv3x3_resize_fwd(xc, wc, size, drop, out_nhwc, want_bits=want)
+        # channels-last ReLU: the forward records its four ReLU / dropout decisions per (output pixel, channel) (4 bits each,
+        # 1/8 of y), and the backward takes them from there instead of re-evaluating the convolution (GT_CRB_BITS=0: off).
+        # SiLU: the backward re-evaluates the convolution and both activations from x; nothing but x and w is kept.
+        want = bool(out_nhwc and _crb_bits[0] and ctx.needs_input_grad[1] and act == H.ACT_RELU)   # (nothing to record for an inference pass)
+        r = H.conv3x3_resize_fwd(xc, wc, size, drop, out_nhwc, want_bits=want, act=act)
         y, bits = r if want else (r, None)
-        ctx.save_for_backward(xc, wc, y, bits)
-        ctx.cfg = (p_drop, salt, out_nhwc)
+        ctx.save_for_backward(xc, wc, y if act == H.ACT_RELU else None, bits)
+        ctx.cfg = (p_drop, salt, out_nhwc, act)
         return y
 
     @staticmethod
     def backward(ctx, g):
         xc, wc, y, bits = ctx.saved_tensors
-        p_drop, salt, out_nhwc = ctx.cfg
+        p_drop, salt, out_nhwc, act = ctx.cfg
         if ctx.needs_input_grad[0]:
             raise RuntimeError("conv3x3_resize: the fused path has no input gradient")
         drop = H.dropout_desc(p_drop, salt, g.device) if p_drop > 0 else None
-        return None, H.conv3x3_resize_bwd(_c(g), y, xc, wc, drop, out_nhwc, bits=bits), None, None, None
+        return None, H.conv3x3_resize_bwd(_c(g), y, xc, wc, drop, out_nhwc, bits=bits, act=act), None, None, None, None
 
 
-def conv3x3_resize(x, weight, size, p_drop: float = 0.0, training: bool = True, out_nhwc: bool = False):
-    """out_nhwc: return (B, Ho, Wo, Cout) channels-last (same values, same dropout mask)."""
+def conv3x3_resize(x, weight, size, p_drop: float = 0.0, training: bool = True, out_nhwc: bool = False, act: str = "relu"):
+    """out_nhwc: return (B, Ho, Wo, Cout) channels-last (same values, same dropout mask).  act: 'relu' or 'silu' (both
+    activations of the block: Interp2dEncoder builds them from one activation_type)."""
     hi, wi = x.shape[2], x.shape[3]
     if isinstance(size, float):
         size = (int(math.floor(hi * size)), int(math.floor(wi * size)))
+    if act not in ("relu", "silu"):
+        raise NotImplementedError(f"conv3x3_resize: activation {act!r}")
     return Conv3x3ResizeFn.apply(x, weight, (int(size[0]), int(size[1])), float(p_drop) if training else 0.0,
-                                 bool(out_nhwc))
+                                 bool(out_nhwc), H.ACT_CODE[act])
 
 
 class ResizeSegFn(Function):
@@ -199,28 +203,39 @@ class ResizeSegFn(Function):
     scaler_conv_chain: (B, Hi, Wi, 3 segp) -> dense channels-last (B, Ho, Wo, C) (layers.py:508-512)."""
 
     @staticmethod
-    def forward(ctx, x, Cc: int, size, seg: int, segp: int, act: int, relu_input: bool):
+    def forward(ctx, x, Cc: int, size, seg: int, segp: int, act: int, relu_input: bool, in_factor=None):
         xc = _c(x)
-        y = H.bilinear2d_seg_fwd(xc, Cc, size, seg, segp, act)
+        dact = None
+        if act == H.ACT_SILU:                    # + silu'(resized value), the factor of the backward
+            y, dact = H.bilinear2d_seg_fwd(xc, Cc, size, seg, segp, act, want_dact=True)
+        else:
+            y = H.bilinear2d_seg_fwd(xc, Cc, size, seg, segp, act)
         ctx.cfg = ((xc.shape[1], xc.shape[2]), seg, segp, act, relu_input)
-        ctx.save_for_backward(y if act == H.ACT_RELU else None, xc if relu_input else None)
+        ctx.save_for_backward(y if act == H.ACT_RELU else dact, xc if relu_input else None, in_factor)
         return y
 
     @staticmethod
     def backward(ctx, g):
         in_size, seg, segp, act, relu_input = ctx.cfg
-        y, xin = ctx.saved_tensors
-        return H.bilinear2d_seg_bwd(_c(g), y, in_size, seg, segp, act, x_gate=xin), None, None, None, None, None, None
+        y, xin, fac = ctx.saved_tensors
+        dx = H.bilinear2d_seg_bwd(_c(g), y, in_size, seg, segp, act, x_gate=fac if fac is not None else xin,
+                                  gate_mul=fac is not None)
+        return dx, None, None, None, None, None, None, None
 
 
-def bilinear_resize_seg(x, n_channels: int, size, seg: int, segp: int, act: str = None, relu_input: bool = False):
+def bilinear_resize_seg(x, n_channels: int, size, seg: int, segp: int, act: str = None, relu_input: bool = False,
+                        in_factor=None):
     """relu_input: x is the output of a ReLU (scaler_conv_chain's buffer) -- the gradient returned for x is already zeroed
-    where x <= 0, which is what its producer's backward would do first (ScalerConvChainFn(grad_masked=True) skips it)."""
+    where x <= 0, which is what its producer's backward would do first (ScalerConvChainFn(grad_masked=True) skips it).
+    in_factor: the same for any other activation -- a buffer shaped like x (scaler_conv_chain's second output: dropout
+    scale x activation derivative) that the returned gradient is multiplied with."""
     hi, wi = x.shape[1], x.shape[2]
     if isinstance(size, float):
         size = (int(math.floor(hi * size)), int(math.floor(wi * size)))
+    if relu_input and in_factor is not None:
+        raise ValueError("bilinear_resize_seg: relu_input and in_factor are alternatives")
     return ResizeSegFn.apply(x, int(n_channels), (int(size[0]), int(size[1])), int(seg), int(segp), H.ACT_CODE[act],
-                             bool(relu_input))
+                             bool(relu_input), in_factor)
 
 
 class UpsampleFcFn(Function):
@@ -496,8 +511,9 @@ def scaler_chain_ok(convs, act_name: str) -> bool:
     """True when the three narrow 3x3 convolutions of Interp2dEncoder (layers.py:431-512: conv1, conv2, conv3, each
     conv -> dropout -> ReLU, outputs concatenated) can run as ``scaler_conv_chain``: plain 3x3 / stride 1 / zero padding 1 /
     bias-free, chained channel counts, the first input a multiple of 16 channels, ReLU (it commutes with the dropout
-    scale, so both ride on the product's epilogue), the split-operand arithmetic."""
-    if not (_scaler_chain[0] and act_name == "relu" and H.get_precision() in H.SPLIT_EXACT and len(convs) == 3):
+    scale, so both ride on the product's epilogue) or SiLU (round 6: the epilogue applies the dropout in front of it,
+    GT_ACT_DROP_SILU), the split-operand arithmetic."""
+    if not (_scaler_chain[0] and act_name in ("relu", "silu") and H.get_precision() in H.SPLIT_EXACT and len(convs) == 3):
         return False
     for c in convs:
         if not (isinstance(c, torch.nn.Conv2d) and tuple(c.kernel_size) == (3, 3) and tuple(c.stride) == (1, 1)
@@ -518,20 +534,23 @@ def _pad_filter(w, co_p, ci_p):
 
 
 class ScalerConvChainFn(Function):
-    """cat[x1, x2, x3] with x_i = relu(dropout(conv3x3(x_{i-1}, w_i))), channels-last, as three implicit GEMMs that write
-    straight into ONE buffer [B, H, W, 3 CP] (CP = the widest output rounded up to 16: each convolution owns a 16-byte
-    aligned CP-column segment, its padding columns come out of the product as exact zeros because the padded filter rows
-    are zero, and the next convolution reads its input segment in place -- no cat, no copies, no layout change).
+    """cat[x1, x2, x3] with x_i = act(dropout(conv3x3(x_{i-1}, w_i))), act = ReLU or SiLU, channels-last, as three implicit
+    GEMMs that write straight into ONE buffer [B, H, W, 3 CP] (CP = the widest output rounded up to 16: each convolution
+    owns a 16-byte aligned CP-column segment, its padding columns come out of the product as exact zeros because the padded
+    filter rows are zero, and the next convolution reads its input segment in place -- no cat, no copies, no layout change).
     Reference: Interp2dEncoder.forward, layers.py:497-507 (conv1 -> conv2 -> conv3 -> torch.cat) with Conv2dResBlock
-    (layers.py:88-150: conv -> dropout -> activation).  Dropout and ReLU sit in the epilogue of the product (ReLU
-    commutes with the non-negative dropout scale); the backward needs only the activated outputs: y > 0 <=> kept and
-    pre-activation > 0.  Backward: one elementwise pass masks the incoming gradient of all three segments, then per
-    convolution (last to first) the data gradient is an implicit GEMM on the tap-reversed filter whose epilogue adds the
-    next segment's masked gradient to it (into a buffer of the backward: the incoming gradient is read-only), and the
-    weight gradient runs next to it on the side stream."""
+    (layers.py:88-150: conv -> dropout -> activation).  Dropout and activation sit in the epilogue of the product.
+    ReLU commutes with the non-negative dropout scale and the backward needs only the activated outputs: y > 0 <=> kept
+    and pre-activation > 0.  SiLU (Interp2dEncoder's default, ex3's down-scaler; round 6) does not: the epilogue applies
+    the dropout in FRONT of it (GT_ACT_DROP_SILU) and leaves the factor of the backward, keepscale * silu'(u), in a second
+    buffer `fac` of the same layout (returned, non-differentiable: bilinear_resize_seg(in_factor=fac) multiplies the
+    gradient with it on the way out).  Backward: per convolution (last to first) the data gradient is an implicit GEMM on
+    the tap-reversed filter whose epilogue multiplies by the previous segment's mask / factor and adds that segment's own
+    masked gradient (into a buffer of the backward: the incoming gradient is read-only), and the weight gradient runs next
+    to it on the side stream."""
 
     @staticmethod
-    def forward(ctx, x0, w1, w2, w3, p_drop: float, grad_masked: bool = False):
+    def forward(ctx, x0, w1, w2, w3, p_drop: float, grad_masked: bool = False, act: int = H.ACT_RELU):
         H.need_f32_cuda(x0, w1, w2, w3)
         B, Hh, Ww, C0 = x0.shape
         ws = (w1, w2, w3)
@@ -539,7 +558,9 @@ class ScalerConvChainFn(Function):
         T = B * Hh * Ww
         dev = x0.device
         x0c = _c(x0)
+        silu = act == H.ACT_SILU
         cat = torch.empty(T, 3 * CP, dtype=torch.float32, device=dev)
+        fac = torch.empty(T, 3 * CP, dtype=torch.float32, device=dev) if silu else None
         salt = _next_salt(3)
         cin = (C0, CP, CP)
         ctx.prec = H.get_precision()             # bf16x3 or f16x2 (scaler_chain_ok); the backward runs in the same arithmetic
@@ -547,32 +568,42 @@ class ScalerConvChainFn(Function):
             wf = _gathered(w, ("chain_fwd", CP, cin[i]), lambda t, ci_=cin[i]: _conv_k_order(_pad_filter(t, CP, ci_)))   # [CP, 9 cin] in k order
             A = x0c.reshape(T, C0) if i == 0 else cat[:, (i - 1) * CP:i * CP]
             H.gemm(A, wf, cat[:, i * CP:(i + 1) * CP], T, CP, 9 * cin[i], lda=(C0 if i == 0 else 3 * CP), ldb=9 * cin[i],
-                   ldc=3 * CP, conv=(Hh, Ww, cin[i]), act=H.ACT_RELU,
+                   ldc=3 * CP, conv=(Hh, Ww, cin[i]), act=H.ACT_DROP_SILU if silu else H.ACT_RELU,
+                   pre=fac[:, i * CP:(i + 1) * CP] if silu else None, ldpre=3 * CP,
                    drop=H.dropout_desc(p_drop, salt + i, dev) if p_drop > 0 else None, precision=ctx.prec)
         if _scaler_mask_sink[0] is not None:
-            c4 = cat.view(B, Hh, Ww, 3 * CP)
-            _scaler_mask_sink[0].append([c4[..., i * CP:i * CP + w.shape[0]] > 0 for i, w in enumerate(ws)])
-        ctx.save_for_backward(x0c, w1, w2, w3, cat)
-        ctx.cfg = (p_drop, CP, grad_masked)
-        return cat.view(B, Hh, Ww, 3 * CP)
+            # ReLU: kept and positive.  SiLU: kept (the factor keepscale * silu'(u) vanishes only where the dropout struck)
+            c4 = (fac if silu else cat).view(B, Hh, Ww, 3 * CP)
+            _scaler_mask_sink[0].append([(c4[..., i * CP:i * CP + w.shape[0]] != 0) if silu else
+                                         (c4[..., i * CP:i * CP + w.shape[0]] > 0) for i, w in enumerate(ws)])
+        ctx.save_for_backward(x0c, w1, w2, w3, cat, fac)
+        ctx.cfg = (p_drop, CP, grad_masked, silu)
+        out = cat.view(B, Hh, Ww, 3 * CP)
+        if not silu:
+            return out
+        fac4 = fac.view(B, Hh, Ww, 3 * CP)
+        ctx.mark_non_differentiable(fac4)
+        return out, fac4
 
     @staticmethod
-    def backward(ctx, g):
-        x0c, w1, w2, w3, cat = ctx.saved_tensors
-        p_drop, CP, grad_masked = ctx.cfg
+    def backward(ctx, g, _gfac=None):
+        x0c, w1, w2, w3, cat, fac = ctx.saved_tensors
+        p_drop, CP, grad_masked, silu = ctx.cfg
         prec = ctx.prec
         B, Hh, Ww, C0 = x0c.shape
         T = B * Hh * Ww
         dev = g.device
         ws = (w1, w2, w3)
         cin = (C0, CP, CP)
-        scale = 1.0 / (1.0 - p_drop)
-        # masked gradient of the three activated outputs in one pass (the dropout scale rides on the products' alpha)
-        # (grad_masked: the consumer -- bilinear_resize_seg(relu_input=True) -- has already zeroed it where cat <= 0).
+        # ReLU: the dropout scale rides on the products' alpha; SiLU: it is part of `fac`
+        scale = 1.0 if silu else 1.0 / (1.0 - p_drop)
+        # masked gradient of the three activated outputs in one pass
+        # (grad_masked: the consumer -- bilinear_resize_seg(relu_input=True / in_factor=fac) -- has already applied it).
         # The incoming gradient is never written: the completed gradients of segments 0 and 1 (their own masked gradient
         # + the data gradient of the convolution behind them) go to a buffer of this function, so a hook / retain_grad on
         # the chain's output, or a second consumer summed by autograd, sees and produces what it should.
-        gsrc = _c(g).reshape(T, 3 * CP) if grad_masked else H.act_bwd(_c(g).reshape(T, 3 * CP), cat, H.ACT_RELU)
+        g2 = _c(g).reshape(T, 3 * CP)
+        gsrc = g2 if grad_masked else (g2 * fac if silu else H.act_bwd(g2, cat, H.ACT_RELU))
         acc = torch.empty(T, 2 * CP, dtype=torch.float32, device=dev)
         dws = [None, None, None]
         dx0 = None
@@ -590,12 +621,13 @@ class ScalerConvChainFn(Function):
                     dx0 = torch.empty(T, C0, dtype=torch.float32, device=dev)
                     H.gemm(seg, wd, dx0, T, C0, 9 * CP, lda=ldseg, ldb=9 * CP, ldc=C0, conv=(Hh, Ww, CP), alpha=scale,
                            precision=prec)
-                else:       # + the segment's own masked gradient (res), through its ReLU / dropout mask (aux)
+                else:       # + the segment's own masked gradient (res), through its ReLU / dropout mask or its SiLU factor (aux)
+                    aux = (fac if silu else cat)[:, (i - 1) * CP:i * CP]
                     H.gemm(seg, wd, acc[:, (i - 1) * CP:i * CP], T, CP, 9 * CP, lda=ldseg, ldb=9 * CP, ldc=2 * CP,
-                           conv=(Hh, Ww, CP), alpha=scale, aux_op=H.AUX_GT0, aux=cat[:, (i - 1) * CP:i * CP], ldaux=3 * CP,
+                           conv=(Hh, Ww, CP), alpha=scale, aux_op=H.AUX_MUL if silu else H.AUX_GT0, aux=aux, ldaux=3 * CP,
                            res=gsrc[:, (i - 1) * CP:i * CP], ldr=3 * CP, precision=prec)
             H.join_side(dev)        # the next weight gradient reads the segment this data gradient has just completed
-        return (None if dx0 is None else dx0.view(B, Hh, Ww, C0)), dws[0], dws[1], dws[2], None, None
+        return (None if dx0 is None else dx0.view(B, Hh, Ww, C0)), dws[0], dws[1], dws[2], None, None, None
 
 
 _scaler_wgrad_hip = [os.environ.get("GT_SCALER_WGRAD", "hip") != "miopen"]     # A/B switch (tools / tests)
@@ -621,12 +653,16 @@ def _scaler_wgrad(dseg, ldg, xin, ldx, w, B, Hh, Ww, CP, cin, scale, prec=None):
     return (dw[:co, :ci] * scale).contiguous()
 
 
-def scaler_conv_chain(x0, w1, w2, w3, p_drop: float = 0.0, training: bool = True, grad_masked: bool = False):
+def scaler_conv_chain(x0, w1, w2, w3, p_drop: float = 0.0, training: bool = True, grad_masked: bool = False,
+                      act: str = "relu"):
     """x0 (B, H, W, C0) channels-last -> (B, H, W, 3 CP): see ScalerConvChainFn; column segment i holds x_{i+1} in its
     first w_i.shape[0] columns, zeros behind them.  grad_masked: the ONLY consumer of the result is
-    bilinear_resize_seg(relu_input=True), whose backward hands the gradient over already multiplied by [result > 0] (the
-    masking pass of the backward is then skipped; the gradient itself is only read)."""
-    return ScalerConvChainFn.apply(x0, w1, w2, w3, float(p_drop) if training else 0.0, bool(grad_masked))
+    bilinear_resize_seg(relu_input=True) (act='silu': in_factor=fac), whose backward hands the gradient over already
+    multiplied by [result > 0] (by fac) -- the masking pass of the backward is then skipped; the gradient itself is only
+    read.  act='silu' returns (buffer, fac)."""
+    if act not in ("relu", "silu"):
+        raise NotImplementedError(f"scaler_conv_chain: activation {act!r}")
+    return ScalerConvChainFn.apply(x0, w1, w2, w3, float(p_drop) if training else 0.0, bool(grad_masked), H.ACT_CODE[act])
 
 
 # ----------------------------------------------------------------------------------- Linear

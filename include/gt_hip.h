@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 19
+#define GT_ABI_VERSION 20
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -37,6 +37,11 @@ extern "C" {
 #define GT_ACT_RELU 1
 #define GT_ACT_SILU 2
 #define GT_ACT_GELU 3   /* erf GELU; gt_dropact_fwd / gt_dropact_bwd only (every other entry point: GT_EINVAL) */
+#define GT_ACT_DROP_SILU 4   /* gt_gemm only: the dropout sits in FRONT of the SiLU -- Conv2dResBlock's conv -> dropout -> activation
+                                (layers.py:139-149) with a non-ReLU activation, where the two do not commute:
+                                    u = keepscale(m, n) * v;   result = silu(u);   pre[m][n] (optional) = keepscale(m, n) * silu'(u)
+                                `drop` is consumed here (not applied again behind the activation), and `pre` receives the factor the
+                                backward multiplies the output gradient with (GT_AUX_MUL) instead of the pre-activation */
 
 /* gt_gemm_desc.aux_op: multiply the result by a function of aux[m][n] */
 #define GT_AUX_NONE      0
@@ -80,7 +85,7 @@ int gt_dropact_bwd(const float* x, const float* gy, float* gx, int64_t n, const 
  *     acc[m][n] = sum_k  A_z(m,k) * keepA(m,k) * B_z(k,n)
  *     v   = alpha*acc + bias[n] + sum_{j<rp} rp_a[m][j]*rp_b[n][j] + add_z[m][n]
  *     pre[m][n] = v                                  (optional)
- *     v   = act(v) ;  v *= f(aux[m][n]) ;  v = dropout(v)
+ *     v   = act(v) ;  v *= f(aux[m][n]) ;  v = dropout(v)          (act = GT_ACT_DROP_SILU: see there)
  *     C_z[m][n] = res_z[m][n] + out_scale*v          (res optional)
  *
  *   layout_a = 0 : A(m,k) = A[m*lda + k]     (k contiguous; activations [tokens, features])
@@ -475,12 +480,16 @@ int gt_bilinear2d_bwd(const float* g, const float* y_saved, float* dx, int32_t B
  * i.e. segment widths seg, seg, C - 2*seg, zeros behind them -- and y [B, Ho, Wo, C] is dense.  The concatenation is never
  * materialised.  Backward: g, y_saved dense like y; dx in the padded layout (padding columns get zero); x_gate (optional)
  * = the forward input x itself when it is the output of a ReLU: dx is zeroed where x <= 0, i.e. the gradient leaves
- * already multiplied by the derivative of the ReLU that produced x (one elementwise pass less in its producer). */
+ * already multiplied by the derivative of the ReLU that produced x (one elementwise pass less in its producer).
+ * ABI v20 -- act = GT_ACT_SILU (Interp2dEncoder's default activation_type, layers.py:446-456; ex3's down-scaler): the forward
+ * also writes dact [B, Ho, Wo, C] = silu'(resized value) and the backward takes THAT buffer as y_saved (its gradient is
+ * g * dact); gate_mul != 0 makes x_gate a multiplicative factor (dx *= x_gate: the keepscale * silu' buffer a
+ * GT_ACT_DROP_SILU product left in `pre`) instead of the ReLU test. */
 int gt_bilinear2d_seg_fwd(const float* x, float* y, int32_t B, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
-                          int32_t Wo, int32_t act, int32_t seg, int32_t segp, void* stream);
+                          int32_t Wo, int32_t act, int32_t seg, int32_t segp, float* dact, void* stream);
 int gt_bilinear2d_seg_bwd(const float* g, const float* y_saved, float* dx, int32_t B, int32_t C, int32_t Hi,
                           int32_t Wi, int32_t Ho, int32_t Wo, int32_t act, int32_t seg, int32_t segp,
-                          const float* x_gate, void* stream);
+                          const float* x_gate, int32_t gate_mul, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * First stage of the CNN down-scaler in one pass (layers.py:483-495 with Conv2dResBlock :88-150):
@@ -488,7 +497,9 @@ int gt_bilinear2d_seg_bwd(const float* g, const float* y_saved, float* dx, int32
  * x [B,Cin,H,W] (Cin <= 4), w [Cout,Cin,3,3] (padding 1, stride 1, no bias), y [B,Cout,Ho,Wo], all
  * channels-first.  The Cout-channel fine-resolution map is never materialised.  The dropout mask is
  * indexed by the linear NCHW index of the (virtual) conv output, i.e. identical to running
- * gt_dropout_apply on it.  act must be GT_ACT_RELU.
+ * gt_dropout_apply on it.  act: GT_ACT_RELU, or (ABI v20) GT_ACT_SILU = the same pass with SiLU on both sides of the resize
+ * (Interp2dEncoder's default activation_type='silu', layers.py:446-456: ex3's down-scaler); the SiLU backward re-evaluates
+ * the convolution at the four source pixels (no decision bits: relu_bits must be NULL) and does not read y.
  * Backward produces the weight gradient only (dw [Cout,Cin,3,3]; two-pass deterministic reduction
  * through ws); callers that need d/dx use the unfused operators.
  * ------------------------------------------------------------------------------------------- */

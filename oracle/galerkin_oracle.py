@@ -45,6 +45,31 @@ Tensor = torch.Tensor
 AttnDrop = Union[None, str, Tensor]
 
 
+# --------------------------------------------------------------------------- mask-replay audit
+# A parity run that replays the device's ReLU decisions (relu_mask / relu_masks below) must not be able to hide a wrong
+# mask behind the replay: with a list installed here, every replayed gate appends a record of how the replayed decisions
+# compare with this function's OWN `pre > 0` -- {"where", "n", "flipped", "max_rel"}: elements, elements whose replayed
+# decision differs, and the largest |pre| / rms(pre) among those.  Decisions may differ only where the pre-activation lies
+# within rounding of the kink; tests/_util.py::check_replay_audit holds the records to that.
+_replay_audit: List[Optional[list]] = [None]
+
+
+def set_replay_audit(sink: Optional[list]) -> None:
+    _replay_audit[0] = sink
+
+
+def _audit(where: str, pre: Tensor, dec: Tensor) -> None:
+    sink = _replay_audit[0]
+    if sink is None:
+        return
+    with torch.no_grad():
+        flip = (pre > 0) != dec.to(torch.bool)
+        nf = int(flip.sum())
+        rms = float(pre.double().pow(2).mean().sqrt())
+        mx = float(pre[flip].abs().max()) / max(rms, 1e-300) if nf else 0.0
+        sink.append({"where": where, "n": pre.numel(), "flipped": nf, "max_rel": mx})
+
+
 # --------------------------------------------------------------------------- helpers
 def _sub(sd: Mapping[str, Tensor], prefix: str) -> Dict[str, Tensor]:
     """Sub-dict of ``sd`` with ``prefix`` stripped."""
@@ -139,6 +164,8 @@ def feed_forward(sd: Mapping[str, Tensor], x: Tensor, activation: str = "relu",
     fp32 implementations, the reference on two machines included, may disagree there; each such element moves the
     parameter gradients by ~1e-4 relative)."""
     pre = F.linear(x, sd["lr1.weight"], sd["lr1.bias"])
+    if relu_mask is not None:
+        _audit("ff", pre, relu_mask)
     h = pre * relu_mask.to(pre.dtype) if relu_mask is not None else _act(activation, "relu")(pre)
     return F.linear(h, sd["lr2.weight"], sd["lr2.bias"])
 
@@ -279,22 +306,23 @@ def interp_downscaler(sd: Mapping[str, Tensor], node: Tensor, *, interp_size,
     act = _act(activation)
     x = node.permute(0, 3, 1, 2)
 
-    def gated(pre, m):
+    def gated(pre, m, where="scaler"):
         if m is None:
             return act(pre)
         m = m.to(pre.device)
         own = (pre > 0)
         dec = torch.where(m == 1, torch.ones_like(own), torch.where(m == 0, torch.zeros_like(own), own))
+        _audit(where, pre, dec)
         return pre * dec.to(pre.dtype)
 
     rm = relu_masks or {}
     chain = rm.get("chain") or [None, None, None]
     chain = [None if m is None else m.permute(0, 3, 1, 2) for m in chain]
-    x = gated(F.conv2d(x, sd["downsample.conv0.conv.0.weight"], padding=1), rm.get("conv0"))
+    x = gated(F.conv2d(x, sd["downsample.conv0.conv.0.weight"], padding=1), rm.get("conv0"), "scaler.conv0")
     x = act(_interp(x, interp_size[0]))
-    x1 = gated(F.conv2d(x, sd["downsample.conv1.conv.0.weight"], padding=1), chain[0])
-    x2 = gated(F.conv2d(x1, sd["downsample.conv2.conv.0.weight"], padding=1), chain[1])
-    x3 = gated(F.conv2d(x2, sd["downsample.conv3.conv.0.weight"], padding=1), chain[2])
+    x1 = gated(F.conv2d(x, sd["downsample.conv1.conv.0.weight"], padding=1), chain[0], "scaler.conv1")
+    x2 = gated(F.conv2d(x1, sd["downsample.conv2.conv.0.weight"], padding=1), chain[1], "scaler.conv2")
+    x3 = gated(F.conv2d(x2, sd["downsample.conv3.conv.0.weight"], padding=1), chain[2], "scaler.conv3")
     out = torch.cat([x1, x2, x3], dim=1)
     out = act(_interp(out, interp_size[1]))
     return out.permute(0, 2, 3, 1)

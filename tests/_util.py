@@ -35,6 +35,38 @@ def all_golden(prefix=""):
                   if f.endswith(".npz") and f.startswith(prefix) and not f.startswith("host_"))
 
 
+class replay_audit:
+    """``with replay_audit() as a: <float64 oracle run with replayed ReLU decisions>`` then ``a.check()``: the decisions the
+    device run handed to the checker may differ from the float64 oracle's own ``pre > 0`` on at most ``max_frac`` of a gate's
+    elements, and only where ``|pre| < max_rel * rms(pre)`` -- i.e. only where the pre-activation lies within rounding of
+    the kink.  A systematically wrong mask (a transposed tile, a stale buffer) fails here instead of being replayed into
+    the reference."""
+
+    def __init__(self, max_frac=1e-5, max_rel=1e-5):
+        self.max_frac, self.max_rel, self.records = max_frac, max_rel, []
+
+    def __enter__(self):
+        from oracle import galerkin_oracle as O
+        O.set_replay_audit(self.records)
+        return self
+
+    def __exit__(self, *exc):
+        from oracle import galerkin_oracle as O
+        O.set_replay_audit(None)
+
+    def summary(self):
+        return {"gates": len(self.records), "elements": sum(r["n"] for r in self.records),
+                "flipped": sum(r["flipped"] for r in self.records),
+                "worst_frac": max((r["flipped"] / r["n"] for r in self.records), default=0.0),
+                "worst_rel": max((r["max_rel"] for r in self.records), default=0.0)}
+
+    def check(self, min_gates=1):
+        assert len(self.records) >= min_gates, (len(self.records), min_gates)
+        bad = [r for r in self.records if r["flipped"] > self.max_frac * r["n"] + 1 or r["max_rel"] > self.max_rel]
+        assert not bad, bad[:8]
+        return self.summary()
+
+
 def rel_l2(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()

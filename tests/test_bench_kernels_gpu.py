@@ -29,7 +29,7 @@ import sys
 import pytest
 import torch
 
-from _util import rel_l2, TOL
+from _util import rel_l2, replay_audit, TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -128,10 +128,12 @@ def test_encoder_layer_bench_kernel_instances(gpu_device, name, mode):
         torch.cuda.synchronize()
         ops.set_relu_mask_sink(None)
         assert len(relu_masks) == 1
-        ref_y, (ref_dx,), ref_dp = O.grads_of(
-            lambda s, xx: O.encoder_layer(s, xx, pos.double(), n_head=h, attention_type="galerkin", layer_norm=False,
-                                          attn_norm=True, norm_eps=eps, attn_drop=mask, relu_mask=relu_masks[0].cpu()),
-            sd, [x.double()], cot.double())
+        with replay_audit() as audit:                      # the replayed decisions vs the oracle's own pre > 0
+            ref_y, (ref_dx,), ref_dp = O.grads_of(
+                lambda s, xx: O.encoder_layer(s, xx, pos.double(), n_head=h, attention_type="galerkin", layer_norm=False,
+                                              attn_norm=True, norm_eps=eps, attn_drop=mask, relu_mask=relu_masks[0].cpu()),
+                sd, [x.double()], cot.double())
+        audit.check(min_gates=1)
         errs = {"out": rel_l2(y, ref_y), "dx": rel_l2(xg.grad, ref_dx)}
         for k, v in dict(layer.named_parameters()).items():
             errs[k] = rel_l2(v.grad, ref_dp[k])
@@ -235,7 +237,9 @@ def test_whole_model_darcy141_vs_oracle(gpu_device, mode, scaler_act):
         if scaler_act == "relu":
             assert len(chain_masks) == 1 and int((conv0_mask < 2).sum()) > 0
             sm = {"conv0": conv0_mask.cpu(), "chain": [m.cpu().to(torch.uint8) for m in chain_masks[0]]}
-        ref, _, ref_dp = oracle(torch.float64, rm, sm)
+        with replay_audit() as audit:
+            ref, _, ref_dp = oracle(torch.float64, rm, sm)
+        audit_rec = audit.check(min_gates=L + (4 if scaler_act == "relu" else 0))
         errs = {"out": rel_l2(out, ref)}
         for k, v in dict(model.named_parameters()).items():
             errs[k] = rel_l2(v.grad, ref_dp[k])
@@ -253,7 +257,7 @@ def test_whole_model_darcy141_vs_oracle(gpu_device, mode, scaler_act):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"parity_whole_model_{mode}_{scaler_act}.json"), "w") as f:
         json.dump({"hip_vs_f64": errs, "oracle_f32_vs_f64": noise, "hip_vs_oracle_f32": vs32,
-                   "precision": gt.get_precision()}, f, indent=1)
+                   "precision": gt.get_precision(), "replay_audit": audit_rec}, f, indent=1)
 
     def tol(k):
         if k == "out":

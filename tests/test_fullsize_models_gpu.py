@@ -19,7 +19,7 @@ import sys
 import pytest
 import torch
 
-from _util import rel_l2, TOL
+from _util import rel_l2, replay_audit, TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -94,7 +94,9 @@ def test_whole_model_full_size_vs_oracle(gpu_device, workload, B):
         sm = {"conv0": conv0_mask.cpu() if int((conv0_mask < 2).sum()) > 0 else None,
               "chain": [m.cpu().to(torch.uint8) for m in chain_masks[0]] if chain_masks else None}
     del conv0_mask
-    ref, _, ref_dp = oracle(torch.float64, rm, sm)
+    with replay_audit() as audit:           # the replayed ReLU decisions vs the float64 oracle's own pre > 0
+        ref, _, ref_dp = oracle(torch.float64, rm, sm)
+    audit_rec = audit.check(min_gates=L)
     y32, _, dp32 = oracle(torch.float32, rm, sm)
     grads = {k: v.grad.cpu() for k, v in model.named_parameters()}
     errs = {k: rel_l2(grads[k], ref_dp[k]) for k in ref_dp}
@@ -105,7 +107,7 @@ def test_whole_model_full_size_vs_oracle(gpu_device, workload, B):
     rec = {"workload": workload, "B": B, "prediction": errs["out"], "grad_max": max(v for k, v in errs.items() if k != "out"),
            "grad_max_oracle_f32": max(v for k, v in noise.items() if k != "out"),
            "worst": sorted(((k, v, noise[k]) for k, v in errs.items()), key=lambda kv: -kv[1])[:5],
-           "precision": gt.get_precision()}
+           "precision": gt.get_precision(), "replay_audit": audit_rec}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"parity_whole_model_full_{workload}.json"), "w") as f:
         json.dump(rec, f, indent=1)
@@ -175,7 +177,9 @@ def test_ns_lite_full_rollout_vs_oracle(gpu_device):
         tot.backward()
         return [p.detach() for p in pr], {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
 
-    p64, g64 = oracle(torch.float64)
+    with replay_audit() as audit:
+        p64, g64 = oracle(torch.float64)
+    audit_rec = audit.check(min_gates=STEPS * L)
     p32, g32 = oracle(torch.float32)
     grads = {k: v.grad.cpu() for k, v in model.named_parameters()}
     errs = {k: rel_l2(grads[k], g64[k]) for k in g64}
@@ -185,7 +189,8 @@ def test_ns_lite_full_rollout_vs_oracle(gpu_device):
     rec = {"workload": "ex4_ns", "B": B, "steps": STEPS, "prediction_worst_step": errs["out"],
            "prediction_last_step": rel_l2(preds[-1], p64[-1]), "prediction_oracle_f32": noise["out"],
            "grad_max": max(v for k, v in errs.items() if k != "out"),
-           "grad_max_oracle_f32": max(v for k, v in noise.items() if k != "out"), "precision": gt.get_precision()}
+           "grad_max_oracle_f32": max(v for k, v in noise.items() if k != "out"), "precision": gt.get_precision(),
+           "replay_audit": audit_rec}
     with open(os.path.join(ROOT, "gpurun_out", "parity_whole_model_full_ex4_ns.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec))

@@ -1392,6 +1392,114 @@ def test_scaler_chain_with_masked_segment_resize_matches_reference(H, gpu_device
     assert torch.equal(buf.grad[buf.detach() <= 0], torch.zeros_like(buf.grad[buf.detach() <= 0]))
 
 
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("B,Cin,Cout,n,size,p_drop", [(2, 1, 192, 141, 0.51, 0.05), (2, 1, 40, 29, (16, 16), 0.0),
+                                                      (1, 3, 24, 9, (25, 21), 0.2), (2, 2, 8, 6, (1, 4), 0.0)])
+def test_conv3x3_resize_silu(H, gpu_device, B, Cin, Cout, n, size, p_drop, nhwc):
+    """gt_conv3x3_resize_* with act = GT_ACT_SILU (ABI v20; reference Interp2dEncoder with its default activation_type='silu',
+    layers.py:446-456, 483-495 -- ex3's down-scaler): silu(resize(silu(dropout(conv3x3(x))))) in one pass and its weight
+    gradient (both activations re-evaluated in the backward) against float64 torch with the dropout mask the stand-alone
+    gt_dropout_apply draws for the same (seed, salt) on the channels-first convolution output."""
+    import torch.nn.functional as F
+    from galerkin_transformer import ops
+    dev = gpu_device
+    x = rnd(B, Cin, n, n + 2, dev=dev, seed=460)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, seed=461, scale=0.5)
+    H.set_seed(778, dev)
+    H._salt[0] = 11
+    wg = w.clone().requires_grad_(True)
+    y = ops.conv3x3_resize(x, wg, size, p_drop, True, out_nhwc=nhwc, act="silu")
+    yc = y.permute(0, 3, 1, 2) if nhwc else y
+    cot = rnd(*yc.shape, dev=dev, seed=462)
+    yc.backward(cot)
+    torch.cuda.synchronize()
+    # the mask of the fused pass = what gt_dropout_apply gives a ones tensor of the conv output's shape with the same salt
+    keep = torch.ones(B, Cout, n, n + 2, device=dev)
+    if p_drop > 0:
+        keep = H.dropout_apply(keep, H.dropout_desc(p_drop, 11, dev))
+        assert abs(float((keep == 0).float().mean()) - p_drop) < 0.02
+    xr, wr = x.double(), w.double().requires_grad_(True)
+    y0 = F.silu(F.conv2d(xr, wr, padding=1) * keep.double())
+    ref = F.silu(F.interpolate(y0, size=tuple(yc.shape[2:]), mode="bilinear", align_corners=True))
+    (gw,) = torch.autograd.grad(ref, wr, cot.double())
+    assert rel_l2(yc, ref) < 3e-6
+    assert rel_l2(wg.grad, gw) < 1e-5
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.05])
+@pytest.mark.parametrize("B,Hh,C0,widths,Ho", [(2, 71, 192, (64, 64, 64), 36), (3, 78, 128, (42, 42, 44), 43)])
+def test_scaler_chain_silu_with_factor_resize_matches_reference(H, gpu_device, p_drop, B, Hh, C0, widths, Ho):
+    """The SiLU form of the down-scaler's production combination (round 6; reference Interp2dEncoder.forward, layers.py:497-512,
+    with activation_type='silu' -- ex3): scaler_conv_chain(act='silu', grad_masked=True) -> bilinear_resize_seg(act='silu',
+    in_factor=fac), i.e. GT_ACT_DROP_SILU epilogues (dropout in front of the SiLU, keepscale * silu' left in `fac`), the
+    GT_AUX_MUL data-gradient epilogues and the multiplicative in-gate of the segment resize, against conv2d x 3 + cat +
+    F.interpolate + SiLU in float64 with the dropout masks the run drew (fac != 0)."""
+    import torch.nn.functional as F
+    from galerkin_transformer import ops
+    dev = gpu_device
+    Ww = Hh
+    x0 = rnd(B, Hh, Ww, C0, dev=dev, seed=471).requires_grad_(True)
+    ws = [rnd(co, ci, 3, 3, dev=dev, seed=472 + i, scale=0.1).requires_grad_(True)
+          for i, (co, ci) in enumerate(zip(widths, (C0,) + widths[:2]))]
+    H.set_seed(81, dev)
+    buf, fac = ops.scaler_conv_chain(x0, *ws, p_drop=p_drop, training=True, grad_masked=True, act="silu")
+    assert not fac.requires_grad
+    buf.retain_grad()
+    CP = buf.shape[-1] // 3
+    y = ops.bilinear_resize_seg(buf, sum(widths), (Ho, Ho), widths[0], CP, act="silu", in_factor=fac)
+    cot = rnd(*y.shape, dev=dev, seed=479)
+    y.backward(cot)
+    torch.cuda.synchronize()
+    for i in range(3):          # padding columns: exact zeros in the buffer
+        assert torch.equal(buf[..., i * CP + widths[i]:(i + 1) * CP], torch.zeros_like(buf[..., i * CP + widths[i]:(i + 1) * CP]))
+    xr = x0.detach().double().requires_grad_(True)
+    wr = [w.detach().double().requires_grad_(True) for w in ws]
+    scale = 1.0 / (1.0 - p_drop)
+    cur, refs = xr, []
+    for i in range(3):
+        keep = (fac[..., i * CP:i * CP + widths[i]] != 0).double()
+        if p_drop > 0:
+            assert abs(1.0 - float(keep.mean()) - p_drop) < 0.01
+        else:
+            assert bool(keep.all())
+        pre = F.conv2d(cur.permute(0, 3, 1, 2), wr[i], padding=1).permute(0, 2, 3, 1)
+        cur = F.silu(pre * keep * scale)
+        refs.append(cur)
+        assert rel_l2(buf[..., i * CP:i * CP + widths[i]], cur) < 3e-6, i
+    rcat = torch.cat(refs, -1).permute(0, 3, 1, 2)
+    ry = F.silu(F.interpolate(rcat, size=(Ho, Ho), mode="bilinear", align_corners=True)).permute(0, 2, 3, 1)
+    ry.backward(cot.double())
+    assert rel_l2(y, ry) < 3e-6
+    for i in range(3):
+        assert rel_l2(ws[i].grad, wr[i].grad) < 5e-6, i
+    assert rel_l2(x0.grad, xr.grad) < 5e-6
+
+
+def test_scaler_chain_silu_unmasked_gradient(H, gpu_device):
+    """scaler_conv_chain(act='silu') consumed directly (grad_masked=False): its backward applies the factor itself."""
+    import torch.nn.functional as F
+    from galerkin_transformer import ops
+    dev = gpu_device
+    B, Hh, C0, widths = 1, 40, 96, (32, 32, 32)
+    x0 = rnd(B, Hh, Hh, C0, dev=dev, seed=481).requires_grad_(True)
+    ws = [rnd(co, ci, 3, 3, dev=dev, seed=482 + i, scale=0.1).requires_grad_(True)
+          for i, (co, ci) in enumerate(zip(widths, (C0,) + widths[:2]))]
+    buf, fac = ops.scaler_conv_chain(x0, *ws, p_drop=0.0, training=True, act="silu")
+    cot = rnd(*buf.shape, dev=dev, seed=489)
+    buf.backward(cot)
+    xr = x0.detach().double().requires_grad_(True)
+    wr = [w.detach().double().requires_grad_(True) for w in ws]
+    cur, refs = xr, []
+    for i in range(3):
+        cur = F.silu(F.conv2d(cur.permute(0, 3, 1, 2), wr[i], padding=1).permute(0, 2, 3, 1))
+        refs.append(cur)
+    rcat = torch.cat(refs, -1)
+    rcat.backward(cot.double())
+    assert rel_l2(buf, rcat) < 3e-6 and rel_l2(x0.grad, xr.grad) < 5e-6
+    for i in range(3):
+        assert rel_l2(ws[i].grad, wr[i].grad) < 5e-6, i
+
+
 def test_resize_seg_equals_dense_resize(H, gpu_device):
     """gt_bilinear2d_seg_fwd/bwd (the last resize of the down-scaler reading the padded three-segment buffer) == the dense
     channels-last resize of the gathered real channels, forward and backward (padding columns of dx: zero)."""
