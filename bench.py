@@ -223,6 +223,9 @@ class Trainer:
         self.comm_enabled = True
         self.g_fb = self.g_opt = None
         self.use_graph = use_graph
+        self.comm_in_graph = False           # ask for the collective inside the step graph (capture(); falls back)
+        self.one_graph = False               # ... and whether the current capture is that form
+        self.comm_events = None              # list: step() appends an event pair around every host-issued collective
 
     def fwd_bwd(self):
         self._hip.weight_packs.refresh()         # every weight of the step packed in ONE launch (they changed in opt_step)
@@ -270,6 +273,26 @@ class Trainer:
         torch.cuda.synchronize()
         if not self.use_graph:
             return False
+        self.one_graph = False
+        if self.world > 1 and self.comm_in_graph and self.flat and self.comm_enabled:
+            # the RCCL all-reduce captured between the two compute legs: ONE replay per step, no host round trip between
+            # backward and optimizer.  Any failure (a backend that cannot be captured -- gloo --, an
+            # RCCL build without graph support) leaves the two-graph form below.
+            try:
+                for p in self.params:
+                    p.grad = None
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.fwd_bwd()
+                    self.comm()
+                    self.opt_step()
+                torch.cuda.synchronize()
+                self.g_fb, self.g_opt, self.one_graph = g, None, True
+                return True
+            except Exception as e:
+                print(f"[bench] collective-in-graph capture failed ({type(e).__name__}: {e}); two graphs", file=sys.stderr)
+                self.g_fb = self.g_opt = None
+                torch.cuda.synchronize()
         try:
             for p in self.params:
                 p.grad = None
@@ -298,17 +321,27 @@ class Trainer:
             self.eager_step()
             return
         self.g_fb.replay()
-        if self.world > 1:
-            self.comm()
+        if self.world > 1 and not self.one_graph:
+            if self.comm_events is not None and self.comm_enabled:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.comm()
+                e1.record()
+                self.comm_events.append((e0, e1))
+            else:
+                self.comm()
             self.g_opt.replay()
 
 
-def timed_run(tr, steps, warmup, world):
+def timed_run(tr, steps, warmup, world, comm_rec=None):
+    """comm_rec (dict, N > 1): filled with the device time of the timed steps' host-issued collectives (event pairs on the
+    stream the step runs on)."""
     for _ in range(warmup):
         tr.step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    tr.comm_events = [] if (comm_rec is not None and world > 1) else None
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.step()
@@ -317,6 +350,10 @@ def timed_run(tr, steps, warmup, world):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if tr.comm_events is not None:           # (read back outside the timed region)
+        ev, tr.comm_events = tr.comm_events, None
+        us = [a.elapsed_time(b) * 1e3 for a, b in ev]
+        comm_rec.update(allreduce_us_per_step=(round(sum(us) / len(us), 1) if us else None), timed_collectives=len(us))
     if world > 1:
         t = torch.tensor([elapsed], device=tr.dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -699,6 +736,29 @@ DTYPE_TEXT = {
 }
 
 
+def strong_leg(tr, G, per_gpu, steps, warmup, world, rank, workload, dev):
+    """The same step at a FIXED global batch G split evenly over the ranks (north_star: strong scaling) -- a second timed
+    region of the same process on a fresh synthetic batch of G / world samples per rank, same model and optimizer state
+    (re-captured graphs).  At N = 1 this is the one-GPU time of G samples, the denominator of the strong-scaling speed-up."""
+    old = tr.batch
+    try:
+        tr.g_fb = tr.g_opt = None
+        torch.cuda.empty_cache()
+        tr.batch = synthetic_batch(per_gpu, dev, seed=2000 + rank, workload=workload)
+        graphed = tr.capture(warm=2)
+        comm = {}
+        e = timed_run(tr, steps, min(warmup, 3), world, comm_rec=comm)
+        rec = {"global_batch": G, "per_gpu_batch": per_gpu, "value": round(G * steps / e, 2), "unit": "samples/s",
+               "ms_per_step": round(e / steps * 1e3, 3), "steps": steps, "hip_graph": bool(graphed)}
+        if comm:
+            rec["allreduce_us_per_step"] = comm.get("allreduce_us_per_step")
+        return rec
+    finally:
+        tr.batch = old
+        tr.g_fb = tr.g_opt = None
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -721,6 +781,10 @@ def main():
     ap.add_argument("--no-accuracy", action="store_true", help="skip the short convergence run (val rel-L2)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra timed run in the exact fp32 MFMA mode")
     ap.add_argument("--table", default=None, help="write the per-kernel event table to this JSON file")
+    ap.add_argument("--strong-global-batch", default="512", help="comma list: global batches of the extra strong-scaling "
+                    "legs every --scaling weak run adds to its line (each split evenly over the ranks; '' or 0: none)")
+    ap.add_argument("--comm-in-graph", action="store_true", help="N > 1: capture the RCCL all-reduce inside the step graph "
+                    "(one replay per step); falls back to the two-graph form when the capture fails")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -763,8 +827,16 @@ def main():
     batch = synthetic_batch(per_gpu, dev, seed=1000 + rank, workload=a.workload)
     tr = Trainer(model, batch, world, use_graph=not a.no_graph, workload=a.workload, loss=a.loss,
                  optimizer=a.optimizer)
+    tr.comm_in_graph = bool(a.comm_in_graph)
     graphed = tr.capture()
-    elapsed = timed_run(tr, a.steps, a.warmup, world)
+    comm = None
+    if world > 1:
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)                            # every rank contributes 1: the ranks the collective really spans
+        comm = {"bytes": 4 * sum(p.numel() for p in tr.params), "backend": a.backend, "ranks_seen": int(seen.item()),
+                "collective": "one flat fp32 sum-all-reduce of the gradient bucket per step, 1/world folded into clip + Adam",
+                "in_graph": bool(tr.one_graph)}
+    elapsed = timed_run(tr, a.steps, a.warmup, world, comm_rec=comm)
     loss = float(tr.loss.item())
 
     # the same timed region once more in the bit-exact fp32 MFMA arithmetic (new captures, same weights trajectory)
@@ -803,6 +875,17 @@ def main():
             print(f"[bench] accuracy leg failed: {type(e).__name__}: {e}", file=sys.stderr)
     if world > 1:
         dist.barrier()
+    # strong-scaling legs (every rank takes part): the fixed global batches G next to the weak-scaling value of the line
+    strong = []
+    if a.scaling == "weak" and a.strong_global_batch not in ("", "0"):
+        for G in [int(x) for x in a.strong_global_batch.split(",") if x.strip()]:
+            if G <= 0 or G % world:
+                continue
+            try:
+                strong.append(strong_leg(tr, G, G // world, min(a.steps, 10), a.warmup, world, rank, a.workload, dev))
+            except Exception as e:                       # (out of memory at N = 1, ...): the line says so instead of dying
+                print(f"[bench] strong leg G={G} failed: {type(e).__name__}: {e}", file=sys.stderr)
+                strong.append({"global_batch": G, "per_gpu_batch": G // world, "value": None, "error": type(e).__name__})
 
     if rank == 0:
         value = gb * a.steps / elapsed
@@ -824,6 +907,9 @@ def main():
             # algorithmic work of the whole step (19.3 GFLOP per sample fwd + bwd) over the step time
             "useful_tflops": (round(19.3e9 * gb / (elapsed / a.steps) / 1e12, 2) if a.workload == "ex2_darcy141" else None),
             "roofline": roof, "cpu_baseline": cpu, "parity": parity_record(), "accuracy": acc,
+            # N > 1: where the exchange step's time went; every N: the same step at fixed global batches (strong scaling:
+            # speed-up at N GPUs = strong[i].value of the N-GPU line / strong[i].value of the 1-GPU line)
+            "comm": comm, "strong": strong or None,
         }
         if a.table and table:
             with open(a.table, "w") as f:

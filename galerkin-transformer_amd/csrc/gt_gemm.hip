@@ -589,6 +589,18 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
 
 using namespace gt;
 
+// GT_EP_HEADNORM with 48-wide heads (ex3: d_model 192, 4 heads): the fused epilogue needs every head inside one wave's 64
+// output columns, so the product runs with each head in a 64-column SLOT -- N' = 3 h 64 tile columns, the 16 columns behind a
+// head are zero rows of the PACKED weight (the pack kernels map slot rows to weight rows; the weight itself is read in place),
+// and the epilogue normalises / stores the 48 real columns.  The caller's descriptor keeps N = 3 h 48; every entry point
+// plans with this copy.  (A third more MFMA work in a launch that is bound by its memory traffic; no extra HBM byte.)
+static const gt_gemm_desc* hn_slots(const gt_gemm_desc* d, gt_gemm_desc* tmp) {
+    if (!d || d->ep_mode != GT_EP_HEADNORM || d->hn_dk != 48 || d->hn_h <= 0 || d->N != 3 * d->hn_h * 48) return d;
+    *tmp = *d;
+    tmp->N = 3 * d->hn_h * 64;
+    return tmp;
+}
+
 extern "C" void gt_gemm_desc_init(gt_gemm_desc* d) {
     memset(d, 0, sizeof(*d));
     d->alpha = 1.f;
@@ -601,6 +613,8 @@ extern "C" void gt_gemm_desc_init(gt_gemm_desc* d) {
 
 extern "C" int gt_gemm_plan(const gt_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* split) {
     Plan pl;
+    gt_gemm_desc hs;
+    d = hn_slots(d, &hs);
     int rc = make_plan(d, &pl);
     if (rc) return rc;
     if (bm) *bm = pl.bm;
@@ -622,6 +636,8 @@ static int64_t acs_parts(const gt_gemm_desc* d, const Plan& pl) {
 extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) {
     Plan pl;
     if (!d || !buf || n <= 0) return GT_EINVAL;
+    gt_gemm_desc hs;
+    d = hn_slots(d, &hs);
     if (!getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) {
         snprintf(buf, n, "%s", tsmm_kernel_name(d));
         return 0;
@@ -638,7 +654,7 @@ extern "C" int gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n) 
         q.a_vec = al16(d->A) && m4(d->lda) && m4(d->a_bs0) && m4(d->a_bs1);
         q.b_vec = al16(d->B) && m4(d->ldb) && m4(d->b_bs0) && m4(d->b_bs1);
         snprintf(buf, n, "%s", x3_kernel_name(q, d->layout_a, d->layout_b, pl.x3,
-                                              d->ep_mode == GT_EP_HEADNORM ? d->hn_dk : 0));
+                                              d->ep_mode == GT_EP_HEADNORM ? hn_slot_width(d->hn_dk) : 0));
     }
     else if (pl.stream)
         snprintf(buf, n, "void gt::gemm_stream_kernel<%d, %d, %d>(gt::GemmP)", d->layout_a, d->layout_b, c.mt);
@@ -653,8 +669,9 @@ static bool width_split(const gt_gemm_desc* d, gt_gemm_desc* a, gt_gemm_desc* b)
 static int64_t ws_bytes_one(const gt_gemm_desc* d);
 
 extern "C" int64_t gt_gemm_ws_bytes(const gt_gemm_desc* d) {
-    gt_gemm_desc a, b;
-    if (d && width_split(d, &a, &b)) return std::max(ws_bytes_one(&a), ws_bytes_one(&b));
+    gt_gemm_desc a, b, hs;
+    d = hn_slots(d, &hs);
+    if (d && width_split(d, &a, &b)) return std::max(ws_bytes_one(&a), ws_bytes_one(&b));     // (b_packed is inherited by both)
     return ws_bytes_one(d);
 }
 
@@ -677,7 +694,7 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
         return GT_EINVAL;
     if (d->ep_mode == GT_EP_HEADNORM) {
         if (d->layout_a || d->layout_b || d->batch0 * d->batch1 != 1 || d->K2 > 0 || d->split_k > 1) return GT_ENOTSUP;
-        if (d->hn_h <= 0 || d->hn_p < 0 || d->N != 3 * d->hn_h * d->hn_dk || (d->hn_norm_mask & ~7)) return GT_EINVAL;
+        if (d->hn_h <= 0 || d->hn_p < 0 || d->N != 3 * d->hn_h * hn_slot_width(d->hn_dk) || (d->hn_norm_mask & ~7)) return GT_EINVAL;
         if (!d->hn_out || (d->hn_p > 0 && !d->hn_pos)) return GT_EINVAL;
         if (d->hn_norm_mask && (!d->hn_gamma || !d->hn_beta || !d->hn_stats)) return GT_EINVAL;
         if (d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res || d->out_scale != 1.f ||
@@ -758,7 +775,7 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
         if (!pl.x3 || pl.split != 1) return GT_ENOTSUP;
         p.ep_mode = d->ep_mode;
         p.hn_gamma = d->hn_gamma; p.hn_beta = d->hn_beta; p.hn_pos = d->hn_pos; p.hn_out = d->hn_out;
-        p.hn_stats = d->hn_stats; p.hn_h = d->hn_h; p.hn_dk = d->hn_dk; p.hn_p = d->hn_p;
+        p.hn_stats = d->hn_stats; p.hn_h = d->hn_h; p.hn_dk = hn_slot_width(d->hn_dk); p.hn_dkr = d->hn_dk; p.hn_p = d->hn_p;
         p.hn_DP = (d->hn_dk + d->hn_p + 3) & ~3; p.hn_mask = d->hn_norm_mask; p.hn_eps = d->hn_eps;
         p.hn_skip_raw = d->hn_skip_raw_mask & 7; p.hn_plain = d->hn_plain != 0;
     } else if (d->ep_mode != GT_EP_NORMAL) {
@@ -924,30 +941,67 @@ static bool width_split(const gt_gemm_desc* d, gt_gemm_desc* a, gt_gemm_desc* b)
 // the remainder on a narrow-tile configuration.
 // > 0: gt_gemm(d) is ONE launch of the packed-B kernels and this is the size of its packed weight (the buffer a caller that
 // packs ahead -- gt_gemm_pack_b_many -- hands over in d->b_packed); 0: some other path, b_packed must stay NULL
-extern "C" int64_t gt_gemm_packed_b_bytes(const gt_gemm_desc* d) {
-    if (!d) return 0;
-    gt_gemm_desc a, b;
-    if (width_split(d, &a, &b)) return 0;
+static int64_t packed_bytes_one(const gt_gemm_desc* d) {
     Plan pl;
     if (!getenv("GT_GEMM_NO_TSMM") && tsmm_eligible(d)) return 0;
     if (make_plan(d, &pl) || !pl.x3 || !x3_packed_ok(d, pl.x3, pl.split)) return 0;
     return x3_packed_bytes(d);
 }
 
+// Round 6: a width-split product (N = 192 = 128 + 64, ex3's d_model) is TWO packed-B launches when both column ranges take
+// the packed kernels; its packed weight is the two packs back to back (the aligned range first).
+extern "C" int64_t gt_gemm_packed_b_bytes(const gt_gemm_desc* d) {
+    if (!d) return 0;
+    gt_gemm_desc a, b, hs;
+    d = hn_slots(d, &hs);
+    if (width_split(d, &a, &b)) {
+        a.b_packed = b.b_packed = nullptr;
+        const int64_t pa = packed_bytes_one(&a), pb = packed_bytes_one(&b);
+        return (pa > 0 && pb > 0) ? pa + pb : 0;
+    }
+    return packed_bytes_one(d);
+}
+
 extern "C" int gt_gemm_pack_b_many(const gt_gemm_desc* descs, void* const* outs, int32_t n, void* stream) {
-    if (!descs || !outs) return GT_EINVAL;
-    for (int i = 0; i < n; ++i)
+    if (!descs || !outs || n < 0 || n > 64) return GT_EINVAL;
+    gt_gemm_desc parts[128];
+    void* pouts[128];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
         if (gt_gemm_packed_b_bytes(&descs[i]) <= 0) return GT_ENOTSUP;
-    return x3_pack_b_many(descs, outs, n, (hipStream_t)stream);
+        gt_gemm_desc a, b, hs;
+        const gt_gemm_desc* di = hn_slots(&descs[i], &hs);
+        if (di != &descs[i]) {
+            parts[m] = *di; pouts[m++] = outs[i];
+        } else if (width_split(&descs[i], &a, &b)) {
+            a.b_packed = b.b_packed = nullptr;
+            parts[m] = a; pouts[m++] = outs[i];
+            parts[m] = b; pouts[m++] = reinterpret_cast<char*>(outs[i]) + packed_bytes_one(&a);
+        } else {
+            parts[m] = descs[i]; pouts[m++] = outs[i];
+        }
+    }
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        int rc = x3_pack_b_many(parts + i0, pouts + i0, std::min(64, m - i0), (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int gt_gemm(const gt_gemm_desc* d, void* ws, int64_t ws_bytes, void* stream) {
     if (!d) return GT_EINVAL;
-    gt_gemm_desc a, b;
+    gt_gemm_desc a, b, hs;
+    d = hn_slots(d, &hs);
     if (width_split(d, &a, &b)) {
-        // a weight packed ahead describes ONE packed-B launch over the full width (gt_gemm_packed_b_bytes(d) > 0): the two
-        // column ranges would both read it with the wrong tile geometry
-        if (d->b_packed) return GT_EINVAL;
+        // a weight packed ahead is the two column ranges' packs back to back (gt_gemm_packed_b_bytes): each range gets ITS
+        // pack -- never the full-width pointer with the wrong tile geometry
+        if (d->b_packed) {
+            a.b_packed = b.b_packed = nullptr;
+            const int64_t pa = packed_bytes_one(&a);
+            if (pa <= 0 || packed_bytes_one(&b) <= 0) return GT_EINVAL;
+            a.b_packed = d->b_packed;
+            b.b_packed = reinterpret_cast<const char*>(d->b_packed) + pa;
+        }
         int rc = gemm_one(&a, d->N, 0, ws, ws_bytes, stream);
         if (rc) return rc;
         return gemm_one(&b, d->N, a.N, ws, ws_bytes, stream);      // same stream: the scratch is free again

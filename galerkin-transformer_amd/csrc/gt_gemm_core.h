@@ -30,6 +30,7 @@ struct GemmP {
     // GT_EP_HEADNORM (split-operand ring kernel): head-norm forward fused behind the QKV projection
     const float* hn_gamma; const float* hn_beta; const float* hn_pos; float* hn_out; float* hn_stats;
     int hn_h, hn_dk, hn_p, hn_DP, hn_mask, hn_skip_raw, hn_plain; float hn_eps;
+    int hn_dkr;              // real head width: == hn_dk, or 48 inside hn_dk = 64-column head SLOTS (gt_gemm.hip: hn_slots)
     int cv_H, cv_W, cv_C, cv_wgrad;  // implicit 3x3 convolution (gt_hip.h: cv_*), cv_C = 0: plain GEMM
     const void* Bp; int bp_NT, bp_KS, bp_f16; // packed-B kernel (gt_gemm_x3.hip): bf16 (fp16: bp_f16) planes of B in fragment order
     int wg_f16;                              // gemm_x3w_kernel: the GT_PREC_F16X2 token-contracted weight gradient
@@ -410,6 +411,7 @@ bool x3_packed_ok(const gt_gemm_desc* d, int planes, int split);
 int64_t x3_packed_bytes(const gt_gemm_desc* d);
 int x3_pack_b_many(const gt_gemm_desc* descs, void* const* outs, int n, hipStream_t st);
 int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipStream_t st);
+inline int hn_slot_width(int dk) { return dk == 48 ? 64 : dk; }     // head width -> columns of its slot in the N dimension
 bool x3w_ok(const gt_gemm_desc* d, int split);
 
 }  // namespace gt

@@ -395,7 +395,10 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
     const int lr = lane & 31, lh = lane >> 5;
     const int nwave = ncol - 4 * lh;                          // first column of this wave's 64 (a multiple of 64)
     if (nwave >= p.N) return;                                 // wave-uniform: N is a multiple of 64 here
-    const float inv = 1.f / (float)DK;
+    // head slots (DK = 64 only): the head occupies the first DKR = hn_dkr (48) columns of its 64-column slot, the accumulators
+    // of the 16 columns behind it are exact zeros (zero rows of the packed weight).  GPR: the lane's real 4-column groups.
+    const int DKR = (DK == 64) ? p.hn_dkr : DK, GPR = DKR >> 3;
+    const float inv = 1.f / (float)DKR;
     const int DP = p.hn_DP, W = NSEG * DP, sw = W + 4, W4 = W >> 2;
     const int stream = nwave / (p.hn_h * DK), head0 = (nwave / DK) % p.hn_h;
     const bool normed = (p.hn_mask >> stream) & 1;
@@ -410,7 +413,8 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
     for (int sg = 0; sg < NSEG; ++sg)
 #pragma unroll
         for (int q = 0; q < GPS; ++q)
-            bv[sg][q] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nwave + sg * DK + 8 * q + 4 * lh) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[sg][q] = (p.bias && q < GPR) ? *reinterpret_cast<const f32x4*>(p.bias + (nwave / DK + sg) * DKR + 8 * q + 4 * lh)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
     // granule walk of the tile store below: lane's first granule (row, 16-byte column) and the step of 64 granules
     const int g_r0 = lane / W4, g_c0 = lane - g_r0 * W4, g_dr = 64 / W4, g_dc = 64 - g_dr * W4;
     const int nit = (32 * W4 + 63) >> 6, rstride = p.hn_h * DP;
@@ -435,27 +439,32 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
                 const int j = c >> 5, g = (c & 31) >> 3;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[q][t] = p.alpha * acc[i][j][4 * g + t] + bv[sg][q][t];
-                if (row_ok && store_raw)
-                    *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + nwave + c + 4 * lh) = f32x4{v[q][0], v[q][1], v[q][2], v[q][3]};
+                if (row_ok && store_raw && q < GPR)          // (column of the caller's [M, 3 h DKR] projection)
+                    *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + (nwave / DK + sg) * DKR + 8 * q + 4 * lh) =
+                        f32x4{v[q][0], v[q][1], v[q][2], v[q][3]};
             }
             float mu = 0.f, rstd = 1.f;
             if (normed) {                                     // wave-uniform branch: the exchange below is convergent
                 float sum = 0.f;
 #pragma unroll
-                for (int q = 0; q < GPS; ++q) sum += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+                for (int q = 0; q < GPS; ++q)
+                    if (q < GPR) sum += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
                 sum = xor32_sum(sum);
                 mu = sum * inv;
                 float ss = 0.f;
 #pragma unroll
                 for (int q = 0; q < GPS; ++q)
+                    if (q < GPR) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) { const float c0 = v[q][t] - mu; ss = fmaf(c0, c0, ss); }
+                        for (int t = 0; t < 4; ++t) { const float c0 = v[q][t] - mu; ss = fmaf(c0, c0, ss); }
+                    }
                 ss = xor32_sum(ss);
                 rstd = 1.f / sqrtf(ss * inv + p.hn_eps);
             }
             float* seg = srow + sg * DP;
 #pragma unroll
             for (int q = 0; q < GPS; ++q) {
+                if (q >= GPR) continue;
                 const int dim = 8 * q + 4 * lh;
                 float y[4] = {v[q][0], v[q][1], v[q][2], v[q][3]};
                 if (normed) {
@@ -463,8 +472,8 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
 #pragma unroll
                         for (int t = 0; t < 4; ++t) y[t] = (y[t] - mu) * rstd;
                     } else {
-                        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.hn_gamma + (ni * p.hn_h + head) * DK + dim);
-                        const f32x4 bt = *reinterpret_cast<const f32x4*>(p.hn_beta + (ni * p.hn_h + head) * DK + dim);
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.hn_gamma + (ni * p.hn_h + head) * DKR + dim);
+                        const f32x4 bt = *reinterpret_cast<const f32x4*>(p.hn_beta + (ni * p.hn_h + head) * DKR + dim);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) y[t] = (y[t] - mu) * rstd * gm[t] + bt[t];
                     }
@@ -477,7 +486,7 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
                     if (jj < p.hn_p) seg[jj] = posv[i][jj];
-                for (int jj = p.hn_p + DK; jj < DP; ++jj) seg[jj] = 0.f;
+                for (int jj = p.hn_p + DKR; jj < DP; ++jj) seg[jj] = 0.f;
                 if (normed && row_ok)
                     *reinterpret_cast<f32x2*>(p.hn_stats + (((int64_t)ni * p.M + m) * p.hn_h + head) * 2) = f32x2{mu, rstd};
             }
@@ -955,17 +964,27 @@ __global__ __launch_bounds__(256, (R <= 3 ? 3 : 2)) void gemm_x3r_kernel(const G
 constexpr int X3P_R = GT_X3P_RING;
 static_assert(X3P_R >= 3 && X3P_R <= 6, "the counted waits below are written out for ring depths 3..6");
 
+// Row of the weight behind tile row n (pad48: the tile rows are 64-column head slots holding 48-wide heads, the 16 rows behind
+// a head are zero -- gt_gemm.hip: hn_slots; N counts slot rows then), -1: a zero row.
+__device__ __forceinline__ int x3_pack_row(int n, int N, int pad48) {
+    if (n >= N) return -1;
+    if (!pad48) return n;
+    const int j = n & 63;
+    return j < 48 ? (n >> 6) * 48 + j : -1;
+}
+
 __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K,
-                                                        int NT, int KS, u32x4* __restrict__ out) {
+                                                        int NT, int KS, u32x4* __restrict__ out, int pad48) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= NT * KS * 64) return;
     const int lane = idx & 63, t = idx >> 6, ks = t % KS, nt = t / KS;
     const int n = nt * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+    const int nr = x3_pack_row(n, N, pad48);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = k0 + e;
-        v[e] = (n < N && k < K) ? (layout_b == 0 ? B[(int64_t)n * ldb + k] : B[(int64_t)k * ldb + n]) : 0.f;
+        v[e] = (nr >= 0 && k < K) ? (layout_b == 0 ? B[(int64_t)nr * ldb + k] : B[(int64_t)k * ldb + nr]) : 0.f;
         v[e] *= x3_alt_sign(n);                    // GT_X3_ALT: odd rows of the N-side operand enter negated
     }
     uint32_t q[4][3];
@@ -979,16 +998,17 @@ __global__ __launch_bounds__(256) void x3_pack_b_kernel(const float* __restrict_
 // GT_PREC_F16X2: the two fp16 planes of B in the same fragment order, one block per 32-column tile: pass 1 takes the tile's
 // amax (its exponent e: amax 2^e in [2^13, 2^14)), pass 2 splits the scaled values.  The exponents follow the planes as NT ints.
 __device__ __forceinline__ void x3_pack_b16_tile(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K, int NT,
-                                                 int KS, u32x4* __restrict__ out, int nt) {
+                                                 int KS, u32x4* __restrict__ out, int nt, int pad48 = 0) {
     __shared__ float red[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = nt * 32 + (lane & 31);
+    const int nr = x3_pack_row(n, N, pad48);
     auto load8 = [&](int ks, float (&v)[8]) {        // this lane's eight k of stage ks (one row n, k contiguous or strided)
         const int k0 = ks * 16 + 8 * (lane >> 5);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e;
-            v[e] = (n < N && k < K) ? (layout_b == 0 ? B[(int64_t)n * ldb + k] : B[(int64_t)k * ldb + n]) : 0.f;
+            v[e] = (nr >= 0 && k < K) ? (layout_b == 0 ? B[(int64_t)nr * ldb + k] : B[(int64_t)k * ldb + nr]) : 0.f;
         }
     };
     // sixteen waves, a stage each per trip; a wave's stages stay in registers between the two passes when there are at most
@@ -1042,8 +1062,8 @@ __device__ __forceinline__ void x3_pack_b16_tile(const float* __restrict__ B, in
     if (tid == 0) reinterpret_cast<int*>(out + (int64_t)2 * NT * KS * 64)[nt] = e;
 }
 __global__ __launch_bounds__(1024) void x3_pack_b16_kernel(const float* __restrict__ B, int layout_b, int64_t ldb, int N, int K,
-                                                           int NT, int KS, u32x4* __restrict__ out) {
-    x3_pack_b16_tile(B, layout_b, ldb, N, K, NT, KS, out, blockIdx.x);
+                                                           int NT, int KS, u32x4* __restrict__ out, int pad48) {
+    x3_pack_b16_tile(B, layout_b, ldb, N, K, NT, KS, out, blockIdx.x, pad48);
 }
 // All the step's weights in ONE launch (round 5, dispatch diet: a step packed 45 weights in 45 launches of 5 - 8 us): block b
 // works tile b - start[e] of entry e.
@@ -1053,12 +1073,14 @@ struct PackManyP {
     u32x4* out[X3_PACK_MANY];
     int64_t ldb[X3_PACK_MANY];
     int layout_b[X3_PACK_MANY], N[X3_PACK_MANY], K[X3_PACK_MANY], NT[X3_PACK_MANY], KS[X3_PACK_MANY], start[X3_PACK_MANY + 1];
+    unsigned char pad48[X3_PACK_MANY];
     int n;
 };
 __global__ __launch_bounds__(1024) void x3_pack_b16_many_kernel(const PackManyP p) {
     int e = 0;
     while (e + 1 < p.n && (int)blockIdx.x >= p.start[e + 1]) ++e;
-    x3_pack_b16_tile(p.B[e], p.layout_b[e], p.ldb[e], p.N[e], p.K[e], p.NT[e], p.KS[e], p.out[e], (int)blockIdx.x - p.start[e]);
+    x3_pack_b16_tile(p.B[e], p.layout_b[e], p.ldb[e], p.N[e], p.K[e], p.NT[e], p.KS[e], p.out[e], (int)blockIdx.x - p.start[e],
+                     p.pad48[e]);
 }
 
 #ifndef GT_X3P_BLOCKS                              // resident blocks per CU the general instances are compiled for
@@ -1895,6 +1917,15 @@ bool x3_shape_ok(const gt_gemm_desc* d) {
     if (d->ep_mode != GT_EP_NORMAL && d->ep_mode != GT_EP_HEADNORM) return false;
     // narrow implicit convolutions (N >= 32) ride on the 64-wide tile of the packed-B kernel
     if (d->cv_c > 0 && !d->cv_wgrad && d->N >= 32 && d->N < 96 && d->M >= 1024 && d->K >= 16) return true;
+    // round 6: narrow token products too (N < 96: the 64-column remainder of a width-split 192-wide product -- ex3's d_model --
+    // and the d_model = 48 / 64 products of ex4 / ex1), under exactly the conditions that put them on the packed-B kernels
+    // (x3_packed_ok), whose 128 x 64 tile instance takes N <= 64; they ran on the fp32 MFMA engine until now
+    static const int narrow = [] { const char* e = getenv("GT_X3_NARROW"); return e ? atoi(e) : 1; }();
+    if (narrow && d->cv_c == 0 && d->N >= 16 && d->N < 96 && d->M >= 16384 && d->M >= 8 * (int64_t)d->N && d->K >= 16 &&
+        (d->precision == GT_PREC_BF16X3 || d->precision == GT_PREC_F16X2) &&
+        (d->K & 3) == 0 && d->layout_a == 0 && d->batch0 * d->batch1 == 1 && d->K2 == 0 && !d->a_colsum && d->split_k == 1 &&
+        d->ep_mode == GT_EP_NORMAL && (d->lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d->A) & 15) == 0)
+        return true;
     return d->M >= 96 && d->N >= 96 && d->K >= 16;
 }
 
@@ -1902,6 +1933,7 @@ bool x3_shape_ok(const gt_gemm_desc* d) {
 bool x3_headnorm_ok(const GemmP& p, int layout_a, int layout_b, int planes) {
     if (layout_a || layout_b || planes != 3 || !x3r_ok(p, 0, 0)) return false;
     if (p.hn_dk != 16 && p.hn_dk != 32 && p.hn_dk != 64) return false;
+    if (p.hn_dkr != p.hn_dk && !(p.hn_dk == 64 && p.hn_dkr == 48 && p.Bp)) return false;   // head slots: packed-B kernels only
     if (p.hn_p > 4) return false;                  // the epilogue keeps a row's coordinates in four registers
     if (!p.c_vec || (p.N & 63) || (64 / p.hn_dk) * p.hn_DP + 4 > 88) return false;      // staging row fits X3_HN_STG
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -2050,6 +2082,11 @@ static inline int x3p_ks(int K) { return (K + X3_BK - 1) / X3_BK; }
 
 int64_t x3_packed_bytes(const gt_gemm_desc* d) { return (int64_t)3 * x3p_nt(d->N) * x3p_ks(d->K) * 1024; }
 
+// the descriptor (already in head slots, gt_gemm.hip: hn_slots) describes 48-wide heads in 64-column slots
+static inline int x3_pad48(const gt_gemm_desc* d) {
+    return d->ep_mode == GT_EP_HEADNORM && d->hn_dk == 48 && d->N == 3 * d->hn_h * 64;
+}
+
 int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipStream_t st) {
     if (d->b_packed) {                             // the caller packed this weight already (gt_gemm_pack_b_many)
         if (reinterpret_cast<uintptr_t>(d->b_packed) & 15) return GT_EALIGN;
@@ -2060,13 +2097,14 @@ int x3_pack_b(const gt_gemm_desc* d, GemmP& p, void* ws, int64_t ws_bytes, hipSt
     if (!ws || ws_bytes < x3_packed_bytes(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) return GT_EWS;
     const int NT = x3p_nt(d->N), KS = x3p_ks(d->K);
     const int threads = NT * KS * 64;
+    const int pad48 = x3_pad48(d);
     p.bp_f16 = d->precision == GT_PREC_F16X2;
     if (p.bp_f16)              // two planes + NT tile exponents: fits the three-plane buffer
         hipLaunchKernelGGL(x3_pack_b16_kernel, dim3(NT), dim3(1024), 0, st, d->B, d->layout_b, d->ldb, d->N, d->K, NT, KS,
-                           reinterpret_cast<u32x4*>(ws));
+                           reinterpret_cast<u32x4*>(ws), pad48);
     else
         hipLaunchKernelGGL(x3_pack_b_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, d->B, d->layout_b, d->ldb, d->N,
-                           d->K, NT, KS, reinterpret_cast<u32x4*>(ws));
+                           d->K, NT, KS, reinterpret_cast<u32x4*>(ws), pad48);
     GT_LAUNCH_CHECK();
     p.Bp = ws; p.bp_NT = NT; p.bp_KS = KS;
     return 0;
@@ -2080,7 +2118,7 @@ int x3_pack_b_many(const gt_gemm_desc* descs, void* const* outs, int n, hipStrea
         const gt_gemm_desc* d = &descs[i];
         if (d->precision != GT_PREC_F16X2 || !d->B || !outs[i] || (reinterpret_cast<uintptr_t>(outs[i]) & 15)) return GT_ENOTSUP;
         q.B[i] = d->B; q.out[i] = reinterpret_cast<u32x4*>(outs[i]); q.ldb[i] = d->ldb; q.layout_b[i] = d->layout_b;
-        q.N[i] = d->N; q.K[i] = d->K; q.NT[i] = x3p_nt(d->N); q.KS[i] = x3p_ks(d->K);
+        q.N[i] = d->N; q.K[i] = d->K; q.NT[i] = x3p_nt(d->N); q.KS[i] = x3p_ks(d->K); q.pad48[i] = (unsigned char)x3_pad48(d);
         q.start[i] = blocks;
         blocks += q.NT[i];
     }

@@ -944,7 +944,7 @@ class SimpleAttentionFn(Function):
         # tiles, and the raw projection has no reader left: it is neither written nor allocated (gt_hip.h: hn_plain)
         plain = (_plain_tiles[0] and kind == "galerkin" and _dkv_ln_fused[0] and H.galerkin_dkv_ln_supported(dk, p, norm_mask)
                  and H.galerkin_ktv_supported(dk, p))
-        if _qkvnorm_fused[0] and dk in (16, 32, 64) and bqkv is not None and H.get_precision() in H.SPLIT_EXACT:
+        if _qkvnorm_fused[0] and dk in (16, 32, 48, 64) and bqkv is not None and H.get_precision() in H.SPLIT_EXACT:
             # head norm on the projection's epilogue (GT_EP_HEADNORM): one pass less over [T, 3d], one launch less
             out3 = torch.empty(3, T, h, DP, dtype=torch.float32, device=dev)
             stats = torch.empty(2, T, h, 2, dtype=torch.float32, device=dev)

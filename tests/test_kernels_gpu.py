@@ -944,8 +944,9 @@ def test_gemm_x3_a_dropout_matches_f32_kernel(H, gpu_device):
                                            (257, 4, 32, 0, 0b000), (700, 4, 48, 2, 0b110)])
 def test_qkv_headnorm_fused_epilogue(H, gpu_device, T, h, dk, p, mask):
     """GT_EP_HEADNORM on the split-operand ring kernel: projection + per-head LayerNorm + position columns in one
-    launch == gt_gemm followed by gt_headnorm_fwd (layers.py:838-874).  dk = 48 is outside the fused kernel: the
-    library must say GT_ENOTSUP (the Python mirror then runs the two launches)."""
+    launch == gt_gemm followed by gt_headnorm_fwd (layers.py:838-874).  dk = 48 is outside the ring kernel's fused epilogue
+    (it exists on the packed-B kernels from 16 384 token rows, test_qkv_headnorm_head_slots_dk48): below that the library
+    must say GT_ENOTSUP (the Python mirror then runs the two launches)."""
     dev = gpu_device
     d = h * dk
     x = rnd(T, d, dev=dev, seed=110)
@@ -1235,6 +1236,149 @@ def test_plain_head_tiles_ktv_and_dkv_ln(H, gpu_device, B, n, h, dk, p):
     for a, c, name in zip(got, ref, ("d_qkv", "dgamma", "dbeta")):
         assert not torch.isnan(a).any(), name
         assert rel_l2(a, c) < 3e-6, name
+
+
+@pytest.mark.parametrize("prec", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("T,mask", [(20736, 0b110), (16500, 0b011)])
+def test_qkv_headnorm_head_slots_dk48(H, gpu_device, T, mask, prec):
+    """Round 6: GT_EP_HEADNORM for 48-wide heads (ex3: d_model 192, 4 heads; reference layers.py:838-874 with d_k = 48) on the
+    packed-B kernels -- every head in a 64-column slot of the tile, the 16 columns behind it zero rows of the packed weight
+    (gt_gemm.hip: hn_slots) -- against gt_gemm + gt_headnorm_fwd: head tiles, statistics, the raw projection where it is
+    written (skip_raw), plain tiles without any raw projection, and the weight packed ahead (gt_gemm_pack_b_many)."""
+    import ctypes as C
+    dev = gpu_device
+    h, dk, p = 4, 48, 2
+    d = h * dk
+    x = rnd(T, d, dev=dev, seed=130)
+    w = rnd(3 * d, d, dev=dev, seed=131, scale=0.2)
+    b = rnd(3 * d, dev=dev, seed=132)
+    gamma = 1 + 0.1 * rnd(2, h, dk, dev=dev, seed=133)
+    beta = 0.1 * rnd(2, h, dk, dev=dev, seed=134)
+    pos = rnd(T, p, dev=dev, seed=135)
+    eps = 1e-7
+    qkv = torch.empty(T, 3 * d, device=dev)
+    H.gemm(x, w, qkv, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, precision="f32")
+    out_ref, st_ref = H.headnorm_fwd(qkv, pos, gamma, beta, T, h, dk, p, mask, eps)
+    DP = H.round4(dk + p)
+    assert DP == 52
+    qkv2 = torch.full_like(qkv, float("nan"))
+    out3 = torch.full((3, T, h, DP), float("nan"), device=dev)
+    stats = torch.zeros(2, T, h, 2, device=dev)
+    hn = dict(gamma=gamma, beta=beta, pos=pos, out=out3, stats=stats, h=h, dk=dk, p=p, norm_mask=mask, eps=eps)
+    H.gemm(x, w, qkv2, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, hn=hn, precision=prec)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out3).any() and not torch.isnan(qkv2).any()
+    assert rel_l2(qkv2, qkv) < 2e-6
+    assert rel_l2(out3, out_ref) < 3e-6 and rel_l2(stats, st_ref) < 3e-6
+    assert torch.equal(out3[..., :p], out_ref[..., :p]) and torch.equal(out3[..., p + dk:], torch.zeros_like(out3[..., p + dk:]))
+    # skip_raw: only the normalised streams' raw blocks are written
+    qkv3 = torch.full_like(qkv, float("nan"))
+    out3b = torch.empty_like(out3)
+    H.gemm(x, w, qkv3, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, hn=dict(hn, out=out3b, skip_raw=(~mask) & 7), precision=prec)
+    torch.cuda.synchronize()
+    for st in range(3):
+        blk = qkv3[:, st * d:(st + 1) * d]
+        if (mask >> st) & 1:
+            assert torch.equal(blk, qkv2[:, st * d:(st + 1) * d])
+        else:
+            assert torch.isnan(blk).all()
+    assert torch.equal(out3b, out3)
+    if mask == 0b110:       # plain tiles: (x - mean) * rstd, nothing written to C (C = None)
+        outp = torch.full_like(out3, float("nan"))
+        stp = torch.zeros_like(stats)
+        H.gemm(x, w, None, T, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=b, precision=prec,
+               hn=dict(hn, out=outp, stats=stp, skip_raw=7, plain=True))
+        torch.cuda.synchronize()
+        assert torch.equal(stp, stats) and torch.equal(outp[0], out3[0])
+        for s_ in (1, 2):
+            val = outp[s_][:, :, p:p + dk] * gamma[s_ - 1] + beta[s_ - 1]
+            assert rel_l2(val, out3[s_][:, :, p:p + dk]) < 1e-6
+            assert torch.equal(outp[s_][:, :, :p], out3[s_][:, :, :p]) and torch.equal(outp[s_][:, :, p + dk:], out3[s_][:, :, p + dk:])
+    if prec == "f16x2":     # the weight packed ahead through the C ABI = the per-call pack, bit for bit
+        dsc = H.GtGemmDesc()
+        L = H.lib()
+        L.gt_gemm_desc_init(C.byref(dsc))
+        dsc.M, dsc.N, dsc.K, dsc.lda, dsc.ldb, dsc.ldc = T, 3 * d, d, d, d, 3 * d
+        dsc.A, dsc.B, dsc.C, dsc.bias = x.data_ptr(), w.data_ptr(), qkv3.data_ptr(), b.data_ptr()
+        dsc.precision, dsc.ep_mode = H.PREC_F16X2, H.EP_HEADNORM
+        dsc.hn_gamma, dsc.hn_beta, dsc.hn_pos = gamma.data_ptr(), beta.data_ptr(), pos.data_ptr()
+        out3c, stc = torch.full_like(out3, float("nan")), torch.zeros_like(stats)
+        dsc.hn_out, dsc.hn_stats = out3c.data_ptr(), stc.data_ptr()
+        dsc.hn_h, dsc.hn_dk, dsc.hn_p, dsc.hn_norm_mask, dsc.hn_eps = h, dk, p, mask, eps
+        need = L.gt_gemm_packed_b_bytes(C.byref(dsc))
+        assert need == 3 * (3 * h * 64 // 32) * (d // 16) * 1024         # planes of the SLOT width 3 h 64, not of 3 h 48
+        pack = torch.empty(need, dtype=torch.uint8, device=dev)
+        descs = (H.GtGemmDesc * 1)(dsc)
+        outs = (C.c_void_p * 1)(pack.data_ptr())
+        H.check(L.gt_gemm_pack_b_many(descs, outs, 1, H.stream_ptr()), "gt_gemm_pack_b_many")
+        dsc.b_packed = pack.data_ptr()
+        assert L.gt_gemm_ws_bytes(C.byref(dsc)) == 0
+        H.check(L.gt_gemm(C.byref(dsc), None, 0, H.stream_ptr()), "gt_gemm")
+        torch.cuda.synchronize()
+        assert torch.equal(out3c, out3) and torch.equal(stc, stats)
+
+
+@pytest.mark.parametrize("N,K,lb", [(64, 192, 0), (64, 384, 1), (48, 96, 0), (48, 48, 1), (16, 64, 0), (80, 128, 0)])
+def test_narrow_token_products_on_the_packed_kernels(H, gpu_device, N, K, lb):
+    """Round 6 (VERDICT r5 missing 4 / next-round 5): token products with a narrow output (N < 96: the d_model = 48 / 64 layers
+    of ex4 / ex1, the 64-column remainder of ex3's 192-wide products; nn.Linear at reference layers.py:811,823,964,976) run on
+    the packed-B two-term fp16 kernels (128 x 64 tile for N <= 64) from 16 384 token rows, with the full fused epilogue --
+    against fp64, and the same mask / residual as the fp32-MFMA engine they ran on before."""
+    dev = gpu_device
+    M = 16384 + 777
+    A = rnd(M, K, dev=dev, seed=300)
+    B = rnd(N, K, dev=dev, seed=301, scale=0.2) if lb == 0 else rnd(K, N, dev=dev, seed=301, scale=0.2)
+    bias, R = rnd(N, dev=dev, seed=302), rnd(M, N, dev=dev, seed=303)
+    name = H.gemm_kernel_name(A, B, M, N, K, layout_b=lb, lda=K, ldb=B.shape[1], ldc=N, precision="f16x2")
+    assert "gemm_x3h_kernel<0, 0, 0, %d>" % (64 if N <= 64 else 128) in name, name
+    assert "x3" not in H.gemm_kernel_name(A[:5000], B, 5000, N, K, layout_b=lb, lda=K, ldb=B.shape[1], ldc=N, precision="f16x2")
+    outs = {}
+    for prec in ("f32", "f16x2", "bf16x3"):
+        Cc = torch.full((M, N), float("nan"), device=dev)
+        H.gemm(A, B, Cc, M, N, K, layout_b=lb, lda=K, ldb=B.shape[1], ldc=N, bias=bias, act=H.ACT_RELU,
+               drop=H.dropout_desc(0.25, 91, dev), res=R, ldr=N, out_scale=-0.5, precision=prec)
+        outs[prec] = Cc
+    torch.cuda.synchronize()
+    keep = H.dropout_apply(torch.ones(M, N, device=dev), H.dropout_desc(0.25, 91, dev)).double()
+    ref = R.double() - 0.5 * torch.relu(ref_mm(A, B, 0, lb) + bias.double()) * keep
+    for prec in outs:
+        assert rel_l2(outs[prec], ref) < KTOL, (prec, rel_l2(outs[prec], ref))
+
+
+def test_width_split_product_takes_a_weight_packed_ahead(H, gpu_device):
+    """N = 192 (ex3's d_model) is cut into a 128-column launch and a 64-column remainder; round 6: both run on the packed-B
+    kernels and gt_gemm_packed_b_bytes / gt_gemm_pack_b_many / gt_gemm_desc.b_packed describe the two packs back to back --
+    the product with the weight packed ahead returns the bits of the per-call pack (and ADVICE r5: a b_packed pointer on a
+    product that is NOT packed that way is refused instead of being read with the wrong geometry)."""
+    import ctypes as C
+    dev = gpu_device
+    M, N, K = 20000, 192, 384
+    A, W = rnd(M, K, dev=dev, seed=310), rnd(N, K, dev=dev, seed=311, scale=0.1)
+    bias, R = rnd(N, dev=dev, seed=312), rnd(M, N, dev=dev, seed=313)
+    ref = torch.full((M, N), float("nan"), device=dev)
+    H.gemm(A, W, ref, M, N, K, lda=K, ldb=K, ldc=N, bias=bias, res=R, ldr=N, precision="f16x2")
+    L = H.lib()
+    d = H.GtGemmDesc()
+    L.gt_gemm_desc_init(C.byref(d))
+    out = torch.full((M, N), float("nan"), device=dev)
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = M, N, K, K, K, N, N
+    d.A, d.B, d.C, d.bias, d.res = A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr(), R.data_ptr()
+    d.precision = H.PREC_F16X2
+    need = L.gt_gemm_packed_b_bytes(C.byref(d))
+    one = lambda n: 3 * ((n + 127) // 128 * 4) * (K // 16) * 1024
+    assert need == one(128) + one(64)
+    pack = torch.empty(need, dtype=torch.uint8, device=dev)
+    H.check(L.gt_gemm_pack_b_many((H.GtGemmDesc * 1)(d), (C.c_void_p * 1)(pack.data_ptr()), 1, H.stream_ptr()), "pack")
+    d.b_packed = pack.data_ptr()
+    assert L.gt_gemm_ws_bytes(C.byref(d)) == 0
+    H.check(L.gt_gemm(C.byref(d), None, 0, H.stream_ptr()), "gt_gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert rel_l2(out, A.double() @ W.double().t() + bias.double() + R.double()) < KTOL
+    d.M = 3000                                   # below the packed kernels' row count: b_packed has no meaning here
+    assert L.gt_gemm_packed_b_bytes(C.byref(d)) == 0
+    ws = H.workspace(dev, max(int(L.gt_gemm_ws_bytes(C.byref(d))), 1 << 20))
+    assert L.gt_gemm(C.byref(d), ws.data_ptr(), ws.numel(), H.stream_ptr()) == -1          # GT_EINVAL
 
 
 def test_qkv_headnorm_plain_tiles(H, gpu_device):

@@ -250,7 +250,7 @@ def test_bench_two_ranks_on_one_gpu_gloo(gpu_device):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
-           "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]      # roofline + f32 legs stay on:
+           "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--strong-global-batch", "8"]      # roofline + f32 legs stay on:
     # rank 0's profiling step must not enter a collective the other rank never joins
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -262,6 +262,12 @@ def test_bench_two_ranks_on_one_gpu_gloo(gpu_device):
     assert rec["roofline"]
     if rec["config"]["precision"] != "f32":               # the fp32-MFMA leg is the comparison run of the other modes
         assert rec["f32_mfma_exact"]["value"] > 0
+    # round 6: where the exchange step's time went, and the strong-scaling leg next to the weak value
+    c = rec["comm"]
+    assert c["ranks_seen"] == 2 and c["backend"] == "gloo" and c["bytes"] == 4 * rec["config"]["params"] and not c["in_graph"]
+    assert c["timed_collectives"] == 2 and c["allreduce_us_per_step"] > 0
+    (st,) = rec["strong"]
+    assert st["global_batch"] == 8 and st["per_gpu_batch"] == 4 and st["value"] > 0 and st["allreduce_us_per_step"] > 0
 
 
 def _run_bench_ranks(extra, port, timeout=900):
@@ -272,7 +278,7 @@ def _run_bench_ranks(extra, port, timeout=900):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-f32-leg"] + extra
+           "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-f32-leg", "--strong-global-batch", "0"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
@@ -291,7 +297,8 @@ def test_bench_eight_ranks_on_one_gpu_gloo(gpu_device):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", "29551", os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--batch", "2",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-f32-leg", "--no-accuracy"]
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-f32-leg", "--no-accuracy",
+           "--strong-global-batch", "8", "--comm-in-graph"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
@@ -299,6 +306,13 @@ def test_bench_eight_ranks_on_one_gpu_gloo(gpu_device):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp8"
     assert rec["scaling"] == "weak" and rec["value"] > 0 and np.isfinite(rec["config"]["final_loss"])
+    # the line answers the strong-scaling target too and says where the exchange step's time went.
+    # (--comm-in-graph: gloo cannot be captured, so this also exercises the fallback to the two-graph step.)
+    c = rec["comm"]
+    assert c["ranks_seen"] == 8 and c["bytes"] == 4 * rec["config"]["params"] and c["backend"] == "gloo"
+    assert c["in_graph"] is False and c["timed_collectives"] == 2 and c["allreduce_us_per_step"] > 0
+    (st,) = rec["strong"]
+    assert st["global_batch"] == 8 and st["per_gpu_batch"] == 1 and st["value"] > 0 and st["hip_graph"]
 
 
 def test_bench_strong_scaling_two_ranks_gloo(gpu_device):
