@@ -274,7 +274,8 @@ class Trainer:
         if not self.use_graph:
             return False
         self.one_graph = False
-        if self.world > 1 and self.comm_in_graph and self.flat and self.comm_enabled:
+        if (self.world > 1 and self.comm_in_graph and self.flat and self.comm_enabled
+                and dist.get_backend() == "nccl"):       # (a gloo collective is a host copy: not capturable, and not recoverable)
             # the RCCL all-reduce captured between the two compute legs: ONE replay per step, no host round trip between
             # backward and optimizer.  Any failure (a backend that cannot be captured -- gloo --, an
             # RCCL build without graph support) leaves the two-graph form below.

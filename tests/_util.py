@@ -38,12 +38,20 @@ def all_golden(prefix=""):
 class replay_audit:
     """``with replay_audit() as a: <float64 oracle run with replayed ReLU decisions>`` then ``a.check()``: the decisions the
     device run handed to the checker may differ from the float64 oracle's own ``pre > 0`` on at most ``max_frac`` of a gate's
-    elements, and only where ``|pre| < max_rel * rms(pre)`` -- i.e. only where the pre-activation lies within rounding of
+    elements, and only where ``|pre| < MAX_REL * rms(pre)`` -- i.e. only where the pre-activation lies within rounding of
     the kink.  A systematically wrong mask (a transposed tile, a stale buffer) fails here instead of being replayed into
     the reference."""
 
-    def __init__(self, max_frac=1e-5, max_rel=1e-5):
-        self.max_frac, self.max_rel, self.records = max_frac, max_rel, []
+    # |pre| / rms(pre) below which a replayed decision may differ.  FeedForward gates: 1e-5 (fp32-class products on both
+    # sides).  Down-scaler gates: 1e-4 -- F.interpolate(align_corners=True) evaluates its source coordinates in the tensor's
+    # dtype, so every float32 evaluation of the first resize (the reference's own included) sits ~1e-4 relative from the
+    # float64 one (DESIGN 2; measured on the replay-relu run: 4 + 7 decisions of 9.4 M, |pre| <= 1.7e-5 rms), and the
+    # chain's pre-activations inherit that offset.
+    MAX_REL = {"ff": 1e-5, "scaler": 1e-4}
+
+    def __init__(self, max_frac=1e-5, max_rel=None):
+        self.max_frac, self.records = max_frac, []
+        self.max_rel = dict(self.MAX_REL) if max_rel is None else {"ff": max_rel, "scaler": max_rel}
 
     def __enter__(self):
         from oracle import galerkin_oracle as O
@@ -62,7 +70,8 @@ class replay_audit:
 
     def check(self, min_gates=1):
         assert len(self.records) >= min_gates, (len(self.records), min_gates)
-        bad = [r for r in self.records if r["flipped"] > self.max_frac * r["n"] + 1 or r["max_rel"] > self.max_rel]
+        bad = [r for r in self.records
+               if r["flipped"] > self.max_frac * r["n"] + 1 or r["max_rel"] > self.max_rel[r["where"].split(".")[0]]]
         assert not bad, bad[:8]
         return self.summary()
 

@@ -24,7 +24,7 @@ for part in $PARTS; do
     wprof:*)
       IFS=: read _ W B <<< "$part"
       cd /tmp
-      GT_DUAL_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$W -o p --output-format csv -- python $R/bench.py --workload $W ${B:+--batch $B} --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-accuracy --no-f32-leg > /dev/null 2>&1
+      GT_DUAL_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$W -o p --output-format csv -- python $R/bench.py --workload $W ${B:+--batch $B} --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-accuracy --no-f32-leg --strong-global-batch 0 > /dev/null 2>&1
       cd $R
       python tools/prof_csv_summary.py $O/prof_$W 70 --last-ms 300 --by-grid > $O/rocprofv3_$W.txt 2>/dev/null
       rm -rf $O/prof_$W
