@@ -307,7 +307,9 @@ __global__ __launch_bounds__(64 * NW, DUAL ? 2 : (DP > 36 ? 3 : 4)) void fourier
     for (int t = 0; t < p.ntile; ++t) {
         // tile t has landed for this wave (vmcnt) and for everybody (barrier); everybody is also done with tile t-1,
         // whose buffer the next request overwrites
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // (lgkmcnt too: the zero_g LDS store in front of the loop and this wave's LDS reads of tile t - 1 are formally
+        // ordered before the other waves' accesses only once the LDS counter has drained -- ADVICE r5)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int e1 = __builtin_amdgcn_readfirstlane(ne1), l1 = __builtin_amdgcn_readfirstlane(nl1);
         const int e2 = __builtin_amdgcn_readfirstlane(ne2), l2 = __builtin_amdgcn_readfirstlane(nl2);
         if (t + 1 < p.ntile) {

@@ -547,8 +547,11 @@ struct DkvLnP {
 // is never formed -- gamma scales the rows of the dM fragments (the contraction index is the tile column), beta dM is a
 // per-output-column constant added to the products, and xh for the LayerNorm backward is the tile itself: the raw
 // projection is neither stored by the forward nor read here.
+// G = 3 (DP = 52: ex3's 48-wide heads): the two sets of dM fragments alone are 104 registers -- at two blocks per CU the
+// kernel spilled 220 (PLAIN) / 119 registers to scratch and ran 2.7x slower per token than G = 2 (499 vs 181 us for the same
+// bytes, round 6 profile); one block per CU opens the whole 512-entry register file (no scratch).
 template <int G, bool PLAIN>
-__global__ __launch_bounds__(256, 2) void galerkin_dkv_ln_kernel(const DkvLnP p) {
+__global__ __launch_bounds__(256, (G >= 3 ? 1 : 2)) void galerkin_dkv_ln_kernel(const DkvLnP p) {
     constexpr int DP = 16 * G + 4, NS = 4 * G + 1, NMT = G + 1;
     __shared__ float red[4][4][NMT][4][4];          // [wave][kq][mt][c][dgK, dbK, dgV, dbV]
     __shared__ __attribute__((aligned(16))) float cst[2][4][NMT][4];    // PLAIN: [dK' | dV'][kq][mt][c] = (beta dM) of the lane's columns
@@ -1095,46 +1098,57 @@ __global__ __launch_bounds__(256) void galerkin_fin_bwd_kernel(
     DropDev drop, const float* __restrict__ Wfc, int h, int DP, int Dr, int d, float inv_n,
     float* __restrict__ dM, float* __restrict__ dWfc_slabs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int dpitch = d + 1;
-    float* sdp = lds;                       // [DP][d+1]   dP_h[j][c]
-    float* sW = sdp + DP * dpitch;          // [d][Dr]
+    // gridDim.y blocks share the two output loops of one (batch, head): part q owns ROWS [j0, j1) of dM and feature COLUMNS
+    // [c0, c1) of dWfc, and stages only what those need -- the row slice and the column slice of dP_h, all of W_h and M.
+    // (Round 6: every part used to stage all of dP_h; at d = 192, DP = 52 that was 89 KB of LDS, one block per CU and
+    // 252 us per launch -- now 69 KB at four parts, two blocks per CU.)
+    const int part = blockIdx.y, parts = gridDim.y;
+    const int jr = (DP + parts - 1) / parts, j0 = part * jr, j1 = min(DP, j0 + jr), nj = max(0, j1 - j0);
+    const int cr = (d + parts - 1) / parts, c0 = part * cr, c1 = min(d, c0 + cr), nc = max(0, c1 - c0);
+    const int dpitch = d + 1, cpitch = cr + 1;
+    float* sdr = lds;                       // [jr][d+1]    dP_h[j0 + j][c]        (rows of this part, every feature)
+    float* sdc = parts == 1 ? sdr : sdr + jr * dpitch;    // [DP][cr+1]   dP_h[j][c0 + c]   (every row, features of this part;
+                                                          //  one part: the same image as sdr)
+    float* sW = sdc + DP * cpitch;          // [d][Dr]
     float* sM = sW + d * Dr;                // [DP][DP]
     const int bh = blockIdx.x, b = bh / h, hh = bh % h;
     const uint32_t key = drop_key_dev(drop);
     const int64_t mo = (int64_t)bh * DP * DP;
     const float* src = dPt + (int64_t)b * d * (h * DP) + hh * DP;
-    for (int e = threadIdx.x; e < d * DP; e += blockDim.x) {
-        const int c = e / DP, j = e % DP;
-        sdp[j * dpitch + c] = src[(int64_t)c * (h * DP) + j];
+    for (int e = threadIdx.x; e < d * nj; e += blockDim.x) {
+        const int c = e / nj, j = e % nj;
+        sdr[j * dpitch + c] = src[(int64_t)c * (h * DP) + j0 + j];
     }
+    if (parts > 1)
+        for (int e = threadIdx.x; e < nc * DP; e += blockDim.x) {
+            const int c = e / DP, j = e % DP;
+            sdc[j * cpitch + c] = src[(int64_t)(c0 + c) * (h * DP) + j];
+        }
     for (int e = threadIdx.x; e < d * Dr; e += blockDim.x) {
         const int c = e / Dr, ee = e % Dr;
         sW[e] = Wfc[(int64_t)c * (h * Dr) + hh * Dr + ee];
     }
     for (int e = threadIdx.x; e < DP * DP; e += blockDim.x) sM[e] = Mt[mo + e];
     __syncthreads();
-    // gridDim.y blocks share the two output loops of one (batch, head) (each stages the operands: they are small and come
-    // out of L2); with one block per (batch, head) the kernel took 37 us at B h = 16 and 52 us at 512
-    const int part = blockIdx.y, parts = gridDim.y;
-    for (int e = part * blockDim.x + threadIdx.x; e < DP * DP; e += parts * blockDim.x) {
-        const int j = e / DP, ee = e % DP;
+    for (int e = threadIdx.x; e < nj * DP; e += blockDim.x) {
+        const int jl = e / DP, ee = e % DP, j = j0 + jl;
         float acc = 0.f;
         if (j < Dr && ee < Dr) {
-            const float* dp = sdp + j * dpitch;
+            const float* dp = sdr + jl * dpitch;
             for (int c = 0; c < d; ++c) acc = fmaf(dp[c], sW[c * Dr + ee], acc);
             float mul = inv_n;
-            if (mask) mul *= mask[mo + e];
-            else if (drop.thresh) mul *= drop_mul(drop, key, (uint32_t)(mo + e));
+            if (mask) mul *= mask[mo + j * DP + ee];
+            else if (drop.thresh) mul *= drop_mul(drop, key, (uint32_t)(mo + j * DP + ee));
             acc *= mul;
         }
-        dM[mo + e] = acc;
+        dM[mo + j * DP + ee] = acc;
     }
     float* dst = dWfc_slabs + (int64_t)b * d * (h * Dr) + hh * Dr;
-    for (int e = part * blockDim.x + threadIdx.x; e < d * Dr; e += parts * blockDim.x) {
-        const int c = e / Dr, ee = e % Dr;
+    for (int e = threadIdx.x; e < nc * Dr; e += blockDim.x) {
+        const int cl = e / Dr, ee = e % Dr;
         float acc = 0.f;
-        for (int j = 0; j < Dr; ++j) acc = fmaf(sdp[j * dpitch + c], sM[j * DP + ee], acc);
-        dst[(int64_t)c * (h * Dr) + ee] = acc;
+        for (int j = 0; j < Dr; ++j) acc = fmaf(sdc[j * cpitch + cl], sM[j * DP + ee], acc);
+        dst[(int64_t)(c0 + cl) * (h * Dr) + ee] = acc;
     }
 }
 
@@ -1667,9 +1681,12 @@ extern "C" int gt_galerkin_finalize_bwd(const float* dPt, const float* Mt, const
         n_tokens <= 0)
         return GT_EINVAL;
     if (drop && drop->p > 0.f && !drop->seed) return GT_EINVAL;
-    const size_t lds = ((size_t)DP * (d + 1) + (size_t)d * Dr + (size_t)DP * DP) * sizeof(float);
+    // parts: enough blocks to fill the chip (each part stages W_h and M in full, its slices of dP_h); wide models (d >= 160:
+    // the full staging would leave one block per CU) always take four
+    const int parts = std::max(d >= 160 ? 4 : 1, std::min(4, 1024 / (B * h)));
+    const size_t lds = ((size_t)((DP + parts - 1) / parts) * (d + 1) + (parts > 1 ? (size_t)DP * ((d + parts - 1) / parts + 1) : 0) +
+                        (size_t)d * Dr + (size_t)DP * DP) * sizeof(float);
     if (int rc = allow_big_lds(galerkin_fin_bwd_kernel, lds)) return rc;
-    const int parts = std::max(1, std::min(4, 1024 / (B * h)));      // enough blocks to fill the chip, no more (each part stages all operands)
     hipLaunchKernelGGL(galerkin_fin_bwd_kernel, dim3(B * h, parts), dim3(256), lds, (hipStream_t)stream, dPt, Mt,
                        mask, make_drop(mask ? nullptr : drop), Wfc, h, DP, Dr, d, 1.f / (float)n_tokens, dM,
                        dWfc_slabs);

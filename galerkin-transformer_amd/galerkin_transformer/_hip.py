@@ -500,6 +500,10 @@ class _WeightPacks:
         self.entries = {}          # key -> [desc copy, buffer or None, B (kept alive: its address is the key), last round seen]
         self.ready = set()
         self.round = 0
+        # buffers a captured HIP graph has baked in (raw pointers in its pack launch and its products): never freed while the
+        # process lives -- a graph replayed after its entries were evicted would read and write freed memory
+        self.pinned = set()
+        self._keep = []
 
     def use(self, d, B):
         """b_packed for this product if it was packed in the current bracket.  A product is packed ahead only once it has
@@ -522,13 +526,15 @@ class _WeightPacks:
         ent[3] = self.round
         if key in self.ready:
             d.b_packed = ent[1].data_ptr()
+            if torch.cuda.is_current_stream_capturing():
+                self.pinned.add(key)
 
     def refresh(self):
         self.ready = set()
         if not self.enabled:
             return
         # forget what the last bracket did not use (transient operands); pack what has a buffer
-        for k in [k for k, e in self.entries.items() if e[3] < self.round - 1]:
+        for k in [k for k, e in self.entries.items() if e[3] < self.round - 1 and k not in self.pinned]:
             del self.entries[k]
         self.round += 1
         items = [(k, e) for k, e in self.entries.items() if e[1] is not None]
@@ -548,6 +554,8 @@ class _WeightPacks:
         self.ready = set()
 
     def clear(self):
+        self._keep.extend(self.entries[k][1] for k in self.pinned if k in self.entries)    # (a captured graph may still replay)
+        self.pinned = set()
         self.entries.clear()
         self.ready = set()
 

@@ -153,6 +153,7 @@ class FlatClipAdam(torch.optim.Optimizer):
     def apply(self):
         """norm -> clip -> Adam on the flat buffers (capturable: no host read-back)."""
         H.need_f32_cuda(self.flat_param, self.flat_grad)
+        H.weight_packs.invalidate()              # the weights change below: packs made ahead of them are stale (ADVICE r5)
         g = self.param_groups[0]
         L = H.lib()
         st = H.stream_ptr()
