@@ -363,6 +363,7 @@ def timed_run(tr, steps, warmup, world, comm_rec=None):
 
 
 FOURIER_KEYS = ("gt_fourier16_attn", "gt_fourier_attn")
+PROFILE_ROUND = "r07"               # prefix of the profiles/ records this line quotes (the measurement pass of build round 6)
 
 
 def roofline_leg(trainer, precision, workload="ex2_darcy141"):
@@ -476,7 +477,10 @@ def roofline_leg(trainer, precision, workload="ex2_darcy141"):
                 traffic=traffic, traffic_source=tsrc, traffic_recorded_at=(_profiles_commit() if traffic else None),
                 traffic_ratio=(round(traffic / mean_bytes, 3) if traffic else None),
                 algorithmic_flops_per_launch=mean_flops, algorithmic_bytes_per_launch=mean_bytes,
-                launch_kinds=launch_kinds)
+                launch_kinds=launch_kinds,
+                # the launch kind with the fewest operands on its own (FFN1 forward: A, B, C -- no saved activation read
+                # back as a 1-bit-per-element ReLU decision): the fraction that does not credit that re-read as useful bytes
+                frac_leanest_kind=(round(launch_kinds[0]["hbm_gbs"] / PEAK_HBM_GBS, 4) if bound == "hbm" and launch_kinds else None))
     # legs the north star names: live per-launch HIP-event time of this step + the HBM bytes / matrix-pipe busy cycles
     # of the same kernel symbol from the rocprofv3 --pmc passes on file (profiles/pmc_step.json: FETCH_SIZE doubled
     # for gfx950, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES in separate passes -- tools/gpu_measure.sh, tools/pmc_to_json.py)
@@ -520,11 +524,20 @@ def leg_record(table, shape_rows, pmc, key, sym, pred):
     leg = dict(us=round(us, 1), launches=t["calls"], kernel=sym)
     if t["flops"] > 0:
         leg["useful_tflops"] = round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2)
+    # roofline fraction against the ALGORITHMIC bytes of the launches (what the operator has to move: operands + result, each
+    # once); the counter bytes of the same symbol (what it did move) and their ratio are carried separately -- a ratio well
+    # above 1 is re-read traffic, not bandwidth achieved
+    alg = t["bytes"] / t["calls"] if t.get("bytes", 0) > 0 else None
+    if alg:
+        leg.update(algorithmic_bytes_per_launch=int(alg), hbm_gbs_algorithmic=round(alg / us / 1e3, 1),
+                   hbm_frac=round(alg / us / 1e3 / PEAK_HBM_GBS, 4))
     c = pmc.get(sym)
     if c and "read_bytes" in c and "write_bytes" in c:
         by = c["read_bytes"] + c["write_bytes"]
-        leg.update(hbm_bytes_per_launch=int(by), hbm_gbs=round(by / us / 1e3, 1), hbm_frac=round(by / us / 1e3 / PEAK_HBM_GBS, 4),
-                   counter_launches_seen=c.get("calls_seen"))
+        leg.update(counter_bytes_per_launch=int(by), counter_gbs=round(by / us / 1e3, 1),
+                   counter_over_algorithmic=(round(by / alg, 3) if alg else None), counter_launches_seen=c.get("calls_seen"))
+        if not alg:
+            leg["hbm_frac"] = round(by / us / 1e3 / PEAK_HBM_GBS, 4)
         if "mfma_util_at_2.4GHz" in c:
             leg["mfma_busy_frac_profiled_pass"] = round(c["mfma_util_at_2.4GHz"], 3)
     return leg
@@ -687,12 +700,12 @@ def parity_record():
     the float64 one (same replayed decisions) is given next to it -- the down-scaler filters dominate both (float32
     interpolation coordinates, see the test's docstring) and are listed separately."""
     out = {}
-    for key, fn in (("trajectory_5_steps", "r06_parity_trajectory.json"),
-                    ("whole_model_replay", "r06_parity_whole_model_replay_relu.json"),
-                    ("whole_model_exact_math", "r06_parity_whole_model_off_silu.json"),
-                    ("full_size_C4_ex3_darcy_inv", "r06_parity_whole_model_full_ex3_darcy_inv.json"),
-                    ("full_size_C3_darcy211_fourier", "r06_parity_whole_model_full_ex2_darcy211_fourier.json"),
-                    ("full_size_C5_ns_rollout", "r06_parity_whole_model_full_ex4_ns.json")):
+    for key, fn in (("trajectory_5_steps", PROFILE_ROUND + "_parity_trajectory.json"),
+                    ("whole_model_replay", PROFILE_ROUND + "_parity_whole_model_replay_relu.json"),
+                    ("whole_model_exact_math", PROFILE_ROUND + "_parity_whole_model_off_silu.json"),
+                    ("full_size_C4_ex3_darcy_inv", PROFILE_ROUND + "_parity_whole_model_full_ex3_darcy_inv.json"),
+                    ("full_size_C3_darcy211_fourier", PROFILE_ROUND + "_parity_whole_model_full_ex2_darcy211_fourier.json"),
+                    ("full_size_C5_ns_rollout", PROFILE_ROUND + "_parity_whole_model_full_ex4_ns.json")):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 r = json.load(f)
@@ -703,7 +716,7 @@ def parity_record():
                                           "param_rel_l2_oracle_f32_vs_f64", "precision") if k in r}
         elif key.startswith("full_size"):
             out[key] = {k: r[k] for k in ("B", "prediction", "prediction_worst_step", "grad_max", "grad_max_oracle_f32",
-                                          "precision") if k in r}
+                                          "precision", "replay_audit") if k in r}
         else:
             e, n = r.get("hip_vs_f64", {}), r.get("oracle_f32_vs_f64", {})
             if e:
@@ -717,9 +730,9 @@ def parity_record():
                             "downscaler_filters_hip_vs_f64": {k.split(".")[2]: v for k, v in ds.items()},
                             "downscaler_filters_hip_vs_oracle_f32": {k.split(".")[2]: v for k, v in
                                                                      r.get("hip_vs_oracle_f32", {}).items() if k.startswith("downscaler.")},
-                            "precision": r.get("precision")}
-    out["source"] = ("profiles/r06_parity_*.json, written by tests/test_bench_kernels_gpu.py / test_fullsize_models_gpu.py on "
-                     "MI355X")
+                            "precision": r.get("precision"), "replay_audit": r.get("replay_audit")}
+    out["source"] = (f"profiles/{PROFILE_ROUND}_parity_*.json, written by tests/test_bench_kernels_gpu.py / "
+                     "test_fullsize_models_gpu.py on MI355X")
     out["recorded_at"] = _profiles_commit()
     return out if len(out) > 2 else None
 

@@ -286,7 +286,7 @@ def test_scaler_chain_eligibility_mirrors_the_segment_kernels_cpu():
     assert ok(128, (43, 43), B=2) and ok(128, (43, 43), B=1)     # round 5: the chain runs from 1 024 pixel rows (was 16 384: B <= 2 fell back)
 
 
-def _bench_record(tag="r06"):
+def _bench_record(tag="r07"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     paths = [os.path.join(root, "profiles", f) for f in (f"{tag}_bench.json", f"{tag}_bench_table.json", "pmc_step.json")]
     if not all(os.path.exists(q) for q in paths):
@@ -310,13 +310,13 @@ def test_roofline_legs_name_kernels_of_the_counter_passes_cpu():
         assert label in sym, label
         assert sym[label] in pmc, (label, sym[label])
         assert leg["kernel"] == sym[label]
-        assert "hbm_bytes_per_launch" in leg and leg["hbm_bytes_per_launch"] > 0, label
+        assert "counter_bytes_per_launch" in leg and leg["counter_bytes_per_launch"] > 0, label
     assert line["roofline"]["traffic"], "no counter record for the dominant kernel's launch geometry"
     assert line["roofline"]["kernel"] in pmc
 
 
 def test_roofline_legs_recompute_from_the_committed_records_cpu():
-    """every `hbm_gbs` of the committed bench line must be (counter bytes of ITS kernel
+    """every `counter_gbs` of the committed bench line must be (counter bytes of ITS kernel
     symbol) / (mean HIP-event time of the launches of THAT symbol) -- recomputed here from profiles/pmc_step.json and the
     per-shape event table written by the same bench run; a leg whose host entry launches several kernel instances must be
     split by shape (the three gt_conv3x3_wgrad_nhwc geometries), and all legs must have seen the same number of profiled steps."""
@@ -335,8 +335,11 @@ def test_roofline_legs_recompute_from_the_committed_records_cpu():
         assert got["launches"] == rec["launches"], label
         assert abs(got["us"] - rec["us"]) <= 0.06, (label, got["us"], rec["us"])
         by = pmc[sym]["read_bytes"] + pmc[sym]["write_bytes"]
-        assert abs(got["hbm_gbs"] - by / got["us"] / 1e3) <= 0.002 * got["hbm_gbs"] + 0.2, (label, got["hbm_gbs"], by / got["us"] / 1e3)
+        assert abs(got["counter_gbs"] - by / got["us"] / 1e3) <= 0.002 * got["counter_gbs"] + 0.2, (label, got["counter_gbs"], by / got["us"] / 1e3)
+        # round 6: the fraction is taken against the ALGORITHMIC bytes of the launches; the counter bytes ride beside it
         assert 0 < got["hbm_frac"] < 1.0, (label, got["hbm_frac"])
+        assert abs(got["hbm_frac"] - got["algorithmic_bytes_per_launch"] / got["us"] / 1e3 / bench.PEAK_HBM_GBS) < 2e-4, label
+        assert abs(got["counter_over_algorithmic"] - by / got["algorithmic_bytes_per_launch"]) < 2e-3 * got["counter_over_algorithmic"] + 1e-3
         ratios[label] = pmc[sym]["calls_seen"] / got["launches"]
     # the counter passes profiled the same number of steps for every kernel (launches per step x steps seen)
     assert len({round(v, 6) for v in ratios.values()}) == 1, ratios
