@@ -1898,7 +1898,7 @@ static int x3w_prefetch() {                          // GT_X3W_PF = 1: the singl
 bool x3w_ok(const gt_gemm_desc* d, int split) {
     static const int on = [] { const char* e = getenv("GT_X3W"); return e ? atoi(e) : 1; }();
     return on && d->precision == GT_PREC_F16X2 && d->layout_a == 1 && d->layout_b == 1 && split > 1 && d->K >= 16384 &&
-           (d->M & 31) == 0 && (d->N & 31) == 0 && d->M >= 96 && d->N >= 96 && d->batch0 * d->batch1 == 1 && d->K2 == 0 && d->cv_c == 0 &&
+           (d->M & 31) == 0 && (d->N & 31) == 0 && d->M >= 32 && d->N >= 32 && d->batch0 * d->batch1 == 1 && d->K2 == 0 && d->cv_c == 0 &&
            !(d->a_drop.p > 0.f) && ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B)) & 15) == 0 &&
            (d->lda & 3) == 0 && (d->ldb & 3) == 0;
 }
@@ -1925,6 +1925,11 @@ bool x3_shape_ok(const gt_gemm_desc* d) {
         (d->precision == GT_PREC_BF16X3 || d->precision == GT_PREC_F16X2) &&
         (d->K & 3) == 0 && d->layout_a == 0 && d->batch0 * d->batch1 == 1 && d->K2 == 0 && !d->a_colsum && d->split_k == 1 &&
         d->ep_mode == GT_EP_NORMAL && (d->lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d->A) & 15) == 0)
+        return true;
+    // ... and the token-contracted weight gradients of the narrow models (ex1: d_model 64, ffn 128): gemm_x3w_kernel takes
+    // partial 128-blocks since round 5, a lone 32 / 64-wide block is the same code path (they ran on the fp32 engine)
+    if (narrow && d->precision == GT_PREC_F16X2 && d->layout_a == 1 && d->layout_b == 1 && d->split_k == 0 && d->K >= 16384 &&
+        d->M >= 32 && d->N >= 32 && (d->M & 31) == 0 && (d->N & 31) == 0 && x3w_ok(d, 2))
         return true;
     return d->M >= 96 && d->N >= 96 && d->K >= 16;
 }

@@ -1993,7 +1993,8 @@ def test_packed_gemm_repeat_launch_bitwise(H, gpu_device, prec):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 256, 33282), (384, 128, 20000), (256, 128, 236672),
-                                   (192, 192, 40000), (576, 192, 33000), (192, 384, 20001), (160, 96, 17000)])   # round 5: partial tiles (ex3: d = 192)
+                                   (192, 192, 40000), (576, 192, 33000), (192, 384, 20001), (160, 96, 17000),    # round 5: partial tiles (ex3: d = 192)
+                                   (192, 64, 262144), (64, 128, 40000), (128, 64, 33000), (64, 64, 17000), (32, 96, 20000)])   # round 6: narrow models (ex1: d = 64)
 def test_gemm_f16x2_weight_gradient_kernel(H, gpu_device, M, N, K):
     """gemm_x3w_kernel (GT_PREC_F16X2 token-contracted weight gradient: a stage of 32 tokens split once into fp16 planes in LDS,
     one running exponent per operand and block with in-flight accumulator rescaling, split-K slabs + fixed-order reduce,
