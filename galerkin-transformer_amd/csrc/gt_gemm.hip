@@ -495,7 +495,7 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 static inline bool m4(int64_t v) { return (v & 3) == 0; }
 
 static bool has_epilogue(const gt_gemm_desc* d) {
-    return d->bias || d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res ||
+    return d->c_masked || d->bias || d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f || d->res ||
            d->out_scale != 1.f || d->ep_mode != GT_EP_NORMAL || d->K2 > 0;
 }
 
@@ -832,7 +832,14 @@ static int gemm_one(const gt_gemm_desc* d, int drop_ld, int n_off, void* ws, int
         p.drop_ld = drop_ld; p.n_off = n_off;
         p.res = d->res; p.ldr = d->ldr; p.r_bs0 = d->r_bs0; p.r_bs1 = d->r_bs1;
         p.out_scale = d->out_scale;
+        if (d->c_masked) {
+            if (batch != 1 || d->ep_mode != GT_EP_NORMAL || d->K2 > 0) return GT_ENOTSUP;
+            if (d->c_mask.p < 0.f || d->c_mask.p >= 1.f || (d->c_mask.p > 0.f && !d->c_mask.seed)) return GT_EINVAL;
+            p.c2 = d->c_masked; p.ldc2 = d->ldc_masked; p.drop2 = make_drop(&d->c_mask);
+            p.c_vec = p.c_vec && al16(d->c_masked) && m4(d->ldc_masked);
+        }
     }
+    if (d->c_masked && pl.split > 1) return GT_ENOTSUP;
 
     dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.split, (unsigned)batch);
     const int lay = d->layout_a * 2 + d->layout_b;
@@ -931,6 +938,7 @@ static bool width_split(const gt_gemm_desc* d, gt_gemm_desc* a, gt_gemm_desc* b)
     if (d->pre) b->pre = d->pre + n_main;
     if (d->aux) b->aux = d->aux + n_main;
     if (d->res) b->res = d->res + n_main;
+    if (d->c_masked) b->c_masked = d->c_masked + n_main;
     if (pl.split == 1) a->split_k = b->split_k = 1;      // else: each part plans its own K slices (split_k as given)
     b->a_colsum = nullptr;                               // the row sums of A ride on the first launch only
     return true;

@@ -30,6 +30,7 @@ struct GemmP {
     // GT_EP_HEADNORM (split-operand ring kernel): head-norm forward fused behind the QKV projection
     const float* hn_gamma; const float* hn_beta; const float* hn_pos; float* hn_out; float* hn_stats;
     int hn_h, hn_dk, hn_p, hn_DP, hn_mask, hn_skip_raw, hn_plain; float hn_eps;
+    float* c2; int64_t ldc2; DropDev drop2;   // gt_gemm_desc.c_masked: the result once more under a second dropout mask
     int hn_dkr;              // real head width: == hn_dk, or 48 inside hn_dk = 64-column head SLOTS (gt_gemm.hip: hn_slots)
     int cv_H, cv_W, cv_C, cv_wgrad;  // implicit 3x3 convolution (gt_hip.h: cv_*), cv_C = 0: plain GEMM
     const void* Bp; int bp_NT, bp_KS, bp_f16; // packed-B kernel (gt_gemm_x3.hip): bf16 (fp16: bp_f16) planes of B in fragment order
@@ -257,6 +258,14 @@ __device__ __forceinline__ void ep_row(const GemmP& p, float (&v)[NT], const flo
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (nb + t < p.N) cp[t] = v[t];
+    }
+    if (p.c2) {                                // the same values under the second mask (gt_gemm_desc.c_masked)
+        const uint32_t key2 = drop_key_dev(p.drop2);
+        const uint32_t di = (uint32_t)(((int64_t)z * p.M + m) * p.drop_ld + p.n_off + nb);
+        float* c2 = p.c2 + (int64_t)m * p.ldc2 + nb;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (nb + t < p.N) c2[t] = v[t] * (p.drop2.thresh ? drop_mul(p.drop2, key2, di + t) : 1.f);
     }
 }
 

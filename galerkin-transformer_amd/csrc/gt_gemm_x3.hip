@@ -332,6 +332,19 @@ __device__ __forceinline__ void x3_epilogue_fast(const GemmP& p, const f32x16 (&
         if (b + 1 < NB) loads(b + 1);          // rs / ax are consumed: the next batch's loads go out in front of the stores
 #pragma unroll
         for (int k = 0; k < HB; ++k) *reinterpret_cast<f32x4*>(C + (int64_t)(m0b + 4 * k) * p.ldc + nb) = v[k];
+        if (p.c2) {                            // gt_gemm_desc.c_masked: the same rows under the second mask
+            const uint32_t key2 = drop_key_dev(p.drop2);
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const uint32_t di = (uint32_t)(((int64_t)z * p.M + m0b + 4 * k) * p.drop_ld + p.n_off + nb);
+                f32x4 w = v[k];
+                if (p.drop2.thresh) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) w[t] *= drop_mul(p.drop2, key2, di + t);
+                }
+                *reinterpret_cast<f32x4*>(p.c2 + (int64_t)(m0b + 4 * k) * p.ldc2 + nb) = w;
+            }
+        }
     }
 }
 

@@ -164,7 +164,7 @@ bool tsmm_eligible(const gt_gemm_desc* d) {
     if (d->layout_a != 1 || d->layout_b != 1 || d->batch0 * d->batch1 != 1 || d->split_k != 0) return false;
     if (d->K < 65536 || d->M % 32 || d->M > 128 || d->N > 32 || (d->N & 1)) return false;
     if (d->a_drop.p > 0.f || d->bias || d->rp || d->add || d->pre || d->act || d->aux_op || d->drop.p > 0.f ||
-        d->res || d->out_scale != 1.f || d->ep_mode != GT_EP_NORMAL || d->K2 > 0)
+        d->res || d->out_scale != 1.f || d->ep_mode != GT_EP_NORMAL || d->K2 > 0 || d->c_masked)
         return false;
     if ((d->lda & 1) || (d->ldb & 1) || d->ldc < d->N) return false;
     if ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B)) & 7) return false;

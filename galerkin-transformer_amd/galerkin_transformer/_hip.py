@@ -68,6 +68,7 @@ class GtGemmDesc(C.Structure):
         ("cv_h", C.c_int32), ("cv_w", C.c_int32), ("cv_c", C.c_int32), ("cv_wgrad", C.c_int32),
         ("hn_skip_raw_mask", C.c_int32), ("hn_plain", C.c_int32),
         ("b_packed", C.c_void_p),
+        ("c_masked", C.c_void_p), ("ldc_masked", C.c_int64), ("c_mask", GtDropout),
     ]
 
 
@@ -583,7 +584,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          K2: int = 0, A2: Optional[torch.Tensor] = None, lda2: int = 0, a2_bs=(0, 0),
          B2: Optional[torch.Tensor] = None, ldb2: int = 0, b2_bs=(0, 0), hn: Optional[dict] = None,
          precision: Optional[str] = None, conv: Optional[Tuple[int, int, int]] = None, conv_wgrad: bool = False,
-         weight_b: bool = False):
+         weight_b: bool = False, c_masked: Optional[torch.Tensor] = None, ldc_masked: int = 0,
+         c_mask: Optional[GtDropout] = None):
     """Thin wrapper over gt_gemm (see include/gt_hip.h for the semantics).  weight_b: B is a model weight at a stable address
     (eligible for the once-per-step pack, weight_packs).  precision=None uses the module mode
     (set_precision).  conv=(H, W, C): A is a channels-last [B, H, W, C] image and the product is the implicit 3x3
@@ -647,6 +649,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if conv is not None:
         d.cv_h, d.cv_w, d.cv_c = conv
         d.cv_wgrad = int(conv_wgrad)
+    if c_masked is not None:    # the result once more under a second dropout mask (gt_hip.h: c_masked)
+        need_f32_cuda(c_masked)
+        d.c_masked, d.ldc_masked = c_masked.data_ptr(), ldc_masked
+        if c_mask is not None and c_mask.p > 0:
+            d.c_mask = c_mask
     if weight_b:
         weight_packs.use(d, B)
     need = L.gt_gemm_ws_bytes(C.byref(d))
@@ -668,7 +675,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         flops = 2.0 * M * N * (K + K2) * nb
         if conv_wgrad:
             nb = 1.0 + 8.0 * (M * N) / (M * K + K * N + M * N)     # both operands are read once for the nine taps
-        nbytes = 4.0 * nb * (M * (conv[2] if conv and not conv_wgrad else K) + K * N + M * N * (1 + (res is not None) + (aux is not None) +
+        nbytes = 4.0 * nb * (M * (conv[2] if conv and not conv_wgrad else K) + K * N + M * N * (1 + (res is not None) + (aux is not None) + (c_masked is not None) +
                                                       (add is not None) + (pre is not None)))
         keep = (A, B, Cout, bias, rp_a, rp_b, add, pre, aux, res, d)
         st = stream_ptr()

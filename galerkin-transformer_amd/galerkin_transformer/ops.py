@@ -63,6 +63,52 @@ def set_scaler_mask_sink(sink):
     _scaler_mask_sink[0] = sink
 
 
+# ----------------------------------------------------------------------------------- masked twins of data gradients
+# A block of the encoder layer ends in  out = res + dropout(y)  (model.py:125, 132); its backward needs the incoming gradient
+# twice: as it is (residual branch) and under that dropout's mask (three contractions).  The masked copy used to be one
+# elementwise gt_dropout_apply pass per block and backward (12 per step at six layers).  Now the block that CONSUMES `out`
+# produces it: its forward finds the mask parameters of its input registered here (keyed by the tensor's address), and the
+# product of its backward that writes d(out) writes the masked copy too (gt_gemm_desc.c_masked).  Everything is advisory: a
+# consumer that finds no twin for exactly its (tensor address, p, salt) -- another op in between, a gradient autograd
+# accumulated from two consumers, a hook that replaced it -- runs the elementwise pass as before.
+_fold_masks = [os.environ.get("GT_FOLD_MASKS", "1") != "0"]
+_mask_hints = {}                # out.data_ptr() -> (p, salt, numel): "the gradient w.r.t. this tensor is wanted under this mask too"
+_masked_twins = {}              # dx.data_ptr()  -> (masked copy, p, salt)
+
+
+_fold_seq = [0]                 # forward blocks that use this registry, in call order
+
+
+def _hint_output_mask(out, p: float, salt: int):
+    """Called at the END of a block's forward.  A hint is only honoured by the very next block's forward (an address that
+    the allocator hands out again later must not resurrect it), and any forward activity drops leftover twins of an earlier
+    backward."""
+    _masked_twins.clear()
+    _mask_hints.clear()
+    if _fold_masks[0] and p > 0:
+        _mask_hints[out.data_ptr()] = (float(p), int(salt), out.numel(), _fold_seq[0])
+
+
+def _wanted_mask(x):
+    """Called at the START of a block's forward: (p, salt) under which the producer of x wants d(x) once more, or None."""
+    _fold_seq[0] += 1
+    e = _mask_hints.pop(x.data_ptr(), None) if _fold_masks[0] else None
+    return (e[0], e[1]) if e is not None and e[2] == x.numel() and e[3] == _fold_seq[0] - 1 else None
+
+
+def _offer_twin(dx, dxm, p: float, salt: int):
+    if len(_masked_twins) > 64:
+        _masked_twins.clear()
+    _masked_twins[dx.data_ptr()] = (dxm, float(p), int(salt))
+
+
+def _take_twin(g, p: float, salt: int):
+    e = _masked_twins.pop(g.data_ptr(), None) if _fold_masks[0] else None
+    if e is not None and e[1] == float(p) and e[2] == int(salt) and e[0].numel() == g.numel() and e[0].device == g.device:
+        return e[0].view(g.shape)
+    return None
+
+
 _qkvnorm_fused = [True]         # QKV projection + head norm in one launch when the library supports the shape
 _next_salt = H.next_salt        # call-site salt counter (rewound by _hip.set_seed / utils.get_seed)
 
@@ -866,6 +912,8 @@ class FeedForwardFn(Function):
         ctx.save_for_backward(xc, w1c, w2c, hid, pre)
         ctx.cfg = (act, p_h, p_out, salt, d, f, dout, b1 is not None, b2 is not None, res is not None,
                    x.shape)
+        ctx.in_mask = _wanted_mask(xc)            # the producer of x wants d(x) under its own output mask too
+        _hint_output_mask(out, p_out, salt + 1)
         return out.reshape(*x.shape[:-1], dout)
 
     @staticmethod
@@ -877,7 +925,11 @@ class FeedForwardFn(Function):
         g = _c(gy).reshape(T, dout)
         # the masked gradient g*mask_out feeds three contractions: one elementwise pass is cheaper than
         # regenerating the mask in each GEMM's operand loader (measured: 257 -> 135 us on the gh GEMM at B=64)
-        gm = H.dropout_apply(g, H.dropout_desc(p_out, salt + 1, dev)) if p_out > 0 else g
+        gm = g
+        if p_out > 0:           # the masked copy the consumer of our output wrote next to d(out), else the elementwise pass
+            gm = _take_twin(g, p_out, salt + 1)
+            if gm is None:
+                gm = H.dropout_apply(g, H.dropout_desc(p_out, salt + 1, dev))
         # gh = (gm W2) * mask_h * act'(pre)
         gh = torch.empty(T, f, dtype=torch.float32, device=dev)
         # bias gradients ride on the weight-gradient GEMMs (row sums of their A operand); the weight gradients run on
@@ -900,7 +952,13 @@ class FeedForwardFn(Function):
         with H.side_branch(dev, T):
             H.gemm(gh, xc, dw1, f, d, T, layout_a=1, layout_b=1, lda=f, ldb=d, ldc=d, split_k=0, a_colsum=db1)
         same = has_res and dout == d
-        H.gemm(gh, w1c, dx, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=g if same else None, ldr=d, weight_b=True)
+        dxm, want = None, ctx.in_mask
+        if want is not None:
+            dxm = torch.empty_like(dx)
+        H.gemm(gh, w1c, dx, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=g if same else None, ldr=d, weight_b=True,
+               c_masked=dxm, ldc_masked=d, c_mask=H.dropout_desc(want[0], want[1], dev) if want else None)
+        if dxm is not None:
+            _offer_twin(dx, dxm, *want)
         H.join_side(dev)
         dx = dx.reshape(xshape)
         # the residual input is x itself: its gradient g is already folded into dx (res epilogue above), so the
@@ -1021,6 +1079,8 @@ class SimpleAttentionFn(Function):
             ctx.save_for_backward(xc, wq, gamma, wpad, qkv, stats, out3, S, att, mask)
             attn_w = S if S is not None else torch.empty(0, device=dev)
         ctx.cfg = cfg
+        ctx.in_mask = _wanted_mask(xc)
+        _hint_output_mask(out, p_out, salt + 1)
         ctx.dims = (B, n, d, h, dk, p, Dr, DP, salt, bqkv is not None, bfc is not None, res is not None,
                     x.shape)
         attn_w = attn_w.detach()
@@ -1036,7 +1096,8 @@ class SimpleAttentionFn(Function):
         g = _c(gy).reshape(T, d)
         g_in = g                                             # unmasked: what flows to the residual branch
         if p_out > 0:                                        # mask once, not in every consumer's operand loader
-            g = H.dropout_apply(g, H.dropout_desc(p_out, salt + 1, dev))
+            gmk = _take_twin(g, p_out, salt + 1)             # ... and not at all when the consumer of `out` wrote the copy
+            g = gmk if gmk is not None else H.dropout_apply(g, H.dropout_desc(p_out, salt + 1, dev))
         d_out = None
         fused_ln = False
         dO3 = None
@@ -1136,8 +1197,14 @@ class SimpleAttentionFn(Function):
         with H.side_branch(dev, T):     # weight gradient next to the data gradient
             H.gemm(dqkv, xc, dwqkv, 3 * d, d, T, layout_a=1, layout_b=1, lda=3 * d, ldb=d, ldc=d, split_k=0,
                    a_colsum=dbqkv)
+        dxm, want = None, ctx.in_mask
+        if want is not None:
+            dxm = torch.empty_like(dx)
         H.gemm(dqkv, wq, dx, T, d, 3 * d, layout_b=1, lda=3 * d, ldb=d, ldc=d, res=g_in if has_res else None,
-               ldr=d, weight_b=True)
+               ldr=d, weight_b=True, c_masked=dxm, ldc_masked=d,
+               c_mask=H.dropout_desc(want[0], want[1], dev) if want else None)
+        if dxm is not None:
+            _offer_twin(dx, dxm, *want)
         H.join_side(dev)
         dres = None                                          # folded into dx (res is x): contributes nothing
         if not norm_mask:

@@ -226,6 +226,15 @@ typedef struct gt_gemm_desc {
      * layout_b, ldb, N, K, precision = GT_PREC_F16X2) since B last changed -- gt_gemm then skips its own pack launch and
      * needs no workspace.  Only where gt_gemm_packed_b_bytes(d) > 0. */
     const void* b_packed;
+
+    /* Second output (ABI v20, round 6): c_masked[m][n] = C[m][n] * keepscale_{c_mask}(m, n)  -- the finished result once more
+     * under a stateless dropout mask (index (z*M + m)*N + n, the index gt_dropout_apply uses on the dense [M, N] tensor), row
+     * pitch ldc_masked.  The data gradient a layer hands to the layer in front of it is needed twice there: as it is (residual
+     * branch) and under that layer's output-dropout mask (nn.Dropout of model.py:125,132 backwards: it feeds three
+     * contractions) -- the product that computes it writes both and the elementwise gt_dropout_apply pass between two layers'
+     * backward passes disappears.  No batching, no split-K, GT_EP_NORMAL only; NULL = off. */
+    float* c_masked; int64_t ldc_masked;
+    gt_dropout c_mask;
 } gt_gemm_desc;
 
 #define GT_PREC_F32    0

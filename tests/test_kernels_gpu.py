@@ -1345,6 +1345,31 @@ def test_narrow_token_products_on_the_packed_kernels(H, gpu_device, N, K, lb):
         assert rel_l2(outs[prec], ref) < KTOL, (prec, rel_l2(outs[prec], ref))
 
 
+@pytest.mark.parametrize("M,N,K,prec", [(20000, 128, 256, "f16x2"), (20000, 192, 384, "f16x2"), (20000, 64, 128, "f16x2"),
+                                        (3000, 128, 256, "f16x2"), (777, 96, 130, "f32"), (20000, 128, 256, "bf16x3")])
+def test_gemm_second_output_under_a_dropout_mask(H, gpu_device, M, N, K, prec):
+    """gt_gemm_desc.c_masked (round 6): the finished result once more under a second stateless dropout mask, bit for bit what
+    gt_dropout_apply makes of C -- on the packed-B fast epilogue, its width-split / narrow-tile forms, the ring kernel and the
+    fp32 engine's per-row epilogue.  (The data gradient between two encoder blocks, reference model.py:125,132 backwards.)"""
+    dev = gpu_device
+    A, W = rnd(M, K, dev=dev, seed=320), rnd(N, K, dev=dev, seed=321, scale=0.1)
+    R = rnd(M, N, dev=dev, seed=322)
+    Cc = torch.full((M, N), float("nan"), device=dev)
+    Cm = torch.full((M, N), float("nan"), device=dev)
+    dm = H.dropout_desc(0.05, 4242, dev)
+    H.gemm(A, W, Cc, M, N, K, lda=K, ldb=K, ldc=N, res=R, ldr=N, precision=prec, c_masked=Cm, ldc_masked=N, c_mask=dm)
+    plain = torch.full((M, N), float("nan"), device=dev)
+    H.gemm(A, W, plain, M, N, K, lda=K, ldb=K, ldc=N, res=R, ldr=N, precision=prec)
+    torch.cuda.synchronize()
+    assert torch.equal(Cc, plain)
+    assert torch.equal(Cm, H.dropout_apply(Cc, dm))
+    assert 0.03 < float((Cm == 0).float().mean()) < 0.07
+    # split-K products have no second output
+    with pytest.raises(NotImplementedError):
+        H.gemm(A, R, torch.empty(K, N, device=dev), K, N, M, layout_a=1, layout_b=1, lda=K, ldb=N, ldc=N, split_k=4,
+               c_masked=torch.empty(K, N, device=dev), ldc_masked=N, c_mask=dm)
+
+
 def test_width_split_product_takes_a_weight_packed_ahead(H, gpu_device):
     """N = 192 (ex3's d_model) is cut into a 128-column launch and a 64-column remainder; round 6: both run on the packed-B
     kernels and gt_gemm_packed_b_bytes / gt_gemm_pack_b_many / gt_gemm_desc.b_packed describe the two packs back to back --

@@ -212,6 +212,45 @@ def test_no_library_convolution_in_the_training_step(gpu_device, workload, B, li
     assert bool(spy.seen) == library_convs, (workload, spy.seen)
 
 
+@pytest.mark.parametrize("workload,B", [("ex2_darcy141", 10), ("ex3_darcy_inv", 14), ("ex4_ns", 5)])
+def test_masked_gradient_twins_change_nothing_but_the_launch_count(gpu_device, workload, B):
+    """Round 6 (the elementwise folds): the dropout-masked copy of the data gradient between two encoder
+    blocks (nn.Dropout of reference model.py:125,132 backwards) is written by the product that computes the gradient
+    (gt_gemm_desc.c_masked, ops._masked_twins) instead of by one gt_dropout_apply pass per block.  Same seed => bit-identical
+    parameter gradients with the fold on and off; with it the step launches fewer gt_dropout_apply (ex4's LayerNorm layers sit
+    between the blocks: nothing to fold there, and nothing may change)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip, ops
+    grads, drops = [], []
+    old = ops._fold_masks[0]
+    try:
+        for fold in (False, True):
+            ops._fold_masks[0] = fold
+            torch.manual_seed(11)
+            model, _ = bench.build_model(workload)
+            model = model.to(gpu_device).train()
+            gt.set_attention_dropout("reference")
+            batch = bench.synthetic_batch(B, gpu_device, seed=7, workload=workload)
+            tr = bench.Trainer(model, batch, 1, use_graph=False, workload=workload)
+            _hip.set_seed(123, gpu_device)
+            for p in tr.params:
+                p.grad = None
+            with _hip.Profile() as prof:
+                tr.fwd_bwd()
+            torch.cuda.synchronize()
+            grads.append(tr.opt.flat_grad.clone())
+            drops.append(prof.table().get("gt_dropout_apply", {}).get("calls", 0))
+    finally:
+        ops._fold_masks[0] = old
+    assert torch.equal(grads[0], grads[1])
+    L = 6 if workload != "ex4_ns" else 0
+    assert drops[0] - drops[1] == (2 * L - 1 if L else 0), drops       # every block but the LAST one (its gradient comes from the up-scaler)
+
+
 def test_graph_step_equals_eager_step(gpu_device):
     """Same seed => the captured training step (fwd+bwd+clip+Adam, all dropouts on) updates the
     parameters exactly like the eager step."""
