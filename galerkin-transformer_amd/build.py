@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 OUT_DIR = os.path.join(HERE, "galerkin_transformer", "_lib")
-SOURCES = ["gt_gemm.hip", "gt_gemm_x3.hip", "gt_ops.hip", "gt_resize.hip", "gt_fourier.hip", "gt_fourier16.hip", "gt_dft.hip", "gt_tsmm.hip", "gt_head.hip", "gt_optim.hip", "gt_convw.hip"]
+SOURCES = ["gt_gemm.hip", "gt_gemm_x3.hip", "gt_ops.hip", "gt_resize.hip", "gt_fourier.hip", "gt_fourier16.hip", "gt_dft.hip", "gt_tsmm.hip", "gt_head.hip", "gt_optim.hip", "gt_convw.hip", "gt_ffn.hip"]
 HEADERS = [os.path.join(CSRC, "gt_common.h"), os.path.join(CSRC, "gt_gemm_core.h"), os.path.join(INC, "gt_hip.h")]
 ARCH = "gfx950"
 

@@ -161,6 +161,9 @@ _PROTOS = {
     "gt_bilinear2d_seg_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 9 + [C.c_void_p, C.c_void_p]),
     "gt_bilinear2d_seg_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p, C.c_int32, C.c_void_p]),
     "gt_bilinear2d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
+    "gt_ffn_fwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "gt_ffn_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 +
+                   [C.POINTER(GtDropout), C.POINTER(GtDropout), C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
     "gt_grad_sqnorm_ws_bytes": (C.c_int64, []),
     "gt_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gt_adam_clip_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_void_p] +
@@ -682,6 +685,48 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         call = lambda: L.gt_gemm(C.byref(d), wsp, wsn, st)
         check(_timed(key, flops, nbytes, call, replay=(call, keep), shape=(M, N, K, nb)), "gt_gemm")
     return Cout
+
+
+_ffn_fused = [os.environ.get("GT_FFN_FUSED", "1") != "0"]
+
+
+def ffn_fwd_supported(T: int, d: int, f: int, act: int) -> bool:
+    """Shapes of the fused FeedForward forward (gt_ffn_fwd): the two-term fp16 arithmetic only."""
+    return (_ffn_fused[0] and _precision[0] == PREC_F16X2 and not _prec_class and d == 128 and f == 256 and T >= 16384
+            and act in (ACT_RELU, ACT_NONE))
+
+
+def ffn_fwd(x2: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, res, drop_h, drop_o, act: int,
+            hid: torch.Tensor, out: torch.Tensor):
+    """hid = drop_h(act(x2 W1^T + b1)), out = res + drop_o(hid W2^T + b2) in one launch (gt_hip.h: gt_ffn_fwd).  The packed
+    weights come from the once-per-step pack when the two products are registered there (weight_packs), else the call packs."""
+    need_f32_cuda(x2, w1, b1, w2, b2, res, hid, out)
+    L = lib()
+    T, d = x2.shape
+    f = w1.shape[0]
+    packs = []
+    for (Bw, N, K) in ((w1, f, d), (w2, d, f)):         # the descriptors H.gemm would build for the two products
+        dsc = GtGemmDesc()
+        L.gt_gemm_desc_init(C.byref(dsc))
+        dsc.M, dsc.N, dsc.K, dsc.lda, dsc.ldb, dsc.ldc = T, N, K, K, K, N
+        dsc.A, dsc.B, dsc.C = x2.data_ptr(), Bw.data_ptr(), out.data_ptr()
+        dsc.precision = PREC_F16X2
+        weight_packs.use(dsc, Bw)
+        packs.append(dsc.b_packed)
+    both = packs[0] and packs[1]
+    wsp, wsn = None, 0
+    if not both:
+        need = L.gt_ffn_fwd_ws_bytes(T, d, f)
+        ws = workspace(x2.device, need)
+        wsp, wsn = ws.data_ptr(), ws.numel()
+    dh = C.byref(drop_h) if (drop_h is not None and drop_h.p > 0) else None
+    do = C.byref(drop_o) if (drop_o is not None and drop_o.p > 0) else None
+    st = stream_ptr()
+    call = lambda: L.gt_ffn_fwd(x2.data_ptr(), T, d, f, w1.data_ptr(), ptr(b1), w2.data_ptr(), ptr(b2), ptr(res), dh, do, act,
+                                hid.data_ptr(), out.data_ptr(), packs[0] if both else None, packs[1] if both else None,
+                                wsp, wsn, st)
+    nbytes = 4.0 * T * (d + f + d + (d if res is not None else 0))
+    check(_timed("gt_ffn_fwd", 4.0 * T * d * f, nbytes, call, shape=(T, d, f)), "gt_ffn_fwd")
 
 
 def gemm_kernel_name(A, B, M, N, K, *, layout_a=0, layout_b=0, lda, ldb, ldc, split_k=1, precision=None) -> str:

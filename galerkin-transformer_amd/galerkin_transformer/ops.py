@@ -901,14 +901,19 @@ class FeedForwardFn(Function):
         salt = _next_salt()
         hid = torch.empty(T, f, dtype=torch.float32, device=dev)
         pre = torch.empty(T, f, dtype=torch.float32, device=dev) if act == H.ACT_SILU else None
-        H.gemm(xc, w1c, hid, T, f, d, lda=d, ldb=d, ldc=f, bias=b1, act=act, pre=pre, ldpre=f,
-               drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None, weight_b=True)
-        if _relu_mask_sink[0] is not None and act == H.ACT_RELU and p_h == 0:
-            _relu_mask_sink[0].append(hid > 0)
         out = torch.empty(T, dout, dtype=torch.float32, device=dev)
         rc = None if res is None else _c(res).reshape(T, dout)
-        H.gemm(hid, w2c, out, T, dout, f, lda=f, ldb=f, ldc=dout, bias=b2,
-               drop=H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None, res=rc, ldr=dout, weight_b=True)
+        d_h = H.dropout_desc(p_h, salt, dev) if p_h > 0 else None
+        d_o = H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None
+        if dout == d and H.ffn_fwd_supported(T, d, f, act):
+            # both products in ONE launch, the hidden tile of 64 token rows kept in LDS between them (gt_ffn.hip): hid is
+            # written for the backward and never read back here; the bits of the two launches below
+            H.ffn_fwd(xc, w1c, b1, w2c, b2, rc, d_h, d_o, act, hid, out)
+        else:
+            H.gemm(xc, w1c, hid, T, f, d, lda=d, ldb=d, ldc=f, bias=b1, act=act, pre=pre, ldpre=f, drop=d_h, weight_b=True)
+            H.gemm(hid, w2c, out, T, dout, f, lda=f, ldb=f, ldc=dout, bias=b2, drop=d_o, res=rc, ldr=dout, weight_b=True)
+        if _relu_mask_sink[0] is not None and act == H.ACT_RELU and p_h == 0:
+            _relu_mask_sink[0].append(hid > 0)
         ctx.save_for_backward(xc, w1c, w2c, hid, pre)
         ctx.cfg = (act, p_h, p_out, salt, d, f, dout, b1 is not None, b2 is not None, res is not None,
                    x.shape)

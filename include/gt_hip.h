@@ -262,6 +262,24 @@ int     gt_gemm_plan(const gt_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* s
 int     gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused FeedForward forward (ABI v20, round 6; layers.py:979-987 with the residual of model.py:131-132) in GT_PREC_F16X2:
+ *     hid[t][:] = dropout_h( act( x[t] W1^T + b1 ) )             [T, f]  written to HBM (the backward reads it)
+ *     out[t][:] = res[t] + dropout_o( hid[t] W2^T + b2 )         [T, d]  (res may be NULL)
+ * in ONE launch: a block owns 64 token rows and keeps their hidden tile in LDS between the two contractions, so the hidden
+ * activation is never read back in the forward.  Value for value the arithmetic of the two gt_gemm launches it replaces
+ * (same packed planes, same running exponents, same product order, same dropout indices t*f + j / t*d + c): bit-identical
+ * results.  x [T, d], W1 [f, d], W2 [d, f] dense fp32, 16-byte aligned; act = GT_ACT_RELU | GT_ACT_NONE.
+ * w1_packed / w2_packed: both NULL (the call packs the weights into ws, gt_ffn_fwd_ws_bytes) or the buffers
+ * gt_gemm_pack_b_many filled for the products [T, d] x W1^T and [T, f] x W2^T (gt_gemm_desc.b_packed of those).
+ * Implemented for d = 128, f = 256, T >= 16384 (else GT_ENOTSUP: two gt_gemm launches do the same).
+ * ------------------------------------------------------------------------------------------- */
+int64_t gt_ffn_fwd_ws_bytes(int64_t T, int32_t d, int32_t f);
+int gt_ffn_fwd(const float* x, int64_t T, int32_t d, int32_t f, const float* W1, const float* b1, const float* W2,
+               const float* b2, const float* res, const gt_dropout* drop_h, const gt_dropout* drop_o, int32_t act,
+               float* hid, float* out, const void* w1_packed, const void* w2_packed, void* ws, int64_t ws_bytes,
+               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * out[n] (+)= sum_m A[m*lda + n] * keepA(m,n)  -- bias gradients.  Two deterministic passes.
  * ------------------------------------------------------------------------------------------- */
 int gt_colsum(const float* A, int64_t lda, int32_t M, int32_t N, const gt_dropout* a_drop,
