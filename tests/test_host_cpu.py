@@ -338,7 +338,7 @@ def test_roofline_legs_recompute_from_the_committed_records_cpu():
         assert abs(got["counter_gbs"] - by / got["us"] / 1e3) <= 0.002 * got["counter_gbs"] + 0.2, (label, got["counter_gbs"], by / got["us"] / 1e3)
         # round 6: the fraction is taken against the ALGORITHMIC bytes of the launches; the counter bytes ride beside it
         assert 0 < got["hbm_frac"] < 1.0, (label, got["hbm_frac"])
-        assert abs(got["hbm_frac"] - got["algorithmic_bytes_per_launch"] / got["us"] / 1e3 / bench.PEAK_HBM_GBS) < 2e-4, label
+        assert abs(got["hbm_frac"] - got["algorithmic_bytes_per_launch"] / got["us"] / 1e3 / bench.PEAK_HBM_GBS) < 2e-3 * got["hbm_frac"] + 2e-4, label   # (`us` is rounded to 0.1)
         assert abs(got["counter_over_algorithmic"] - by / got["algorithmic_bytes_per_launch"]) < 2e-3 * got["counter_over_algorithmic"] + 1e-3
         ratios[label] = pmc[sym]["calls_seen"] / got["launches"]
     # the counter passes profiled the same number of steps for every kernel (launches per step x steps seen)
