@@ -25,6 +25,7 @@
 //            wave-private transposing tile (aliasing the dead H image): + b2, dropout, + residual, 256-byte row segments.
 // LDS: 65 792 B (x tile / H image / out staging, one after the other) -> two blocks per CU.
 #include <cstdint>
+#include <cstdlib>
 #include <algorithm>
 
 #include "gt_common.h"
@@ -127,6 +128,16 @@ __device__ __forceinline__ void ffn_unscale(f32x16& a, int ea, int eb, float sgn
     asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier"                                                                \
                  : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1])::"memory")
 
+// PS (pre-split, the default): epilogue 1 splits the hidden tile ONCE into two fp16 planes in LDS under one power-of-two
+// exponent per token row (taken over all f columns: the four waves' column-chunk maxima meet in a 1-KB table), phase 2 reads
+// finished MFMA fragments and has no operand split left -- in the !PS form every wave re-splits the whole tile for its 32
+// output columns (1 280 of the ~4 100 VALU instructions of a lane; the launch is issue-bound).  The fp32 values stay in the
+// phase-1 accumulator registers and go to HBM after phase 2 through a wave-private transposing tile.  !PS returns the bits
+// of the two gt_gemm launches (running exponent per row and stage, as gemm_x3h); PS the same products under a different
+// (never smaller) scale: fp32-class against fp64 like every other launch of the arithmetic, not bit-identical.
+constexpr int FFN_HST_SW = 68;                                 // PS: row pitch (floats) of a wave's 64 x 64 hidden staging tile
+constexpr int FFN_PS_TAB = 4 * 64 * FFN_HST_SW * 4;            // PS: byte offset of the [4][64] chunk-amax table
+template <bool PS>
 __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const himg = smem;                                   // x tile (8 stages) in phase 1, then the H image: 16 stages x FFN_HSTRIDE
@@ -224,7 +235,57 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
     asm volatile("s_barrier" ::: "memory");                    // everybody is done with the x tile: the region becomes the H image
 
     // ------------------------------------------------------------------------------------------------- epilogue 1
-    {
+    int er[2] = {0, 0};                                        // PS: the rows' exponents (this lane's row of tile i)
+    if constexpr (PS) {
+        const int* ebp = reinterpret_cast<const int*>(reinterpret_cast<const char*>(p.Bp1) + 2 * bplane) + wn_u * 2;
+        const uint32_t key = drop_key_dev(p.dh);
+        float* tab = reinterpret_cast<float*>(smem + FFN_PS_TAB);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 32 * i + lr;
+            const uint32_t di0 = (uint32_t)((int64_t)(m0 + row) * p.f + 64 * wave + 4 * lh);
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ffn_unscale(acc[i][j], ea[i], ebp[j], ffn_alt(i));
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {          // the hidden value, in place in the accumulator register
+                        float y = acc[i][j][4 * g + t] + b1v[j][g][t];
+                        if (p.act == GT_ACT_RELU) y = fmaxf(y, 0.f);
+                        if (p.dh.thresh) y *= drop_mul(p.dh, key, di0 + 32 * j + 8 * g + t);
+                        acc[i][j][4 * g + t] = y;
+                        amax = fmaxf(amax, fabsf(y));
+                    }
+            }
+            amax = xor32_max(amax);                        // the row's 64 columns of this wave sit in the lane pair
+            if (lh == 0) tab[wave * 64 + row] = amax;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // table complete; everybody is done with the x tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 32 * i + lr;
+            const float a = fmaxf(fmaxf(tab[row], tab[64 + row]), fmaxf(tab[128 + row], tab[192 + row]));
+            const int ex = (int)(__float_as_uint(a) >> 23);
+            er[i] = ex == 0 ? 0 : min(FFN_E0, FFN_TARGET + 127 - ex);      // scaled row amax in [2^13, 2^14)
+            const float sv = ffn_pow2(er[i]) * ffn_alt(i);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint32_t h0, l0, h1, l1;
+                    f16_mulsplit_pair(acc[i][j][4 * g], sv, acc[i][j][4 * g + 1], sv, h0, l0);
+                    f16_mulsplit_pair(acc[i][j][4 * g + 2], sv, acc[i][j][4 * g + 3], sv, h1, l1);
+                    // hidden columns 64 wave + 32 j + 8 g + 4 lh .. + 3 = k-half g & 1 of stage 4 wave + 2 j + g / 2, second half of
+                    // the fragment's eight k for lh = 1:  [plane][stage][row][k-half] x 16 B
+                    const int st = 4 * wave + 2 * j + (g >> 1);
+                    char* dst = smem + ((st * 64 + row) * 32 + (g & 1) * 16 + lh * 8);
+                    *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
+                    *reinterpret_cast<uint2*>(dst + 16 * 64 * 32) = uint2{l0, l1};
+                }
+        }
+    } else {
         const int* ebp = reinterpret_cast<const int*>(reinterpret_cast<const char*>(p.Bp1) + 2 * bplane) + wn_u * 2;
         const uint32_t key = drop_key_dev(p.dh);
 #pragma unroll
@@ -266,9 +327,18 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
     auto stage2 = [&](int kt2, f16x8 (&bn)[1][2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            float v[8];
-            ffn_frag(himg + kt2 * FFN_HSTRIDE, 32 * i + lr, lh, v);
-            ffn_tile_stage<1>(v, ea2[i], ffn_alt(i), bn, acc2[i]);
+            if constexpr (PS) {                                // finished fragments: no split, no exponent bookkeeping
+                const char* fr = smem + ((kt2 * 64 + 32 * i + lr) * 32 + lh * 16);
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(fr);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(fr + 16 * 64 * 32);
+                acc2[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bn[0][0], a1, acc2[i][0], 0, 0, 0);     // h1 g0
+                acc2[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bn[0][1], a0, acc2[i][0], 0, 0, 0);     // h0 g1
+                acc2[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bn[0][0], a0, acc2[i][0], 0, 0, 0);     // h0 g0
+            } else {
+                float v[8];
+                ffn_frag(himg + kt2 * FFN_HSTRIDE, 32 * i + lr, lh, v);
+                ffn_tile_stage<1>(v, ea2[i], ffn_alt(i), bn, acc2[i]);
+            }
         }
     };
     // behind B(k) sit B(k+1) .. B(k+3): 6 loads
@@ -292,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
     {
         const int* ebp2 = reinterpret_cast<const int*>(reinterpret_cast<const char*>(p.Bp2) + 2 * bplane2) + wn_u;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ffn_unscale(acc2[i][0], ea2[i], ebp2[0], ffn_alt(i));
+        for (int i = 0; i < 2; ++i) ffn_unscale(acc2[i][0], PS ? er[i] : ea2[i], ebp2[0], ffn_alt(i));
     }
 
     // ------------------------------------------------------------------------------------------------- epilogue 2
@@ -308,6 +378,29 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
         }
     }
     const f32x4 b2v = p.b2 ? *reinterpret_cast<const f32x4*>(p.b2 + ocol) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PS) {
+        // hidden tile -> HBM out of the phase-1 accumulator registers: the wave's 64 x 64 tile through its private transposing
+        // tile (over the dead planes), then 256-byte row segments, four rows per instruction
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everybody is done with the planes
+        float* hs = reinterpret_cast<float*>(smem) + wave * (64 * FFN_HST_SW);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(hs + (32 * i + lr) * FFN_HST_SW + 32 * j + 8 * g + 4 * lh) =
+                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int c4 = lane & 15, r4 = lane >> 4;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = 4 * it + r4;
+            const f32x4 h = *reinterpret_cast<const f32x4*>(hs + row * FFN_HST_SW + 4 * c4);
+            if (m0 + row < p.T) *reinterpret_cast<f32x4*>(p.hid + (int64_t)(m0 + row) * p.f + 64 * wave + 4 * c4) = h;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the tile is read out: the wave's region becomes the out staging
+    } else {
     // hidden tile -> HBM: wave w stores rows 16 w .. 16 w + 15, a row = 1 KB = one instruction (lane l: columns 4 l ..)
     {
         const int st = lane >> 2, gq = lane & 3;
@@ -319,8 +412,9 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everybody is done with the H image: it becomes staging
+    }
     {
-        float* stg = reinterpret_cast<float*>(smem) + wave * (64 * FFN_EP_SW);
+        float* stg = reinterpret_cast<float*>(smem) + wave * (PS ? 64 * FFN_HST_SW : 64 * FFN_EP_SW);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -389,16 +483,21 @@ extern "C" int gt_ffn_fwd(const float* x, int64_t T, int32_t d, int32_t f, const
     } else if (!al(w1_packed) || !al(w2_packed)) return GT_EALIGN;
     FfnP p{x, res, hid, out, b1, b2, w1_packed, w2_packed, (int)T, d, f,
            d / 16, ((f + 127) / 128) * 4, f / 16, ((d + 127) / 128) * 4, make_drop(drop_h), make_drop(drop_o), act};
-    const size_t lds = (size_t)16 * FFN_HSTRIDE;
+    static const int presplit = [] { const char* e = getenv("GT_FFN_PRESPLIT"); return e ? atoi(e) : 1; }();
+    const size_t lds0 = (size_t)16 * FFN_HSTRIDE, lds1 = (size_t)FFN_PS_TAB + 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fwd16_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fwd16_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fwd16_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     const unsigned tiles = (unsigned)((T + FFN_BM - 1) / FFN_BM);
-    hipLaunchKernelGGL(ffn_fwd16_kernel, dim3(tiles), dim3(256), lds, st, p);
+    if (presplit) hipLaunchKernelGGL(ffn_fwd16_kernel<true>, dim3(tiles), dim3(256), lds1, st, p);
+    else hipLaunchKernelGGL(ffn_fwd16_kernel<false>, dim3(tiles), dim3(256), lds0, st, p);
     GT_LAUNCH_CHECK();
     return 0;
 }
