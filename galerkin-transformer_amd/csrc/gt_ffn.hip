@@ -57,6 +57,14 @@ struct FfnP {
     int KS1, NT1, KS2, NT2;
     DropDev dh, dout;
     int act;                                               // GT_ACT_RELU | GT_ACT_NONE
+    // ReLU / dropout decisions of the hidden tile, one bit per value in the accumulator layout of phase 1: word
+    // [(tile * 4 + wave) * 64 + lane][i], bit 16 j + 4 g + t  <->  hidden value (row 32 i + lr, column 64 wave + 32 j + 8 g + 4 lh + t).
+    // The forward writes them (bits_out), the backward (bwd != 0) takes its mask from them (bits_in): both run this kernel's
+    // geometry, so the word is lane-local on both sides.
+    uint32_t* bits_out; const uint32_t* bits_in;
+    int bwd;                                               // 1: gh = (gm W2) .* bits * e1_scale ;  dx = res + gh W1 ;  out2 = dx .* mask2
+    float e1_scale;
+    float* out2; DropDev d2;
 };
 
 __device__ __forceinline__ float ffn_pow2(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }
@@ -245,6 +253,9 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
             const int row = 32 * i + lr;
             const uint32_t di0 = (uint32_t)((int64_t)(m0 + row) * p.f + 64 * wave + 4 * lh);
             float amax = 0.f;
+            const int64_t widx = ((int64_t)(tile * 4 + wave) * 64 + lane) * 2 + i;
+            const uint32_t bin = p.bwd ? p.bits_in[widx] : 0u;
+            uint32_t bout = 0u;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 ffn_unscale(acc[i][j], ea[i], ebp[j], ffn_alt(i));
@@ -252,13 +263,20 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {          // the hidden value, in place in the accumulator register
-                        float y = acc[i][j][4 * g + t] + b1v[j][g][t];
-                        if (p.act == GT_ACT_RELU) y = fmaxf(y, 0.f);
-                        if (p.dh.thresh) y *= drop_mul(p.dh, key, di0 + 32 * j + 8 * g + t);
+                        float y;
+                        if (p.bwd) {                       // d(hidden): through the forward's ReLU / dropout decision
+                            y = ((bin >> (16 * j + 4 * g + t)) & 1u) ? acc[i][j][4 * g + t] * p.e1_scale : 0.f;
+                        } else {
+                            y = acc[i][j][4 * g + t] + b1v[j][g][t];
+                            if (p.act == GT_ACT_RELU) y = fmaxf(y, 0.f);
+                            if (p.dh.thresh) y *= drop_mul(p.dh, key, di0 + 32 * j + 8 * g + t);
+                            bout |= (y > 0.f ? 1u : 0u) << (16 * j + 4 * g + t);
+                        }
                         acc[i][j][4 * g + t] = y;
                         amax = fmaxf(amax, fabsf(y));
                     }
             }
+            if (p.bits_out) p.bits_out[widx] = bout;
             amax = xor32_max(amax);                        // the row's 64 columns of this wave sit in the lane pair
             if (lh == 0) tab[wave * 64 + row] = amax;
         }
@@ -435,6 +453,14 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
                 v[t] = p.res ? rs[it][t] + y : y;
             }
             if (m < p.T) *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.d + ocol) = v;
+            if (p.out2) {                                  // the same rows under a second mask (gt_gemm_desc.c_masked's twin)
+                const uint32_t key2 = drop_key_dev(p.d2);
+                if (p.d2.thresh) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] *= drop_mul(p.d2, key2, di + t);
+                }
+                if (m < p.T) *reinterpret_cast<f32x4*>(p.out2 + (int64_t)m * p.d + ocol) = v;
+            }
         }
     }
 }
@@ -455,35 +481,22 @@ extern "C" int64_t gt_ffn_fwd_ws_bytes(int64_t T, int32_t d, int32_t f) {
     return (pa > 0 && pb > 0) ? pa + pb : 0;
 }
 
-extern "C" int gt_ffn_fwd(const float* x, int64_t T, int32_t d, int32_t f, const float* W1, const float* b1,
-                          const float* W2, const float* b2, const float* res, const gt_dropout* drop_h,
-                          const gt_dropout* drop_o, int32_t act, float* hid, float* out, const void* w1_packed,
-                          const void* w2_packed, void* ws, int64_t ws_bytes, void* stream) {
-    if (!x || !W1 || !W2 || !hid || !out || T <= 0) return GT_EINVAL;
-    if (d != 128 || f != 256 || T < 16384 || T > (1 << 30) || (act != GT_ACT_RELU && act != GT_ACT_NONE)) return GT_ENOTSUP;
-    if ((drop_h && drop_h->p > 0.f && !drop_h->seed) || (drop_o && drop_o->p > 0.f && !drop_o->seed)) return GT_EINVAL;
-    if ((drop_h && (drop_h->p < 0.f || drop_h->p >= 1.f)) || (drop_o && (drop_o->p < 0.f || drop_o->p >= 1.f))) return GT_EINVAL;
+static int ffn_launch(FfnP& p, const gt_gemm_desc& a, const gt_gemm_desc& b, const void* p1, const void* p2, void* ws,
+                      int64_t ws_bytes, void* stream) {
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (!al(x) || !al(W1) || !al(W2) || !al(hid) || !al(out) || !al(res) || !al(b1) || !al(b2)) return GT_EALIGN;
-    if ((w1_packed == nullptr) != (w2_packed == nullptr)) return GT_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    gt_gemm_desc a, b;
-    gt_gemm_desc_init(&a); gt_gemm_desc_init(&b);
-    a.M = b.M = (int32_t)T;
-    a.N = f; a.K = d; a.A = x; a.lda = d; a.B = W1; a.ldb = d; a.C = hid; a.ldc = f; a.precision = GT_PREC_F16X2;
-    b.N = d; b.K = f; b.A = hid; b.lda = f; b.B = W2; b.ldb = f; b.C = out; b.ldc = d; b.precision = GT_PREC_F16X2;
+    if ((p1 == nullptr) != (p2 == nullptr)) return GT_EINVAL;
     const int64_t pa = gt_gemm_packed_b_bytes(&a), pb = gt_gemm_packed_b_bytes(&b);
     if (pa <= 0 || pb <= 0) return GT_ENOTSUP;
-    if (!w1_packed) {                                          // pack both weights into the scratch (one launch)
+    if (!p1) {                                                 // pack both weights into the scratch (one launch)
         if (!ws || ws_bytes < pa + pb || !al(ws)) return GT_EWS;
         gt_gemm_desc two[2] = {a, b};
         void* outs[2] = {ws, reinterpret_cast<char*>(ws) + pa};
         if (int rc = gt_gemm_pack_b_many(two, outs, 2, stream)) return rc;
-        w1_packed = outs[0]; w2_packed = outs[1];
-    } else if (!al(w1_packed) || !al(w2_packed)) return GT_EALIGN;
-    FfnP p{x, res, hid, out, b1, b2, w1_packed, w2_packed, (int)T, d, f,
-           d / 16, ((f + 127) / 128) * 4, f / 16, ((d + 127) / 128) * 4, make_drop(drop_h), make_drop(drop_o), act};
+        p1 = outs[0]; p2 = outs[1];
+    } else if (!al(p1) || !al(p2)) return GT_EALIGN;
+    p.Bp1 = p1; p.Bp2 = p2;
     static const int presplit = [] { const char* e = getenv("GT_FFN_PRESPLIT"); return e ? atoi(e) : 1; }();
+    if (!presplit && (p.bwd || p.bits_out)) return GT_ENOTSUP;       // the decision bits exist in the pre-split form only
     const size_t lds0 = (size_t)16 * FFN_HSTRIDE, lds1 = (size_t)FFN_PS_TAB + 1024;
     static bool attr_done = false;
     if (!attr_done) {
@@ -495,9 +508,56 @@ extern "C" int gt_ffn_fwd(const float* x, int64_t T, int32_t d, int32_t f, const
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    const unsigned tiles = (unsigned)((T + FFN_BM - 1) / FFN_BM);
+    const unsigned tiles = (unsigned)(((int64_t)p.T + FFN_BM - 1) / FFN_BM);
+    hipStream_t st = (hipStream_t)stream;
     if (presplit) hipLaunchKernelGGL(ffn_fwd16_kernel<true>, dim3(tiles), dim3(256), lds1, st, p);
     else hipLaunchKernelGGL(ffn_fwd16_kernel<false>, dim3(tiles), dim3(256), lds0, st, p);
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+static bool ffn_shape_ok(int64_t T, int32_t d, int32_t f) { return d == 128 && f == 256 && T >= 16384 && T <= (1 << 30); }
+
+extern "C" int64_t gt_ffn_bits_bytes(int64_t T) { return T > 0 ? ((T + FFN_BM - 1) / FFN_BM) * 4 * 64 * 2 * (int64_t)sizeof(uint32_t) : 0; }
+
+extern "C" int gt_ffn_fwd(const float* x, int64_t T, int32_t d, int32_t f, const float* W1, const float* b1,
+                          const float* W2, const float* b2, const float* res, const gt_dropout* drop_h,
+                          const gt_dropout* drop_o, int32_t act, float* hid, float* out, void* relu_bits,
+                          const void* w1_packed, const void* w2_packed, void* ws, int64_t ws_bytes, void* stream) {
+    if (!x || !W1 || !W2 || !hid || !out || T <= 0) return GT_EINVAL;
+    if (!ffn_shape_ok(T, d, f) || (act != GT_ACT_RELU && act != GT_ACT_NONE)) return GT_ENOTSUP;
+    if ((drop_h && drop_h->p > 0.f && !drop_h->seed) || (drop_o && drop_o->p > 0.f && !drop_o->seed)) return GT_EINVAL;
+    if ((drop_h && (drop_h->p < 0.f || drop_h->p >= 1.f)) || (drop_o && (drop_o->p < 0.f || drop_o->p >= 1.f))) return GT_EINVAL;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al(x) || !al(W1) || !al(W2) || !al(hid) || !al(out) || !al(res) || !al(b1) || !al(b2) || !al(relu_bits)) return GT_EALIGN;
+    gt_gemm_desc a, b;
+    gt_gemm_desc_init(&a); gt_gemm_desc_init(&b);
+    a.M = b.M = (int32_t)T;
+    a.N = f; a.K = d; a.A = x; a.lda = d; a.B = W1; a.ldb = d; a.C = hid; a.ldc = f; a.precision = GT_PREC_F16X2;
+    b.N = d; b.K = f; b.A = hid; b.lda = f; b.B = W2; b.ldb = f; b.C = out; b.ldc = d; b.precision = GT_PREC_F16X2;
+    FfnP p{x, res, hid, out, b1, b2, nullptr, nullptr, (int)T, d, f,
+           d / 16, ((f + 127) / 128) * 4, f / 16, ((d + 127) / 128) * 4, make_drop(drop_h), make_drop(drop_o), act,
+           reinterpret_cast<uint32_t*>(relu_bits), nullptr, 0, 1.f, nullptr, make_drop(nullptr)};
+    return ffn_launch(p, a, b, w1_packed, w2_packed, ws, ws_bytes, stream);
+}
+
+extern "C" int gt_ffn_bwd(const float* gm, int64_t T, int32_t d, int32_t f, const float* W2, const float* W1,
+                          const void* relu_bits, float hid_scale, const float* res, float* gh, float* dx, float* dx_masked,
+                          const gt_dropout* mask2, const void* w2_packed, const void* w1_packed, void* ws, int64_t ws_bytes,
+                          void* stream) {
+    if (!gm || !W1 || !W2 || !relu_bits || !gh || !dx || T <= 0) return GT_EINVAL;
+    if (!ffn_shape_ok(T, d, f)) return GT_ENOTSUP;
+    if (mask2 && (mask2->p < 0.f || mask2->p >= 1.f || (mask2->p > 0.f && !mask2->seed))) return GT_EINVAL;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al(gm) || !al(W1) || !al(W2) || !al(gh) || !al(dx) || !al(res) || !al(dx_masked) || !al(relu_bits)) return GT_EALIGN;
+    // gh [T, f] = gm [T, d] W2  (B(k, n) = W2[k * f + n]: layout_b = 1);  dx [T, d] = gh W1  (B(k, n) = W1[k * d + n])
+    gt_gemm_desc a, b;
+    gt_gemm_desc_init(&a); gt_gemm_desc_init(&b);
+    a.M = b.M = (int32_t)T;
+    a.N = f; a.K = d; a.A = gm; a.lda = d; a.B = W2; a.ldb = f; a.layout_b = 1; a.C = gh; a.ldc = f; a.precision = GT_PREC_F16X2;
+    b.N = d; b.K = f; b.A = gh; b.lda = f; b.B = W1; b.ldb = d; b.layout_b = 1; b.C = dx; b.ldc = d; b.precision = GT_PREC_F16X2;
+    FfnP p{gm, res, gh, dx, nullptr, nullptr, nullptr, nullptr, (int)T, d, f,
+           d / 16, ((f + 127) / 128) * 4, f / 16, ((d + 127) / 128) * 4, make_drop(nullptr), make_drop(nullptr), GT_ACT_NONE,
+           nullptr, reinterpret_cast<const uint32_t*>(relu_bits), 1, hid_scale, dx_masked, make_drop(mask2)};
+    return ffn_launch(p, a, b, w2_packed, w1_packed, ws, ws_bytes, stream);
 }

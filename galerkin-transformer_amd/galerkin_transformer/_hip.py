@@ -163,7 +163,10 @@ _PROTOS = {
     "gt_bilinear2d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p]),
     "gt_ffn_fwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "gt_ffn_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 +
-                   [C.POINTER(GtDropout), C.POINTER(GtDropout), C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
+                   [C.POINTER(GtDropout), C.POINTER(GtDropout), C.c_int32] + [C.c_void_p] * 6 + [C.c_int64, C.c_void_p]),
+    "gt_ffn_bits_bytes": (C.c_int64, [C.c_int64]),
+    "gt_ffn_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 3 + [C.c_float] +
+                   [C.c_void_p] * 4 + [C.POINTER(GtDropout)] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]),
     "gt_grad_sqnorm_ws_bytes": (C.c_int64, []),
     "gt_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gt_adam_clip_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_void_p] +
@@ -696,37 +699,65 @@ def ffn_fwd_supported(T: int, d: int, f: int, act: int) -> bool:
             and act in (ACT_RELU, ACT_NONE))
 
 
+def _ffn_packs(T, specs, dev_tensor):
+    """b_packed of the two products of a fused FeedForward launch when the once-per-step pack holds them, else (None, None).
+    specs: ((weight, layout_b, ldb, N, K), ...) -- the descriptors H.gemm would build for them."""
+    L = lib()
+    packs = []
+    for (Bw, lb, ldb, N, K) in specs:
+        dsc = GtGemmDesc()
+        L.gt_gemm_desc_init(C.byref(dsc))
+        dsc.M, dsc.N, dsc.K, dsc.lda, dsc.ldb, dsc.ldc, dsc.layout_b = T, N, K, K, ldb, N, lb
+        dsc.A, dsc.B, dsc.C = dev_tensor.data_ptr(), Bw.data_ptr(), dev_tensor.data_ptr()
+        dsc.precision = PREC_F16X2
+        weight_packs.use(dsc, Bw)
+        packs.append(dsc.b_packed)
+    return (packs[0], packs[1]) if (packs[0] and packs[1]) else (None, None)
+
+
 def ffn_fwd(x2: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, res, drop_h, drop_o, act: int,
-            hid: torch.Tensor, out: torch.Tensor):
+            hid: torch.Tensor, out: torch.Tensor, want_bits: bool = False):
     """hid = drop_h(act(x2 W1^T + b1)), out = res + drop_o(hid W2^T + b2) in one launch (gt_hip.h: gt_ffn_fwd).  The packed
-    weights come from the once-per-step pack when the two products are registered there (weight_packs), else the call packs."""
+    weights come from the once-per-step pack when the two products are registered there (weight_packs), else the call packs.
+    want_bits: also returns the ReLU / dropout decision bits of the hidden tile for ffn_bwd (an opaque uint8 tensor)."""
     need_f32_cuda(x2, w1, b1, w2, b2, res, hid, out)
     L = lib()
     T, d = x2.shape
     f = w1.shape[0]
-    packs = []
-    for (Bw, N, K) in ((w1, f, d), (w2, d, f)):         # the descriptors H.gemm would build for the two products
-        dsc = GtGemmDesc()
-        L.gt_gemm_desc_init(C.byref(dsc))
-        dsc.M, dsc.N, dsc.K, dsc.lda, dsc.ldb, dsc.ldc = T, N, K, K, K, N
-        dsc.A, dsc.B, dsc.C = x2.data_ptr(), Bw.data_ptr(), out.data_ptr()
-        dsc.precision = PREC_F16X2
-        weight_packs.use(dsc, Bw)
-        packs.append(dsc.b_packed)
-    both = packs[0] and packs[1]
+    p1, p2 = _ffn_packs(T, ((w1, 0, d, f, d), (w2, 0, f, d, f)), x2)
     wsp, wsn = None, 0
-    if not both:
-        need = L.gt_ffn_fwd_ws_bytes(T, d, f)
-        ws = workspace(x2.device, need)
+    if p1 is None:
+        ws = workspace(x2.device, L.gt_ffn_fwd_ws_bytes(T, d, f))
         wsp, wsn = ws.data_ptr(), ws.numel()
+    bits = torch.empty(L.gt_ffn_bits_bytes(T), dtype=torch.uint8, device=x2.device) if want_bits else None
     dh = C.byref(drop_h) if (drop_h is not None and drop_h.p > 0) else None
     do = C.byref(drop_o) if (drop_o is not None and drop_o.p > 0) else None
     st = stream_ptr()
     call = lambda: L.gt_ffn_fwd(x2.data_ptr(), T, d, f, w1.data_ptr(), ptr(b1), w2.data_ptr(), ptr(b2), ptr(res), dh, do, act,
-                                hid.data_ptr(), out.data_ptr(), packs[0] if both else None, packs[1] if both else None,
-                                wsp, wsn, st)
+                                hid.data_ptr(), out.data_ptr(), ptr(bits), p1, p2, wsp, wsn, st)
     nbytes = 4.0 * T * (d + f + d + (d if res is not None else 0))
     check(_timed("gt_ffn_fwd", 4.0 * T * d * f, nbytes, call, shape=(T, d, f)), "gt_ffn_fwd")
+    return bits
+
+
+def ffn_bwd(gm: torch.Tensor, w2: torch.Tensor, w1: torch.Tensor, bits: torch.Tensor, hid_scale: float, res,
+            gh: torch.Tensor, dx: torch.Tensor, dx_masked=None, mask2=None):
+    """gh = (gm W2) .* bits * hid_scale, dx = res + gh W1 (+ dx_masked = dx under mask2) in one launch (gt_hip.h: gt_ffn_bwd)."""
+    need_f32_cuda(gm, w2, w1, res, gh, dx, dx_masked)
+    L = lib()
+    T, d = gm.shape
+    f = w1.shape[0]
+    p2, p1 = _ffn_packs(T, ((w2, 1, f, f, d), (w1, 1, d, d, f)), gm)
+    wsp, wsn = None, 0
+    if p2 is None:
+        ws = workspace(gm.device, L.gt_ffn_fwd_ws_bytes(T, d, f))
+        wsp, wsn = ws.data_ptr(), ws.numel()
+    m2 = C.byref(mask2) if (mask2 is not None and mask2.p > 0) else None
+    st = stream_ptr()
+    call = lambda: L.gt_ffn_bwd(gm.data_ptr(), T, d, f, w2.data_ptr(), w1.data_ptr(), bits.data_ptr(), float(hid_scale), ptr(res),
+                                gh.data_ptr(), dx.data_ptr(), ptr(dx_masked), m2, p2, p1, wsp, wsn, st)
+    nbytes = 4.0 * T * (d + f + d + (d if res is not None else 0) + (d if dx_masked is not None else 0))
+    check(_timed("gt_ffn_bwd", 4.0 * T * d * f, nbytes, call, shape=(T, d, f)), "gt_ffn_bwd")
 
 
 def gemm_kernel_name(A, B, M, N, K, *, layout_a=0, layout_b=0, lda, ldb, ldc, split_k=1, precision=None) -> str:

@@ -72,6 +72,7 @@ def set_scaler_mask_sink(sink):
 # consumer that finds no twin for exactly its (tensor address, p, salt) -- another op in between, a gradient autograd
 # accumulated from two consumers, a hook that replaced it -- runs the elementwise pass as before.
 _fold_masks = [os.environ.get("GT_FOLD_MASKS", "1") != "0"]
+_ffn_bwd_fused = [os.environ.get("GT_FFN_BWD_FUSED", "1") != "0"]      # data half of the FeedForward backward in one launch (gt_ffn_bwd)
 _mask_hints = {}                # out.data_ptr() -> (p, salt, numel): "the gradient w.r.t. this tensor is wanted under this mask too"
 _masked_twins = {}              # dx.data_ptr()  -> (masked copy, p, salt)
 
@@ -905,16 +906,19 @@ class FeedForwardFn(Function):
         rc = None if res is None else _c(res).reshape(T, dout)
         d_h = H.dropout_desc(p_h, salt, dev) if p_h > 0 else None
         d_o = H.dropout_desc(p_out, salt + 1, dev) if p_out > 0 else None
+        bits = None
         if dout == d and H.ffn_fwd_supported(T, d, f, act):
             # both products in ONE launch, the hidden tile of 64 token rows kept in LDS between them (gt_ffn.hip): hid is
-            # written for the backward and never read back here; the bits of the two launches below
-            H.ffn_fwd(xc, w1c, b1, w2c, b2, rc, d_h, d_o, act, hid, out)
+            # written for the backward (dW2) and never read back here; the ReLU / dropout decisions go along as one bit per
+            # value for the fused data half of the backward
+            bits = H.ffn_fwd(xc, w1c, b1, w2c, b2, rc, d_h, d_o, act, hid, out,
+                             want_bits=bool(act == H.ACT_RELU and _ffn_bwd_fused[0] and any(ctx.needs_input_grad[:5])))
         else:
             H.gemm(xc, w1c, hid, T, f, d, lda=d, ldb=d, ldc=f, bias=b1, act=act, pre=pre, ldpre=f, drop=d_h, weight_b=True)
             H.gemm(hid, w2c, out, T, dout, f, lda=f, ldb=f, ldc=dout, bias=b2, drop=d_o, res=rc, ldr=dout, weight_b=True)
         if _relu_mask_sink[0] is not None and act == H.ACT_RELU and p_h == 0:
             _relu_mask_sink[0].append(hid > 0)
-        ctx.save_for_backward(xc, w1c, w2c, hid, pre)
+        ctx.save_for_backward(xc, w1c, w2c, hid, pre, bits)
         ctx.cfg = (act, p_h, p_out, salt, d, f, dout, b1 is not None, b2 is not None, res is not None,
                    x.shape)
         ctx.in_mask = _wanted_mask(xc)            # the producer of x wants d(x) under its own output mask too
@@ -923,7 +927,7 @@ class FeedForwardFn(Function):
 
     @staticmethod
     def backward(ctx, gy):
-        xc, w1c, w2c, hid, pre = ctx.saved_tensors
+        xc, w1c, w2c, hid, pre, bits = ctx.saved_tensors
         act, p_h, p_out, salt, d, f, dout, hb1, hb2, has_res, xshape = ctx.cfg
         dev = gy.device
         T = xc.shape[0]
@@ -944,7 +948,18 @@ class FeedForwardFn(Function):
         with H.side_branch(dev, T):
             H.gemm(gm, hid, dw2, dout, f, T, layout_a=1, layout_b=1, lda=dout, ldb=f, ldc=f, split_k=0,
                    a_colsum=db2)
-        if act == H.ACT_RELU:
+        dx = torch.empty(T, d, dtype=torch.float32, device=dev)
+        same = has_res and dout == d
+        dxm, want = None, ctx.in_mask
+        if want is not None:
+            dxm = torch.empty_like(dx)
+        fused_bwd = bits is not None and act == H.ACT_RELU
+        if fused_bwd:
+            # gh = (gm W2) through the forward's decision bits, dx = g + gh W1 and its masked twin: ONE launch, the hidden
+            # activation is not read (gt_ffn_bwd); dW1 = gh^T x follows on the side stream
+            H.ffn_bwd(gm, w2c, w1c, bits, 1.0 / (1.0 - p_h), g if same else None, gh, dx, dxm,
+                      H.dropout_desc(want[0], want[1], dev) if want else None)
+        elif act == H.ACT_RELU:
             H.gemm(gm, w2c, gh, T, f, dout, layout_b=1, lda=dout, ldb=f, ldc=f,
                    aux_op=H.AUX_GT0, aux=hid, ldaux=f, aux_scale=1.0 / (1.0 - p_h), weight_b=True)
         else:
@@ -953,15 +968,11 @@ class FeedForwardFn(Function):
                    drop=H.dropout_desc(p_h, salt, dev) if p_h > 0 else None, weight_b=True)
         dw1 = torch.empty(f, d, dtype=torch.float32, device=dev)
         db1 = torch.empty(f, dtype=torch.float32, device=dev) if hb1 else None
-        dx = torch.empty(T, d, dtype=torch.float32, device=dev)
         with H.side_branch(dev, T):
             H.gemm(gh, xc, dw1, f, d, T, layout_a=1, layout_b=1, lda=f, ldb=d, ldc=d, split_k=0, a_colsum=db1)
-        same = has_res and dout == d
-        dxm, want = None, ctx.in_mask
-        if want is not None:
-            dxm = torch.empty_like(dx)
-        H.gemm(gh, w1c, dx, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=g if same else None, ldr=d, weight_b=True,
-               c_masked=dxm, ldc_masked=d, c_mask=H.dropout_desc(want[0], want[1], dev) if want else None)
+        if not fused_bwd:
+            H.gemm(gh, w1c, dx, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=g if same else None, ldr=d, weight_b=True,
+                   c_masked=dxm, ldc_masked=d, c_mask=H.dropout_desc(want[0], want[1], dev) if want else None)
         if dxm is not None:
             _offer_twin(dx, dxm, *want)
         H.join_side(dev)

@@ -276,8 +276,23 @@ int     gt_gemm_kernel_name(const gt_gemm_desc* d, char* buf, int32_t n);
 int64_t gt_ffn_fwd_ws_bytes(int64_t T, int32_t d, int32_t f);
 int gt_ffn_fwd(const float* x, int64_t T, int32_t d, int32_t f, const float* W1, const float* b1, const float* W2,
                const float* b2, const float* res, const gt_dropout* drop_h, const gt_dropout* drop_o, int32_t act,
-               float* hid, float* out, const void* w1_packed, const void* w2_packed, void* ws, int64_t ws_bytes,
-               void* stream);
+               float* hid, float* out, void* relu_bits, const void* w1_packed, const void* w2_packed, void* ws,
+               int64_t ws_bytes, void* stream);
+/* relu_bits (optional, gt_ffn_bits_bytes(T) bytes, 16-byte aligned): one bit per hidden value -- kept by the dropout AND
+ * positive -- in the kernel's own register layout (opaque to the caller), for gt_ffn_bwd.
+ *
+ * The data half of the backward (autograd of the above, nn.Linear / ReLU / nn.Dropout backwards) in the same geometry:
+ *     gh[t][:] = (gm[t] W2) .* bits .* hid_scale          [T, f]  written to HBM (dW1 = gh^T x needs it)
+ *     dx[t][:] = res[t] + gh[t] W1                        [T, d]  (res = the unmasked incoming gradient of a residual layer, or NULL)
+ *     dx_masked = dx .* keepscale_{mask2}                 optional second output (gt_gemm_desc.c_masked's twin)
+ * gm = the incoming gradient under the output-dropout mask; hid_scale = 1 / (1 - p_h).  The hidden activation itself is not
+ * read (its 242 MB at B = 128 were re-read as a 1-bit decision by the unfused hidden-gradient launch).  w2_packed / w1_packed:
+ * the packs of the products [T, d] x W2 (layout_b = 1, N = f) and [T, f] x W1 (layout_b = 1, N = d), or both NULL + ws
+ * (gt_ffn_fwd_ws_bytes).  Same shapes as gt_ffn_fwd, else GT_ENOTSUP. */
+int64_t gt_ffn_bits_bytes(int64_t T);
+int gt_ffn_bwd(const float* gm, int64_t T, int32_t d, int32_t f, const float* W2, const float* W1, const void* relu_bits,
+               float hid_scale, const float* res, float* gh, float* dx, float* dx_masked, const gt_dropout* mask2,
+               const void* w2_packed, const void* w1_packed, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * out[n] (+)= sum_m A[m*lda + n] * keepA(m,n)  -- bias gradients.  Two deterministic passes.

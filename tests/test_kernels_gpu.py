@@ -1423,6 +1423,44 @@ def test_ffn_fused_forward_equals_two_launches(H, gpu_device, T, p_h, p_o, with_
     assert not H.ffn_fwd_supported(5000, d, f, a) and not H.ffn_fwd_supported(T, 192, 384, a)
 
 
+@pytest.mark.parametrize("T,p_h,with_res,p2", [(16384 + 37, 0.05, True, 0.05), (236672, 0.05, True, 0.0), (20000, 0.0, False, 0.1)])
+def test_ffn_fused_backward_data_half(H, gpu_device, T, p_h, with_res, p2):
+    """gt_ffn_bwd (round 6): gh = (gm W2) through the forward's ReLU / dropout decision bits, dx = g + gh W1 and the masked twin
+    of dx in ONE launch -- against the two packed-B launches it replaces (hidden-gradient product with the saved activation as
+    its GT_AUX_GT0 operand, data-gradient product with c_masked) and against fp64; the hidden activation is not an input."""
+    dev = gpu_device
+    d, f = 128, 256
+    x = rnd(T, d, dev=dev, seed=340)
+    w1, b1 = rnd(f, d, dev=dev, seed=341, scale=0.1), rnd(f, dev=dev, seed=342, scale=0.1)
+    w2, b2 = rnd(d, f, dev=dev, seed=343, scale=0.1), rnd(d, dev=dev, seed=344, scale=0.1)
+    dh = H.dropout_desc(p_h, 510, dev) if p_h > 0 else None
+    hid, out = torch.empty(T, f, device=dev), torch.empty(T, d, device=dev)
+    bits = H.ffn_fwd(x, w1, b1, w2, b2, x, dh, None, H.ACT_RELU, hid, out, want_bits=True)
+    gm, g = rnd(T, d, dev=dev, seed=345), rnd(T, d, dev=dev, seed=346)
+    res = g if with_res else None
+    m2 = H.dropout_desc(p2, 511, dev) if p2 > 0 else None
+    scale = 1.0 / (1.0 - p_h)
+    # the two launches
+    gh0, dx0, dxm0 = (torch.full((T, n), float("nan"), device=dev) for n in (f, d, d))
+    H.gemm(gm, w2, gh0, T, f, d, layout_b=1, lda=d, ldb=f, ldc=f, aux_op=H.AUX_GT0, aux=hid, ldaux=f, aux_scale=scale, precision="f16x2")
+    H.gemm(gh0, w1, dx0, T, d, f, layout_b=1, lda=f, ldb=d, ldc=d, res=res, ldr=d, c_masked=dxm0, ldc_masked=d, c_mask=m2,
+           precision="f16x2")
+    gh1, dx1, dxm1 = (torch.full((T, n), float("nan"), device=dev) for n in (f, d, d))
+    H.ffn_bwd(gm, w2, w1, bits, scale, res, gh1, dx1, dxm1, m2)
+    torch.cuda.synchronize()
+    assert torch.equal(gh1, gh0)                           # phase 1 + decision bits: the first launch, value for value
+    assert rel_l2(dx1, dx0) < 5e-7
+    keep2 = H.dropout_apply(torch.ones(T, d, device=dev), m2) if m2 is not None else torch.ones(T, d, device=dev)
+    assert torch.equal(dxm1, dx1 * keep2)
+    ghr = (gm.double() @ w2.double()) * (hid > 0).double() * scale
+    dxr = ghr @ w1.double() + (g.double() if with_res else 0.0)
+    assert rel_l2(gh1, ghr) < KTOL and rel_l2(dx1, dxr) < KTOL
+    first = dx1.clone()
+    for _ in range(5):
+        H.ffn_bwd(gm, w2, w1, bits, scale, res, gh1, dx1, dxm1, m2)
+        assert torch.equal(dx1, first) and torch.equal(gh1, gh0)
+
+
 def test_width_split_product_takes_a_weight_packed_ahead(H, gpu_device):
     """N = 192 (ex3's d_model) is cut into a 128-column launch and a 64-column remainder; round 6: both run on the packed-B
     kernels and gt_gemm_packed_b_bytes / gt_gemm_pack_b_many / gt_gemm_desc.b_packed describe the two packs back to back --
