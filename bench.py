@@ -450,8 +450,23 @@ def roofline_leg(trainer, precision, workload="ex2_darcy141"):
         elif x3_name(dom):
             # one launch geometry of the symbol: the split-operand kernels run 256 threads per 128 x 128 output tile
             Ms, Ns = best[6][0], best[6][1]
-            grid = -(-Ms // 128) * -(-Ns // 128) * 256 * best[6][3]
+            tiles = -(-Ms // 128) * -(-Ns // 128)
+            grid = tiles * 256 * best[6][3]
             rec = pj.get("_by_grid", {}).get(f"gt::{dom.replace('+splitk', '')}|{grid}")
+            if rec is None and dom.endswith("+splitk"):
+                # split-K launch: tiles x K chunks workgroups, the chunk count is the library's choice -- the ONE launch
+                # geometry of this symbol in the profiled steps whose workgroup count is a multiple of this tile count and
+                # of no other tile count the symbol ran with
+                others = {-(-r[6][0] // 128) * -(-r[6][1] // 128) for r in recs} - {tiles}
+                cands = []
+                for k in pj.get("_by_grid", {}):
+                    if k.startswith(kernel_symbol + "|"):
+                        wg = int(k.rsplit("|", 1)[1]) // 256
+                        if wg % tiles == 0 and not any(wg % o == 0 for o in others if o > tiles or tiles % o):
+                            cands.append(k)
+                if len(cands) == 1:
+                    grid = int(cands[0].rsplit("|", 1)[1])
+                    rec = pj["_by_grid"][cands[0]]
         if rec is None and kernel_symbol in pj and len([k for k in pj.get("_by_grid", {}) if k.startswith(kernel_symbol + "|")]) == 1:
             rec = pj[kernel_symbol]                  # a symbol with ONE launch geometry in the profiled steps: its average is this launch
         if rec and "read_bytes" in rec and "write_bytes" in rec:

@@ -127,6 +127,7 @@ struct DftSP {
     const float* F; const float* Z; const float* X2; const float* W2; const float* bias;
     float* Y; float* pre;
     int nb, n, P, act;
+    const float* gate = nullptr;       // gt_dft_synthesis_gated: Y *= silu'(gate) (same layout as Y)
 };
 
 // MAXT = output row tiles (16 rows) per wave: ceil(ceil(n/16) / 4)
@@ -227,6 +228,10 @@ __global__ __launch_bounds__(256, 2) void dft_synthesis_kernel(const DftSP p) {
                     if (PRE) *reinterpret_cast<f32x2*>(p.pre + obase + (int64_t)orow * DFT_C + 2 * j) = v;
                     if (p.act == GT_ACT_SILU) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); }
                     else if (p.act == GT_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+                    if (p.gate) {
+                        const f32x2 gt = *reinterpret_cast<const f32x2*>(p.gate + obase + (int64_t)orow * DFT_C + 2 * j);
+                        v[0] *= dsilu_f(gt[0]); v[1] *= dsilu_f(gt[1]);
+                    }
                     *reinterpret_cast<f32x2*>(p.Y + obase + (int64_t)orow * DFT_C + 2 * j) = v;
                 }
             }
@@ -264,7 +269,15 @@ extern "C" int gt_dft_analysis(const float* F, const float* X, float* Y, int32_t
 extern "C" int gt_dft_synthesis(const float* F, const float* Z, float* Y, int32_t nb, int32_t n, int32_t P,
                                 int32_t Co, const float* X2, const float* W2, int32_t C2, const float* bias,
                                 int32_t act, float* pre, void* stream) {
+    return gt_dft_synthesis_gated(F, Z, Y, nb, n, P, Co, X2, W2, C2, bias, act, pre, nullptr, stream);
+}
+
+extern "C" int gt_dft_synthesis_gated(const float* F, const float* Z, float* Y, int32_t nb, int32_t n, int32_t P,
+                                      int32_t Co, const float* X2, const float* W2, int32_t C2, const float* bias,
+                                      int32_t act, float* pre, const float* out_gate, void* stream) {
     if (!F || !Z || !Y || nb <= 0 || n <= 0 || P <= 0 || Co <= 0) return GT_EINVAL;
+    if (out_gate && (act != GT_ACT_NONE || pre)) return GT_EINVAL;
+    if (reinterpret_cast<uintptr_t>(out_gate) & 7) return GT_EALIGN;
     if (act != GT_ACT_NONE && act != GT_ACT_RELU && act != GT_ACT_SILU) return GT_EINVAL;
     if (Co != DFT_C || C2 != DFT_C || !X2 || !W2 || P > 32 || (P & 3) || n > 256) return GT_ENOTSUP;
     const uintptr_t al = reinterpret_cast<uintptr_t>(X2) | reinterpret_cast<uintptr_t>(Z);
@@ -274,7 +287,7 @@ extern "C" int gt_dft_synthesis(const float* F, const float* Z, float* Y, int32_
     const int nch = (xch + zch + 3) / 4 * 4;
     const size_t lds = (size_t)(2 * nch) * 1024;
     if (lds > 65536) return GT_ENOTSUP;
-    DftSP p{F, Z, X2, W2, bias, Y, pre, nb, n, P, act};
+    DftSP p{F, Z, X2, W2, bias, Y, pre, nb, n, P, act, out_gate};
     const int maxt = ((n + 15) / 16 + 3) / 4;
     dim3 grid((unsigned)dft_blocks(nb, lds <= 53 * 1024 ? 3 : 2));
 #define GT_DS(T)                                                                                         \

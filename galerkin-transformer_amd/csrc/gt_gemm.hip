@@ -511,7 +511,9 @@ static int x3_planes(const gt_gemm_desc* d) {
 static int make_plan(const gt_gemm_desc* d, Plan* pl) {
     if (d->M <= 0 || d->N <= 0 || d->K < 0 || d->batch0 <= 0 || d->batch1 <= 0) return GT_EINVAL;
     if (d->precision < GT_PREC_F32 || d->precision > GT_PREC_F16X2) return GT_EINVAL;
-    if (d->act < GT_ACT_NONE || (d->act > GT_ACT_SILU && d->act != GT_ACT_DROP_SILU)) return GT_EINVAL;   // GT_ACT_GELU: elementwise entry points only
+    if (d->act < GT_ACT_NONE || (d->act > GT_ACT_SILU && d->act != GT_ACT_DROP_SILU && d->act != GT_ACT_SILU2))
+        return GT_EINVAL;                          // GT_ACT_GELU: elementwise entry points only
+    if (d->act == GT_ACT_SILU2 && d->drop.p > 0.f) return GT_EINVAL;
     const int64_t batch = (int64_t)d->batch0 * d->batch1;
     if (batch > 65535) return GT_EINVAL;
     pl->x3 = x3_planes(d);

@@ -206,9 +206,19 @@ __device__ __forceinline__ void ep_row(const GemmP& p, float (&v)[NT], const flo
             dfac[t] = ks * da;
         }
     }
+    if (p.act == GT_ACT_SILU2) {               // silu(silu(v)); `pre` takes the product of the two derivatives (gt_hip.h)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float a1, d1, a2, d2;
+            silu_both(v[t], a1, d1);
+            silu_both(a1, a2, d2);
+            v[t] = a2;
+            dfac[t] = d1 * d2;
+        }
+    }
     if (p.pre) {
         float* pp = p.pre + ((int64_t)z * p.M + m) * p.ldpre + nb;
-        const bool df = p.act == GT_ACT_DROP_SILU;
+        const bool df = p.act == GT_ACT_DROP_SILU || p.act == GT_ACT_SILU2;
         if (vec4) {
             *reinterpret_cast<f32x4*>(pp) = df ? f32x4{dfac[0], dfac[1 % NT], dfac[2 % NT], dfac[3 % NT]}
                                                : f32x4{v[0], v[1 % NT], v[2 % NT], v[3 % NT]};

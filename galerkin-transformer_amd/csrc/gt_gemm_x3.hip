@@ -274,6 +274,20 @@ __device__ __forceinline__ void x3_epilogue_fast(const GemmP& p, const f32x16 (&
                 }
                 if (p.pre) *reinterpret_cast<f32x4*>(p.pre + ((int64_t)z * p.M + m0b + 4 * k) * p.ldpre + nb) = df;
             }
+        } else if (p.act == GT_ACT_SILU2) {     // silu(silu(v)); `pre` = silu'(v) silu'(silu(v)) (gt_hip.h, ep_row)
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                f32x4 df;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float a1, d1, a2, d2;
+                    silu_both(v[k][t], a1, d1);
+                    silu_both(a1, a2, d2);
+                    v[k][t] = a2;
+                    df[t] = d1 * d2;
+                }
+                if (p.pre) *reinterpret_cast<f32x4*>(p.pre + ((int64_t)z * p.M + m0b + 4 * k) * p.ldpre + nb) = df;
+            }
         } else if (p.pre) {
 #pragma unroll
             for (int k = 0; k < HB; ++k)

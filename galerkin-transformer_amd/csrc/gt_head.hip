@@ -34,7 +34,15 @@ struct HeadP {
     float* out; float* dX; float* slabs;
     int64_t T;
     int n_mtiles;
+    const float* gate = nullptr;       // gt_mlp_head_bwd_gated: dX *= silu'(gate) (same layout as X)
 };
+
+// dX *= silu'(pre-activation of the layer that produced X): the SiLU backward of that layer on this kernel's store
+__device__ __forceinline__ void head_gate4(const float* gp, f32x4& v) {
+    const f32x4 gt = *reinterpret_cast<const f32x4*>(gp);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] *= dsilu_f(gt[t]);
+}
 
 template <int ACT>
 __device__ __forceinline__ void head_act(float h, float& a, float& da) {
@@ -198,7 +206,9 @@ __global__ __launch_bounds__(256, 2) void head_bwd_kernel(const HeadP p) {
         if (active) {
             if (p.dX && m0 + j < p.T) {                                // this wave stores in-features [16 half, +16)
                 const f32x4 o = *reinterpret_cast<const f32x4*>(&ex[((wave ^ 1) * 2 + half) * 256 + lane * 4]);
-                *reinterpret_cast<f32x4*>(p.dX + (m0 + j) * HK + 16 * half + 4 * kq) = accX[half] + o;
+                f32x4 dxv = accX[half] + o;
+                if (p.gate) head_gate4(p.gate + (m0 + j) * HK + 16 * half + 4 * kq, dxv);
+                *reinterpret_cast<f32x4*>(p.dX + (m0 + j) * HK + 16 * half + 4 * kq) = dxv;
             }
             // (3) dW1 tiles (hidden hb + 16mt.., in 16t..) += dh^T[hidden][row 4kq + s] x[row 4kq + s][in 16t + j]
             float xr[2][4];
@@ -629,7 +639,9 @@ __global__ __launch_bounds__(256, 2) void head_bwd16_kernel(const HeadP p) {
             for (int u = 0; u < 2; ++u)
                 if (m0 + 16 * u + j < p.T) {         // this wave stores in-features [16 half, +16)
                     const f32x4 o = *reinterpret_cast<const f32x4*>(&sEx[((wave ^ 1) * 2 + u) * 256 + lane * 4]);
-                    *reinterpret_cast<f32x4*>(p.dX + (m0 + 16 * u + j) * HK + 16 * half + 4 * kq) = own[u] + o;
+                    f32x4 dxv = own[u] + o;
+                    if (p.gate) head_gate4(p.gate + (m0 + 16 * u + j) * HK + 16 * half + 4 * kq, dxv);
+                    *reinterpret_cast<f32x4*>(p.dX + (m0 + 16 * u + j) * HK + 16 * half + 4 * kq) = dxv;
                 }
         }
         if (active && !(H16_ABL & 1)) {
@@ -802,8 +814,18 @@ extern "C" int gt_mlp_head_bwd(const float* X, int64_t T, int32_t K, int32_t N, 
                                const float* b1, const float* w2, int32_t act, int32_t precision, const float* g,
                                float* dX, float* dW1, float* db1, float* dw2, float* db2, void* ws, int64_t ws_bytes,
                                void* stream) {
+    return gt_mlp_head_bwd_gated(X, T, K, N, n_out, W1, b1, w2, act, precision, g, dX, nullptr, dW1, db1, dw2, db2, ws,
+                                 ws_bytes, stream);
+}
+
+extern "C" int gt_mlp_head_bwd_gated(const float* X, int64_t T, int32_t K, int32_t N, int32_t n_out, const float* W1,
+                                     const float* b1, const float* w2, int32_t act, int32_t precision, const float* g,
+                                     float* dX, const float* dx_gate, float* dW1, float* db1, float* dw2, float* db2,
+                                     void* ws, int64_t ws_bytes, void* stream) {
     int rc = head_check(X, T, K, N, n_out, W1, w2, act);
     if (rc) return rc;
+    if (dx_gate && !dX) return GT_EINVAL;
+    if (reinterpret_cast<uintptr_t>(dx_gate) & 15) return GT_EALIGN;
     if (!g || !dW1 || precision < GT_PREC_F32 || precision > GT_PREC_F16X2) return GT_EINVAL;
     if (reinterpret_cast<uintptr_t>(dX) & 15) return GT_EALIGN;
     if (!ws || ws_bytes < gt_mlp_head_bwd_ws_bytes(T)) return GT_EWS;
@@ -811,7 +833,7 @@ extern "C" int gt_mlp_head_bwd(const float* X, int64_t T, int32_t K, int32_t N, 
     if (head_use_f16(precision)) {                   // 32 rows per wave pair and trip, two pairs per block
         const int64_t n32 = (T + 31) / 32;
         const int blocks16 = (int)std::min<int64_t>(512, (n32 + 1) / 2);
-        HeadP q{X, W1, b1, w2, nullptr, g, nullptr, dX, reinterpret_cast<float*>(ws), T, (int)((T + 15) / 16)};
+        HeadP q{X, W1, b1, w2, nullptr, g, nullptr, dX, reinterpret_cast<float*>(ws), T, (int)((T + 15) / 16), dx_gate};
         // the opt-in is per DEVICE: one bit per device ordinal (a process driving several GPUs)
         static std::atomic<uint64_t> raised{0};
         int dev = 0;
@@ -835,7 +857,7 @@ extern "C" int gt_mlp_head_bwd(const float* X, int64_t T, int32_t K, int32_t N, 
         return 0;
     }
     const int blocks = head_blocks(T, 2);
-    HeadP p{X, W1, b1, w2, nullptr, g, nullptr, dX, reinterpret_cast<float*>(ws), T, (int)((T + 15) / 16)};
+    HeadP p{X, W1, b1, w2, nullptr, g, nullptr, dX, reinterpret_cast<float*>(ws), T, (int)((T + 15) / 16), dx_gate};
     if (act == GT_ACT_SILU) hipLaunchKernelGGL((head_bwd_kernel<GT_ACT_SILU>), dim3(blocks), dim3(256), 0, st, p);
     else if (act == GT_ACT_RELU) hipLaunchKernelGGL((head_bwd_kernel<GT_ACT_RELU>), dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((head_bwd_kernel<GT_ACT_NONE>), dim3(blocks), dim3(256), 0, st, p);

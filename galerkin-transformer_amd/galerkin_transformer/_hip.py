@@ -15,9 +15,10 @@ import torch
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 _LIB_NAME = os.environ.get("GT_HIP_LIB", "libgt_hip.so")     # GT_HIP_LIB=libgt_hip_emu.so for the debug twin
 
-ABI_VERSION = 20          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
+ABI_VERSION = 21          # GT_ABI_VERSION of include/gt_hip.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 ACT_DROP_SILU = 4          # gt_gemm only: dropout in front of the SiLU, `pre` = keepscale * silu' (gt_hip.h)
+ACT_SILU2 = 5              # gt_gemm only: silu(silu(v)), `pre` = silu'(v) * silu'(silu(v)) (gt_hip.h)
 AUX_NONE, AUX_GT0, AUX_DSILU, AUX_MUL = 0, 1, 2, 3
 EP_NORMAL, EP_ROWDOT, EP_MLP_BWD, EP_HEADNORM = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3, PREC_BF16X2, PREC_BF16 = 0, 1, 2, 3
@@ -120,6 +121,10 @@ _PROTOS = {
     "gt_mlp_head_bwd_ws_bytes": (C.c_int64, [C.c_int64]),
     "gt_mlp_head_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 3 +
                         [C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_int64, C.c_void_p]),
+    "gt_mlp_head_bwd_gated": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 3 +
+                              [C.c_int32, C.c_int32] + [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
+    "gt_dft_synthesis_gated": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gt_dft_analysis": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p]),
     "gt_dft_synthesis": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                                                      C.c_int32, C.c_void_p, C.c_void_p]),
@@ -1189,18 +1194,19 @@ def mlp_head_fwd(x2, w1, b1, w2, b2, act: int, out, precision: Optional[str] = N
     return out
 
 
-def mlp_head_bwd(x2, w1, b1, w2, act: int, g, dx, dw1, db1, dw2, db2, precision: Optional[str] = None):
-    need_f32_cuda(x2, w1, b1, w2, g, dx, dw1, db1, dw2, db2)
+def mlp_head_bwd(x2, w1, b1, w2, act: int, g, dx, dw1, db1, dw2, db2, precision: Optional[str] = None, dx_gate=None):
+    """dx_gate [T, K]: dx *= silu'(dx_gate) on the kernel's store (gt_mlp_head_bwd_gated)."""
+    need_f32_cuda(x2, w1, b1, w2, g, dx, dw1, db1, dw2, db2, dx_gate)
     T, K = x2.shape
     N, no = w1.shape[0], w2.shape[0]
     prec = head_precision(precision)
     need = lib().gt_mlp_head_bwd_ws_bytes(T)
     ws = workspace(x2.device, need)
-    check(_timed("gt_mlp_head_bwd", 2.0 * T * N * (3 * K + 2 * no), 4.0 * T * (2 * K + no),
-                 lambda: lib().gt_mlp_head_bwd(x2.data_ptr(), T, K, N, no, w1.data_ptr(), ptr(b1), w2.data_ptr(), act,
-                                               prec, g.data_ptr(), ptr(dx), dw1.data_ptr(), ptr(db1), ptr(dw2), ptr(db2),
-                                               ws.data_ptr(), ws.numel(), stream_ptr()), shape=(T, K, N, no)),
-          "gt_mlp_head_bwd")
+    check(_timed("gt_mlp_head_bwd", 2.0 * T * N * (3 * K + 2 * no), 4.0 * T * ((3 if dx_gate is not None else 2) * K + no),
+                 lambda: lib().gt_mlp_head_bwd_gated(x2.data_ptr(), T, K, N, no, w1.data_ptr(), ptr(b1), w2.data_ptr(), act,
+                                                     prec, g.data_ptr(), ptr(dx), ptr(dx_gate), dw1.data_ptr(), ptr(db1),
+                                                     ptr(dw2), ptr(db2), ws.data_ptr(), ws.numel(), stream_ptr()),
+                 shape=(T, K, N, no)), "gt_mlp_head_bwd")
 
 
 def dft_supported(n: int, P: int, C_: int, Co: int) -> bool:
@@ -1217,13 +1223,16 @@ def dft_analysis(F, X, Y, nb: int, n: int, P: int, C_: int):
     return Y
 
 
-def dft_synthesis(F, Z, Y, nb: int, n: int, P: int, Co: int, X2, W2, C2: int, bias=None, act: int = 0, pre=None):
-    """Y[b] (n x Co) = act(F Z[b] + X2[b] W2 + bias) for nb grid lines (gt_dft_synthesis)."""
-    need_f32_cuda(F, Z, Y, X2, W2, bias, pre)
+def dft_synthesis(F, Z, Y, nb: int, n: int, P: int, Co: int, X2, W2, C2: int, bias=None, act: int = 0, pre=None,
+                  out_gate=None):
+    """Y[b] (n x Co) = act(F Z[b] + X2[b] W2 + bias) for nb grid lines (gt_dft_synthesis); out_gate [nb, n, Co]:
+    Y *= silu'(out_gate) on the store (gt_dft_synthesis_gated)."""
+    need_f32_cuda(F, Z, Y, X2, W2, bias, pre, out_gate)
     check(_timed("gt_dft_synthesis", 2.0 * nb * n * (P + C2) * Co,
-                 4.0 * nb * (n * (C2 + Co * (2 if pre is not None else 1)) + P * Co),
-                 lambda: lib().gt_dft_synthesis(F.data_ptr(), Z.data_ptr(), Y.data_ptr(), nb, n, P, Co, X2.data_ptr(),
-                                                W2.data_ptr(), C2, ptr(bias), act, ptr(pre), stream_ptr()),
+                 4.0 * nb * (n * (C2 + Co * (2 if pre is not None or out_gate is not None else 1)) + P * Co),
+                 lambda: lib().gt_dft_synthesis_gated(F.data_ptr(), Z.data_ptr(), Y.data_ptr(), nb, n, P, Co, X2.data_ptr(),
+                                                      W2.data_ptr(), C2, ptr(bias), act, ptr(pre), ptr(out_gate),
+                                                      stream_ptr()),
                  shape=(nb, n, P, Co, C2)), "gt_dft_synthesis")
     return Y
 

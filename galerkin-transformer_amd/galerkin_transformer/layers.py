@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 
 import numpy as np
 
@@ -261,6 +262,9 @@ class Interp2dEncoder(nn.Module):
         return _resize(out, self.interp_size[1], self.activation, out_nhwc=out_nhwc)
 
 
+_fuse_act2 = [os.environ.get("GT_CONV_ACT2", "1") != "0"]      # A/B switch: the up-scaler's two SiLUs on the convolution's epilogue
+
+
 class Interp2dUpsample(nn.Module):
     """resize -> conv block -> dropout -> act -> resize (layers.py:624-670)."""
 
@@ -285,9 +289,17 @@ class Interp2dUpsample(nn.Module):
         return (self.conv_block and self.interp_mode == "bilinear" and self.conv[0].plain()
                 and ops.conv3x3_nhwc_ok(self.conv[0].conv[0]))
 
-    def forward_features(self, x, in_nhwc=False, out_nhwc=False):
+    def forward_features(self, x, in_nhwc=False, out_nhwc=False, want_factor=False):
         """Everything but the final resize, at the intermediate size: (B, C, H1, W1) channels-first, or (B, H1, W1, C)
-        with ``out_nhwc`` (only when ``features_nhwc()``)."""
+        with ``out_nhwc`` (only when ``features_nhwc()``).
+        ``want_factor``: returns (features, fac-or-None).  With a tensor in the second place the two SiLUs behind the
+        convolution ran on its epilogue (ops.conv3x3_nhwc(act2=True): dropouts off, channels-last) and the caller MUST be
+        the only consumer of the features and multiply their gradient by ``fac`` (ops.upsample_fc(in_factor=fac))."""
+        if want_factor:
+            return self._features(x, in_nhwc, out_nhwc, True)
+        return self._features(x, in_nhwc, out_nhwc, False)[0]
+
+    def _features(self, x, in_nhwc, out_nhwc, may_fuse):
         if self.interp_mode != "bilinear":
             raise NotImplementedError(f"interp_mode={self.interp_mode!r}: only bilinear has a HIP path")
         if out_nhwc and not self.features_nhwc():
@@ -296,12 +308,16 @@ class Interp2dUpsample(nn.Module):
         if self.conv_block:
             blk = self.conv[0]
             if blk.plain():       # conv -> drop -> act -> drop -> act: the four elementwise stages in one pass
+                no_drop = not self.training or (blk.conv[1].p == 0 and self.dropout.p == 0)
+                if (may_fuse and out_nhwc and no_drop and _fuse_act2[0] and ops.conv3x3_nhwc_implicit(x)
+                        and _act_name(blk.activation) == "silu" and _act_name(self.activation) == "silu"):
+                    return ops.conv3x3_nhwc(x, blk.conv[0].weight, act2=True)       # ... or on the product's epilogue
                 y = ops.conv3x3_nhwc(x, blk.conv[0].weight) if out_nhwc else blk.conv[0](x)
                 x = ops.drop_act(y, blk.conv[1].p, _act_name(blk.activation), self.training,
                                  self.dropout.p, _act_name(self.activation))
             else:
                 x = ops.drop_act(blk(x), self.dropout.p, _act_name(self.activation), self.training)
-        return x
+        return x, None
 
     def forward(self, x, in_nhwc=False, out_nhwc=False):
         """x (B, C, H, W), or (B, H, W, C) with ``in_nhwc``; the layout changes ride on the resizes."""

@@ -157,21 +157,26 @@ class SpectralRegressor(nn.Module):
         self.return_latent = return_latent
         self.debug = debug
 
-    def forward(self, x, edge=None, pos=None, grid=None, upsample_to=None, x_nhwc=False):
+    def forward(self, x, edge=None, pos=None, grid=None, upsample_to=None, x_nhwc=False, in_factor=None):
         """``upsample_to=(Ho, Wo)``: x is the (B, C, H1, W1) feature map -- (B, H1, W1, C) with ``x_nhwc`` -- BEFORE the
-        scaler's final bilinear resize; the resize is then commuted behind ``fc`` (ops.upsample_fc)."""
+        scaler's final bilinear resize; the resize is then commuted behind ``fc`` (ops.upsample_fc).  ``in_factor``: see
+        Interp2dUpsample.forward_features(want_factor=True)."""
         x_latent = []
         if upsample_to is not None:
             assert self.spacial_fc
-            x = ops.upsample_fc(x, upsample_to, self.fc.weight, self.fc.bias, grid, x_nhwc=x_nhwc)
+            x = ops.upsample_fc(x, upsample_to, self.fc.weight, self.fc.bias, grid, x_nhwc=x_nhwc,
+                                in_factor=in_factor if in_factor is not None and in_factor.numel() else None)
         elif self.spacial_fc:
             x = ops.linear(x, self.fc.weight, self.fc.bias, extra=grid)
-        for layer in self.spectral_conv:
-            x = layer(x)
-            if self.return_latent:
-                x_latent.append(x.contiguous())
-        x = ops.mlp_head(x, self.regressor[0].weight, self.regressor[0].bias, self.regressor[2].weight,
-                         self.regressor[2].bias, act=_act_name(self.activation))
+        # every intermediate of the stack has exactly one consumer (unless the latents are handed out): the SiLU backward of
+        # a layer rides on the kernel that forms its result's gradient (ops.silu_gate_scope)
+        with ops.silu_gate_scope(not self.return_latent):
+            for layer in self.spectral_conv:
+                x = layer(x)
+                if self.return_latent:
+                    x_latent.append(x.contiguous())
+            x = ops.mlp_head(x, self.regressor[0].weight, self.regressor[0].bias, self.regressor[2].weight,
+                             self.regressor[2].bias, act=_act_name(self.activation))
         if self.normalizer:
             x = self.normalizer.inverse_transform(x)
         if self.return_freq or self.return_latent:
@@ -427,8 +432,8 @@ class FourierTransformer2D(_ConfiguredModel):
             # nothing sits between the upscaler's last resize and the regressor's fc: run fc at the coarse
             # resolution and interpolate its freq_dim channels instead of the n_hidden ones
             mid = up.features_nhwc()
-            x = self.regressor(up.forward_features(x, in_nhwc=True, out_nhwc=mid), grid=grid,
-                               upsample_to=tuple(up.interp_size[1]), x_nhwc=mid)
+            feat, fac = up.forward_features(x, in_nhwc=True, out_nhwc=mid, want_factor=True)
+            x = self.regressor(feat, grid=grid, upsample_to=tuple(up.interp_size[1]), x_nhwc=mid, in_factor=fac)
         else:
             x = self.upscaler(x)
             if self.return_latent:

@@ -299,8 +299,10 @@ class UpsampleFcFn(Function):
     nothing (dropout) sits between the resize and the Linear -- the caller checks."""
 
     @staticmethod
-    def forward(ctx, x, size, weight, bias, grid, x_nhwc):
-        H.need_f32_cuda(x, weight, bias, grid)
+    def forward(ctx, x, size, weight, bias, grid, x_nhwc, in_factor=None):
+        H.need_f32_cuda(x, weight, bias, grid, in_factor)
+        if in_factor is not None and not x_nhwc:
+            raise NotImplementedError("ops.upsample_fc: in_factor needs channels-last features")
         if x_nhwc:
             B, Hi, Wi, K = x.shape
         else:
@@ -318,13 +320,13 @@ class UpsampleFcFn(Function):
                    c_bs=(HW * N, 0))
         out = H.bilinear2d_fwd(z, (Ho, Wo), True, True, H.ACT_NONE, bias=bias, rp_a=gc.reshape(B, Ho, Wo, p),
                                rp_b=w[:, K:], rp_ldb=K + p)
-        ctx.save_for_backward(xc, w, gc)
+        ctx.save_for_backward(xc, w, gc, None if in_factor is None else _c(in_factor))
         ctx.cfg = (B, K, Hi, Wi, Ho, Wo, N, p, bias is not None, x_nhwc)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        xc, w, gc = ctx.saved_tensors
+        xc, w, gc, fac = ctx.saved_tensors
         B, K, Hi, Wi, Ho, Wo, N, p, has_b, x_nhwc = ctx.cfg
         dev, HW, To = g.device, Hi * Wi, B * Ho * Wo
         gg = _c(g)
@@ -343,8 +345,12 @@ class UpsampleFcFn(Function):
             dw[:, :K].copy_(dwxt.t())
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(B, Hi, Wi, K, **f32)
-                H.gemm(dz, w, dx, B * HW, K, N, layout_b=1, lda=N, ldb=K + p, ldc=K)
-            return dx, None, dw, db, None, None
+                if fac is None:
+                    H.gemm(dz, w, dx, B * HW, K, N, layout_b=1, lda=N, ldb=K + p, ldc=K)
+                else:       # in_factor: the producer's activation derivative rides on this product's epilogue
+                    H.gemm(dz, w, dx, B * HW, K, N, layout_b=1, lda=N, ldb=K + p, ldc=K, aux_op=H.AUX_MUL,
+                           aux=fac.reshape(B * HW, K), ldaux=K)
+            return dx, None, dw, db, None, None, None
         # d W_x = sum_b dz_b^T x_b^T : one [N, K] slab per batch entry, reduced in a fixed order
         slabs = torch.empty(B, N, K, **f32)
         H.gemm(dz, xc, slabs, N, K, HW, layout_a=1, layout_b=0, lda=N, ldb=HW, ldc=K, batch=(B, 1),
@@ -357,13 +363,15 @@ class UpsampleFcFn(Function):
             dx = torch.empty(B, K, Hi, Wi, **f32)
             H.gemm(w, dz, dx, K, HW, N, layout_a=1, layout_b=0, lda=K + p, ldb=N, ldc=HW, batch=(B, 1),
                    b_bs=(HW * N, 0), c_bs=(K * HW, 0))
-        return dx, None, dw, db, None, None
+        return dx, None, dw, db, None, None, None
 
 
-def upsample_fc(x, size, weight, bias, grid, x_nhwc: bool = False):
+def upsample_fc(x, size, weight, bias, grid, x_nhwc: bool = False, in_factor=None):
+    """in_factor (same shape as x, channels-last only): x is the output of conv3x3_nhwc(act2=True), whose backward expects
+    the gradient already multiplied by this factor -- the data-gradient product here does it on its epilogue."""
     if grid.requires_grad:
         raise NotImplementedError("ops.upsample_fc: `grid` gets no gradient")
-    return UpsampleFcFn.apply(x, (int(size[0]), int(size[1])), weight, bias, grid, bool(x_nhwc))
+    return UpsampleFcFn.apply(x, (int(size[0]), int(size[1])), weight, bias, grid, bool(x_nhwc), in_factor)
 
 
 # ----------------------------------------------------------------------------------- 3x3 convolution, channels-last
@@ -479,7 +487,7 @@ class Conv3x3NhwcFn(Function):
     wrw kernel on the same buffers instead -- the two tie at B = 128."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, act2: bool = False):
         H.need_f32_cuda(x, weight)
         B, Hh, Ww, Cin = x.shape
         Cout = weight.shape[0]
@@ -487,13 +495,25 @@ class Conv3x3NhwcFn(Function):
         wf = _gathered(weight, "conv_fwd", lambda t: _conv_k_order(t.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)))   # [Cout][tap][Cin] -> k order
         y = torch.empty(B, Hh, Ww, Cout, dtype=torch.float32, device=x.device)
         ctx.prec = H.get_precision()             # the backward products run in the arithmetic of the forward
-        H.gemm(xc, wf, y, B * Hh * Ww, Cout, 9 * Cin, lda=Cin, ldb=9 * Cin, ldc=Cout, conv=(Hh, Ww, Cin),
-               precision=ctx.prec)
         ctx.save_for_backward(xc, weight)
-        return y
+        if not act2:
+            H.gemm(xc, wf, y, B * Hh * Ww, Cout, 9 * Cin, lda=Cin, ldb=9 * Cin, ldc=Cout, conv=(Hh, Ww, Cin),
+                   precision=ctx.prec)
+            return y
+        # act2: y = silu(silu(conv)) on the product's epilogue (GT_ACT_SILU2) + the factor silu' * silu'(silu), which the
+        # CONSUMER's backward multiplies the gradient with (ops.upsample_fc(in_factor=fac)): what arrives here is then
+        # already the gradient of the convolution's own output, and the backward below is the plain one
+        need = any(ctx.needs_input_grad)         # (grad mode itself is off inside Function.forward)
+        fac = torch.empty_like(y) if need else None
+        H.gemm(xc, wf, y, B * Hh * Ww, Cout, 9 * Cin, lda=Cin, ldb=9 * Cin, ldc=Cout, conv=(Hh, Ww, Cin),
+               act=H.ACT_SILU2, pre=fac, ldpre=Cout, precision=ctx.prec)
+        if fac is None:
+            fac = y.new_empty(0)
+        ctx.mark_non_differentiable(fac)
+        return y, fac
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gfac=None):
         xc, weight = ctx.saved_tensors
         B, Hh, Ww, Cin = xc.shape
         Cout = weight.shape[0]
@@ -538,15 +558,26 @@ class Conv3x3NhwcFn(Function):
                     g.permute(0, 3, 1, 2), xc.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last),
                     None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].contiguous()
         H.join_side(dev)
-        return dx, dw
+        return dx, dw, None
 
 
-def conv3x3_nhwc(x, weight):
+def conv3x3_nhwc_implicit(x) -> bool:
+    """True when conv3x3_nhwc(x, .) runs the implicit GEMM (and so can carry act2)."""
+    return x.shape[0] * x.shape[1] * x.shape[2] >= 96 and H.get_precision() != "f32"
+
+
+def conv3x3_nhwc(x, weight, act2: bool = False):
     """x (B, H, W, Cin) channels-last, weight (Cout, Cin, 3, 3) -> (B, H, W, Cout); see Conv3x3NhwcFn.  Less than one
-    tile of pixels (< 96) goes to the library convolution on the same buffers."""
-    if x.shape[0] * x.shape[1] * x.shape[2] < 96 or H.get_precision() == "f32":
+    tile of pixels (< 96) goes to the library convolution on the same buffers.
+    act2: returns (silu(silu(conv)), fac) -- the caller hands `fac` to the ONLY consumer of the first result, whose backward
+    must multiply the gradient by it (ops.upsample_fc(in_factor=fac)); implicit-GEMM path only (conv3x3_nhwc_implicit)."""
+    if not conv3x3_nhwc_implicit(x):
+        if act2:
+            raise H.GtNotSupported("conv3x3_nhwc(act2=True) outside the implicit-GEMM path")
         # (the implicit GEMM exists on the split-operand engine only: gt_hip.h says GT_ENOTSUP -> the library convolution)
         return torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), weight, padding=1).permute(0, 2, 3, 1).contiguous()
+    if act2:
+        return Conv3x3NhwcFn.apply(x, weight, True)
     return Conv3x3NhwcFn.apply(x, weight)
 
 
@@ -794,6 +825,51 @@ def linear(x, weight, bias=None, extra=None, act: str = None, p_drop: float = 0.
     return LinearFn.apply(x, weight, bias, extra, H.ACT_CODE[act], float(p_drop))
 
 
+# ----------------------------------------------------------------------------------- SiLU gates on the producer of a gradient
+# Inside a `silu_gate_scope` (SpectralRegressor's layer loop: every intermediate has exactly ONE consumer there) a Function
+# whose result is silu(pre) OFFERS its pre-activation under the result's address; the Function that consumes the result
+# TAKES it, and its backward multiplies the gradient it forms by silu'(pre) on the store of the kernel that forms it
+# (gt_dft_synthesis_gated / gt_mlp_head_bwd_gated).  The producer's backward then receives the gradient of its
+# PRE-activation (ctx.g_gated) and skips its own gt_act_bwd pass: 2 x 172 us per step at the headline shape.
+_gate_fold = [os.environ.get("GT_FOLD_GATES", "1") != "0"]       # A/B switch (tools / tests)
+_gate_depth = [0]
+_silu_gates = {}                 # data_ptr of an activated result -> (ctx of its Function, pre-activation)
+
+
+class silu_gate_scope:
+    def __init__(self, enabled: bool = True):
+        self.on = bool(enabled) and _gate_fold[0]
+
+    def __enter__(self):
+        if self.on:
+            _gate_depth[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _gate_depth[0] -= 1
+            if _gate_depth[0] == 0:
+                _silu_gates.clear()          # offers nobody took: their producers run gt_act_bwd as ever
+        return False
+
+
+def _offer_gate(ctx, out, pre):
+    ctx.g_gated = False
+    if _gate_depth[0] > 0 and pre is not None:
+        _silu_gates[out.data_ptr()] = (ctx, pre)
+
+
+def _take_gate(x):
+    """The pre-activation whose SiLU produced ``x`` (the caller's backward MUST multiply d(x) by silu' of it), or None."""
+    if _gate_depth[0] <= 0:
+        return None
+    ent = _silu_gates.pop(x.data_ptr(), None)
+    if ent is None or ent[1].numel() != x.numel():
+        return None
+    ent[0].g_gated = True
+    return ent[1]
+
+
 class MlpHeadFn(Function):
     """y = W2 act(W1 x + b1) + b2 with a narrow output (n_out <= 4) and hidden width <= 128: the tail of
     SpectralRegressor / PointwiseRegressor (model.py:575-580, 625-629).  The [T, hidden] activation never
@@ -814,13 +890,14 @@ class MlpHeadFn(Function):
         else:
             H.gemm(x2, w1c, None, T, N, K, lda=K, ldb=K, ldc=N, bias=b1, act=act, ep_mode=H.EP_ROWDOT, w2=w2c,
                    b2=b2, out2=out)
-        ctx.save_for_backward(x2, w1c, b1, w2c)
+        gate = _take_gate(x2) if ctx.needs_input_grad[0] else None
+        ctx.save_for_backward(x2, w1c, b1, w2c, gate)
         ctx.cfg = (act, K, N, no, b1 is not None, b2 is not None, x.shape)
         return out.reshape(*x.shape[:-1], no)
 
     @staticmethod
     def backward(ctx, gy):
-        x2, w1c, b1, w2c = ctx.saved_tensors
+        x2, w1c, b1, w2c, gate = ctx.saved_tensors
         act, K, N, no, hb1, hb2, xshape = ctx.cfg
         dev, T = gy.device, x2.shape[0]
         g = _c(gy).reshape(T, no)
@@ -830,7 +907,8 @@ class MlpHeadFn(Function):
             dw1, dw2 = torch.empty(N, K, **f32), torch.empty(no, N, **f32)
             db1 = torch.empty(N, **f32) if hb1 else None
             db2 = torch.empty(no, **f32) if hb2 else None
-            H.mlp_head_bwd(x2, w1c, b1, w2c, act, g, dx, dw1, db1, dw2, db2, precision=ctx.prec)
+            H.mlp_head_bwd(x2, w1c, b1, w2c, act, g, dx, dw1, db1, dw2, db2, precision=ctx.prec,
+                           dx_gate=None if gate is None else gate.reshape(T, K))
             return (dx.reshape(xshape) if dx is not None else None), dw1, db1, dw2, db2, None
         dh, dw2 = torch.empty(T, N, **f32), torch.empty(no, N, **f32)
         H.gemm(x2, w1c, dh, T, N, K, lda=K, ldb=K, ldc=N, bias=b1, act=act, ep_mode=H.EP_MLP_BWD, w2=w2c, g2=g,
@@ -840,6 +918,8 @@ class MlpHeadFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, K, **f32)
             H.gemm(dh, w1c, dx, T, K, N, layout_b=1, lda=N, ldb=K, ldc=K)
+            if gate is not None:
+                dx = H.act_bwd(dx, gate.reshape(T, K), H.ACT_SILU)
             dx = dx.reshape(xshape)
         dw1 = torch.empty(N, K, **f32)
         db1 = torch.empty(N, **f32) if hb1 else None

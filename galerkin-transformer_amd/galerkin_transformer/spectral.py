@@ -25,6 +25,7 @@ import torch
 from torch.autograd import Function
 
 from . import _hip as H
+from . import ops
 from .ops import _c
 
 _basis_cache: Dict[Tuple, Tuple[torch.Tensor, ...]] = {}
@@ -106,22 +107,25 @@ class SpectralConv2dFn(Function):
             H.gemm(F4, Z, out, n, Co, 2 * m, layout_b=1, lda=2 * m, ldb=Co, ldc=Co, batch=(B * n, 1),
                    b_bs=(2 * m * Co, 0), c_bs=(n * Co, 0), bias=blin, act=act, pre=pre, ldpre=Co,
                    K2=C, A2=xc, lda2=C, a2_bs=(n * C, 0), B2=wlT, ldb2=Co)
-        ctx.save_for_backward(xc, wl, w0c, w1c, X2, pre)
+        gate = ops._take_gate(xc) if ctx.needs_input_grad[0] else None       # x = silu(gate) of the layer in front (ops.silu_gate_scope)
+        ctx.save_for_backward(xc, wl, w0c, w1c, X2, pre, gate)
         ctx.cfg = (B, n, C, Co, m, act, blin is not None)
+        ops._offer_gate(ctx, out, pre if act == H.ACT_SILU else None)
         Yout = Y if want_freq else Y.new_empty(0)        # the mixed retained modes [B, 2, 2 m m, Co] (detached)
         ctx.mark_non_differentiable(Yout)
         return out, Yout
 
     @staticmethod
     def backward(ctx, gy, _gfreq=None):
-        xc, wl, w0c, w1c, X2, pre = ctx.saved_tensors
+        xc, wl, w0c, w1c, X2, pre, gate = ctx.saved_tensors
         B, n, C, Co, m, act, has_b = ctx.cfg
         dev = gy.device
         F1, G2, G3, F4 = _bases(n, m, dev)
         T, Q = B * n * n, 2 * m * m
         f32 = dict(dtype=torch.float32, device=dev)
         g = _c(gy)
-        dpre = H.act_bwd(g, pre, act) if act != H.ACT_NONE else g
+        # (g_gated: the consumer of this layer's result took its pre-activation and already multiplied by silu')
+        dpre = g if act == H.ACT_NONE or getattr(ctx, "g_gated", False) else H.act_bwd(g, pre, act)
         dZ = torch.empty(B * n, 2 * m, Co, **f32)
         line = H.dft_supported(n, 2 * m, C, Co)
         if line:
@@ -142,11 +146,13 @@ class SpectralConv2dFn(Function):
         # dx = r2c-stage^T(dX1) + dpre Wl  (second product of the same launch)
         dx = torch.empty(B, n, n, C, **f32)
         if line:
-            H.dft_synthesis(F1, dX1, dx, B * n, n, 2 * m, C, dpre, wl, Co)
+            H.dft_synthesis(F1, dX1, dx, B * n, n, 2 * m, C, dpre, wl, Co, out_gate=gate)
         else:
             H.gemm(F1, dX1, dx, n, C, 2 * m, layout_b=1, lda=2 * m, ldb=C, ldc=C, batch=(B * n, 1),
                    b_bs=(2 * m * C, 0), c_bs=(n * C, 0),
                    K2=Co, A2=dpre, lda2=Co, a2_bs=(n * Co, 0), B2=wl, ldb2=C)
+            if gate is not None:
+                dx = H.act_bwd(dx, gate.reshape(dx.shape), H.ACT_SILU)
         dwl = torch.empty(Co, C, **f32)
         dbl = torch.empty(Co, **f32) if has_b else None
         H.gemm(dpre, xc, dwl, Co, C, T, layout_a=1, layout_b=1, lda=Co, ldb=C, ldc=C, split_k=0, a_colsum=dbl)

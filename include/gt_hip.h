@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 20
+#define GT_ABI_VERSION 21
 
 /* argument errors */
 #define GT_EINVAL   (-1)   /* bad shape / flag combination            */
@@ -42,6 +42,12 @@ extern "C" {
                                     u = keepscale(m, n) * v;   result = silu(u);   pre[m][n] (optional) = keepscale(m, n) * silu'(u)
                                 `drop` is consumed here (not applied again behind the activation), and `pre` receives the factor the
                                 backward multiplies the output gradient with (GT_AUX_MUL) instead of the pre-activation */
+
+#define GT_ACT_SILU2 5       /* gt_gemm only (ABI v21): two SiLUs in a row -- Interp2dUpsample's conv block -> activation -> activation
+                                (layers.py:642-650: Conv2dResBlock's own activation, then the up-scaler's) when its dropouts are off:
+                                    result = silu(silu(v));   pre[m][n] (optional) = silu'(v) * silu'(silu(v))
+                                `pre` is again the factor of the backward (GT_AUX_MUL on the product that forms the result's
+                                gradient); `drop` must be NULL / p = 0 (GT_EINVAL) */
 
 /* gt_gemm_desc.aux_op: multiply the result by a function of aux[m][n] */
 #define GT_AUX_NONE      0
@@ -435,6 +441,13 @@ int gt_dft_analysis(const float* F, const float* X, float* Y, int32_t nb, int32_
 int gt_dft_synthesis(const float* F, const float* Z, float* Y, int32_t nb, int32_t n, int32_t P, int32_t Co,
                      const float* X2, const float* W2, int32_t C2, const float* bias, int32_t act, float* pre,
                      void* stream);
+/* ABI v21: the same with  Y *= silu'(out_gate)  on the store (out_gate [nb, n, Co]; act must be GT_ACT_NONE, pre NULL).  In the
+ * backward of a SpectralConv2d stack (model.py:569-572 backwards) the synthesis of layer l + 1 forms the gradient of layer l's
+ * activated output: with out_gate = layer l's saved pre-activation it hands over the gradient of the pre-activation, and
+ * layer l's own gt_act_bwd pass disappears. */
+int gt_dft_synthesis_gated(const float* F, const float* Z, float* Y, int32_t nb, int32_t n, int32_t P, int32_t Co,
+                           const float* X2, const float* W2, int32_t C2, const float* bias, int32_t act, float* pre,
+                           const float* out_gate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused pointwise regression head  out[t] = w2 . act(W1 x[t] + b1) + b2  (model.py:575-580, 625-629: the
@@ -455,6 +468,12 @@ int64_t gt_mlp_head_bwd_ws_bytes(int64_t T);
 int gt_mlp_head_bwd(const float* X, int64_t T, int32_t K, int32_t N, int32_t n_out, const float* W1,
                     const float* b1, const float* w2, int32_t act, int32_t precision, const float* g, float* dX,
                     float* dW1, float* db1, float* dw2, float* db2, void* ws, int64_t ws_bytes, void* stream);
+/* ABI v21: dX *= silu'(dx_gate) on the store (dx_gate [T, K] = the pre-activation of the layer whose SiLU produced X, e.g.
+ * the last SpectralConv2d in front of the head, model.py:572-575); NULL = gt_mlp_head_bwd. */
+int gt_mlp_head_bwd_gated(const float* X, int64_t T, int32_t K, int32_t N, int32_t n_out, const float* W1,
+                          const float* b1, const float* w2, int32_t act, int32_t precision, const float* g, float* dX,
+                          const float* dx_gate, float* dW1, float* db1, float* dw2, float* db2, void* ws, int64_t ws_bytes,
+                          void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row LayerNorm over the feature axis (model.py:128-129,134-135 when layer_norm=True).

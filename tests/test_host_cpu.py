@@ -99,7 +99,7 @@ def test_c_abi_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(_hip.EXPORTED_SYMBOLS)
-    assert _hip.lib().gt_abi_version() == _hip.ABI_VERSION == 20
+    assert _hip.lib().gt_abi_version() == _hip.ABI_VERSION == 21
     assert _hip.lib().gt_target_arch() == b"gfx950"
 
 

@@ -657,6 +657,46 @@ def test_gemm_tall_skinny_wgrad(H, gpu_device, M, N, K, sign, colsum):
         assert rel_l2(cs, sign * A.double().sum(0)) < KTOL
 
 
+@pytest.mark.parametrize("prec", ["f16x2", "f32"])
+def test_silu_gate_on_the_store_of_the_gradient_kernels(H, gpu_device, prec):
+    """ABI v21: gt_dft_synthesis_gated / gt_mlp_head_bwd_gated multiply the gradient they form by silu'(gate) on their own
+    store -- bit for bit the ungated kernel followed by gt_act_bwd (which the SpectralConv2d in front of them then skips)."""
+    dev = gpu_device
+    nb, n, P, C = 300, 141, 24, 32
+    g = torch.Generator().manual_seed(77)
+    F = torch.randn(n, P, generator=g).to(dev)
+    Z = torch.randn(nb, P, C, generator=g).to(dev)
+    X = torch.randn(nb, n, C, generator=g).to(dev)
+    W2 = (torch.randn(C, C, generator=g) / 6).to(dev)
+    gate = (2.0 * torch.randn(nb, n, C, generator=g)).to(dev)
+    plain = torch.full((nb, n, C), float("nan"), device=dev)
+    gated = torch.full((nb, n, C), float("nan"), device=dev)
+    H.dft_synthesis(F, Z, plain, nb, n, P, C, X, W2, C)
+    H.dft_synthesis(F, Z, gated, nb, n, P, C, X, W2, C, out_gate=gate)
+    assert torch.equal(gated, H.act_bwd(plain, gate, H.ACT_SILU))
+    gd = gate.double()
+    sg = torch.sigmoid(gd)
+    assert rel_l2(gated, plain.double() * sg * (1 + gd * (1 - sg))) < 2e-6
+    with pytest.raises(H.GtError):                  # a gate and an activation of its own do not go together
+        H.dft_synthesis(F, Z, gated, nb, n, P, C, X, W2, C, act=H.ACT_SILU, out_gate=gate)
+    T = 4099
+    x = rnd(T, 32, dev=dev, seed=80)
+    w1, b1 = rnd(128, 32, dev=dev, seed=81, scale=0.3), rnd(128, dev=dev, seed=84, scale=0.3)
+    w2 = rnd(1, 128, dev=dev, seed=82, scale=0.3)
+    gy = rnd(T, 1, dev=dev, seed=83)
+    hg = 2.0 * rnd(T, 32, dev=dev, seed=85)
+    outs = []
+    for dx_gate in (None, hg):
+        dx = torch.full((T, 32), float("nan"), device=dev)
+        dw1, db1 = torch.full((128, 32), float("nan"), device=dev), torch.full((128,), float("nan"), device=dev)
+        dw2 = torch.full((1, 128), float("nan"), device=dev)
+        H.mlp_head_bwd(x, w1, b1, w2, H.ACT_SILU, gy, dx, dw1, db1, dw2, None, precision=prec, dx_gate=dx_gate)
+        outs.append((dx, dw1, db1, dw2))
+    assert torch.equal(outs[1][0], H.act_bwd(outs[0][0], hg, H.ACT_SILU))
+    for a, b_ in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(a, b_)
+
+
 def test_mlp_head_dedicated_kernels_without_optional_outputs(H, gpu_device):
     """gt_mlp_head_fwd / gt_mlp_head_bwd with no biases and no input gradient (the x.requires_grad == False
     case), against the GEMM-epilogue implementation of the same head."""
@@ -1368,6 +1408,40 @@ def test_gemm_second_output_under_a_dropout_mask(H, gpu_device, M, N, K, prec):
     with pytest.raises(NotImplementedError):
         H.gemm(A, R, torch.empty(K, N, device=dev), K, N, M, layout_a=1, layout_b=1, lda=K, ldb=N, ldc=N, split_k=4,
                c_masked=torch.empty(K, N, device=dev), ldc_masked=N, c_mask=dm)
+
+
+@pytest.mark.parametrize("M,N,K,prec,conv", [(20000, 128, 256, "f16x2", None), (4 * 40 * 40, 128, 9 * 128, "f16x2", (40, 40, 128)),
+                                             (777, 96, 130, "f32", None), (20000, 128, 256, "bf16x3", None)])
+def test_gemm_two_silus_on_the_epilogue(H, gpu_device, M, N, K, prec, conv):
+    """GT_ACT_SILU2 (ABI v21): silu(silu(A W^T)) with the product of the two derivatives left in `pre` -- the conv block ->
+    activation -> activation tail of Interp2dUpsample (reference layers.py:642-650) when its dropouts are off -- on the
+    packed-B fast epilogue (plain and implicit 3x3 convolution), the ring kernel and the fp32 engine's per-row epilogue."""
+    dev = gpu_device
+    if conv is None:
+        A, W = rnd(M, K, dev=dev, seed=340), rnd(N, K, dev=dev, seed=341, scale=0.1)
+        u = A.double() @ W.double().t()
+        kw = dict(lda=K, ldb=K, ldc=N)
+    else:
+        Hh, Ww, Cc = conv
+        img = rnd(M // (Hh * Ww), Hh, Ww, Cc, dev=dev, seed=340)
+        w4 = rnd(N, Cc, 3, 3, dev=dev, seed=341, scale=0.05)
+        u = torch.nn.functional.conv2d(img.double().permute(0, 3, 1, 2), w4.double(), padding=1).permute(0, 2, 3, 1).reshape(M, N)
+        from galerkin_transformer import ops as _ops
+        A, W = img.reshape(M, Cc), _ops._conv_k_order(w4.permute(0, 2, 3, 1).reshape(N, 9, Cc))
+        kw = dict(lda=Cc, ldb=9 * Cc, ldc=N, conv=conv)
+    out = torch.full((M, N), float("nan"), device=dev)
+    fac = torch.full((M, N), float("nan"), device=dev)
+    H.gemm(A, W, out, M, N, K, act=H.ACT_SILU2, pre=fac, ldpre=N, precision=prec, **kw)
+    out_only = torch.full((M, N), float("nan"), device=dev)
+    H.gemm(A, W, out_only, M, N, K, act=H.ACT_SILU2, precision=prec, **kw)
+    torch.cuda.synchronize()
+    ud = u.clone().requires_grad_(True)
+    ref = torch.nn.functional.silu(torch.nn.functional.silu(ud))
+    ref.sum().backward()
+    assert rel_l2(out, ref.detach()) < KTOL and rel_l2(fac, ud.grad) < KTOL
+    assert torch.equal(out, out_only)
+    with pytest.raises(H.GtError):         # a dropout has no place in this form (GT_EINVAL)
+        H.gemm(A, W, out, M, N, K, act=H.ACT_SILU2, drop=H.dropout_desc(0.1, 5, dev), precision=prec, **kw)
 
 
 @pytest.mark.parametrize("T,p_h,p_o,with_res,act", [(16384 + 37, 0.05, 0.05, True, "relu"), (236672, 0.05, 0.1, True, "relu"),

@@ -251,6 +251,85 @@ def test_masked_gradient_twins_change_nothing_but_the_launch_count(gpu_device, w
     assert drops[0] - drops[1] == (2 * L - 1 if L else 0), drops       # every block but the LAST one (its gradient comes from the up-scaler)
 
 
+@pytest.mark.parametrize("workload,B", [("ex2_darcy141", 2), ("ex2_darcy211_fourier", 1)])
+def test_upscaler_activations_on_the_convolution_epilogue(gpu_device, workload, B):
+    """Round 6: the conv -> SiLU -> SiLU tail of Interp2dUpsample (reference layers.py:642-650; ex2: upscaler_dropout 0) runs
+    on the epilogue of the implicit-GEMM convolution (GT_ACT_SILU2) and its derivative on the epilogue of the product that
+    forms the features' gradient (ops.upsample_fc(in_factor=...)) instead of in gt_dropact_fwd / gt_dropact_bwd.  Same
+    seed => the same loss and parameter gradients as the unfused passes to rounding, and two elementwise launches fewer."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip, layers
+    grads, calls, losses = [], [], []
+    old = layers._fuse_act2[0]
+    try:
+        for fuse in (False, True):
+            layers._fuse_act2[0] = fuse
+            torch.manual_seed(11)
+            model, _ = bench.build_model(workload)
+            model = model.to(gpu_device).train()
+            gt.set_attention_dropout("reference")
+            batch = bench.synthetic_batch(B, gpu_device, seed=7, workload=workload)
+            tr = bench.Trainer(model, batch, 1, use_graph=False, workload=workload)
+            _hip.set_seed(123, gpu_device)
+            for p in tr.params:
+                p.grad = None
+            with _hip.Profile() as prof:
+                tr.fwd_bwd()
+            torch.cuda.synchronize()
+            grads.append(tr.opt.flat_grad.clone())
+            losses.append(float(tr.loss.item()))
+            t = prof.table()
+            calls.append(t.get("gt_dropact_fwd", {}).get("calls", 0) + t.get("gt_dropact_bwd", {}).get("calls", 0))
+    finally:
+        layers._fuse_act2[0] = old
+    assert calls[0] - calls[1] == 2, calls
+    assert abs(losses[0] - losses[1]) <= 1e-6 * abs(losses[0])
+    rel = float((grads[0] - grads[1]).norm() / grads[0].norm())
+    assert rel < 2e-6, rel
+
+
+@pytest.mark.parametrize("workload,B", [("ex2_darcy141", 2), ("ex2_darcy211_fourier", 1)])
+def test_silu_backward_of_the_spectral_layers_on_the_gradient_kernels(gpu_device, workload, B):
+    """Round 6: inside SpectralRegressor (reference model.py:569-580) the SiLU backward of a SpectralConv2d rides on the store
+    of the kernel that forms its result's gradient (the next layer's synthesis, the regression head's backward:
+    ops.silu_gate_scope) instead of a gt_act_bwd pass of its own.  Same seed => bit-identical parameter gradients, two
+    gt_act_bwd launches fewer."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import galerkin_transformer as gt
+    from galerkin_transformer import _hip, ops
+    grads, calls = [], []
+    old = ops._gate_fold[0]
+    try:
+        for fold in (False, True):
+            ops._gate_fold[0] = fold
+            torch.manual_seed(11)
+            model, _ = bench.build_model(workload)
+            model = model.to(gpu_device).train()
+            gt.set_attention_dropout("reference")
+            batch = bench.synthetic_batch(B, gpu_device, seed=7, workload=workload)
+            tr = bench.Trainer(model, batch, 1, use_graph=False, workload=workload)
+            _hip.set_seed(123, gpu_device)
+            for p in tr.params:
+                p.grad = None
+            with _hip.Profile() as prof:
+                tr.fwd_bwd()
+            torch.cuda.synchronize()
+            grads.append(tr.opt.flat_grad.clone())
+            calls.append(prof.table().get("gt_act_bwd", {}).get("calls", 0))
+    finally:
+        ops._gate_fold[0] = old
+    assert calls[0] - calls[1] == 2, calls
+    assert torch.equal(grads[0], grads[1])
+    assert not ops._silu_gates and ops._gate_depth[0] == 0
+
+
 def test_graph_step_equals_eager_step(gpu_device):
     """Same seed => the captured training step (fwd+bwd+clip+Adam, all dropouts on) updates the
     parameters exactly like the eager step."""
