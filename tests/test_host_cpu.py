@@ -389,3 +389,47 @@ def test_ctypes_prototypes_match_the_header_cpu():
         assert (pres, res) in ((C.c_int, "int"), (C.c_int32, "int32_t"), (C.c_int64, "int64_t"), (C.c_char_p, "const char *"), (C.c_char_p, "const char*"),
                                (None, "void")), (name, pres, res)
     assert seen == set(_hip._PROTOS), sorted(set(_hip._PROTOS) - seen)
+
+
+def test_silu_gate_registry_bookkeeping_cpu():
+    """ops.silu_gate_scope (round 6): offers are only recorded inside a scope, a taker marks the producer's ctx and gets its
+    pre-activation exactly once, a size mismatch or a take outside the scope gives nothing (the producer then runs its own
+    gt_act_bwd), and leaving the outermost scope drops what nobody took."""
+    import torch
+    from galerkin_transformer import ops
+
+    class Ctx:
+        pass
+
+    out, pre = torch.zeros(4, 8), torch.ones(4, 8)
+    c0 = Ctx()
+    ops._offer_gate(c0, out, pre)                       # outside a scope: nothing recorded
+    assert c0.g_gated is False and not ops._silu_gates
+    assert ops._take_gate(out) is None
+    old = ops._gate_fold[0]
+    try:
+        ops._gate_fold[0] = True
+        with ops.silu_gate_scope(True):
+            c1 = Ctx()
+            ops._offer_gate(c1, out, pre)
+            got = ops._take_gate(out.view(32))          # a reshaped view of the result: same address
+            assert got is pre and c1.g_gated is True
+            assert ops._take_gate(out) is None          # one consumer only
+            c2, c3 = Ctx(), Ctx()
+            ops._offer_gate(c2, out, pre)
+            assert ops._take_gate(torch.zeros(4, 8)) is None and c2.g_gated is False      # another tensor
+            ops._offer_gate(c3, out, torch.ones(2, 8))  # replaces c2's offer; the size does not fit the result
+            assert ops._take_gate(out) is None and c3.g_gated is False
+            with ops.silu_gate_scope(True):             # nested scopes share the registry
+                ops._offer_gate(c2, out, pre)
+            assert ops._silu_gates
+        assert not ops._silu_gates and ops._gate_depth[0] == 0
+        with ops.silu_gate_scope(False):                # disabled scope (return_latent): no offers
+            ops._offer_gate(c2, out, pre)
+            assert not ops._silu_gates
+        ops._gate_fold[0] = False
+        with ops.silu_gate_scope(True):                 # GT_FOLD_GATES=0
+            ops._offer_gate(c2, out, pre)
+            assert not ops._silu_gates
+    finally:
+        ops._gate_fold[0] = old
