@@ -2076,8 +2076,10 @@ int x3_launch(const GemmP& p, int layout_a, int layout_b, int planes, unsigned t
     }
     if (p.wg_f16) {                                // GT_PREC_F16X2 weight gradient (x3w_ok said yes)
         const int pf = x3w_prefetch();
-        static const int map = [] { const char* e = getenv("GT_X3W_MAP"); return e ? atoi(e) : 2; }();
-        GemmP q = p;                                   // map 0: tile-major grid; 1: chunk-major within an XCD; 2: that for two tiles
+        // map 0: tile-major grid; 1: chunk-major within an XCD (default since round 6: the same time as 2 at three tiles, and
+        // the narrower operand is fetched once instead of once per tile -- 727 -> ~500 MB at [384 x 128]); 2: that for two tiles only
+        static const int map = [] { const char* e = getenv("GT_X3W_MAP"); return e ? atoi(e) : 1; }();
+        GemmP q = p;
         q.x3w_map = map == 1 || (map == 2 && tiles == 2);
         const dim3 g1 = q.x3w_map ? dim3(8u * ((split + 7) / 8) * tiles) : grid;
         if (pf == 1) hipLaunchKernelGGL(gemm_x3w_kernel<1>, g1, dim3(256), 0, st, q);

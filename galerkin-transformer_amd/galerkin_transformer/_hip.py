@@ -740,8 +740,11 @@ def ffn_fwd(x2: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, res, d
     st = stream_ptr()
     call = lambda: L.gt_ffn_fwd(x2.data_ptr(), T, d, f, w1.data_ptr(), ptr(b1), w2.data_ptr(), ptr(b2), ptr(res), dh, do, act,
                                 hid.data_ptr(), out.data_ptr(), ptr(bits), p1, p2, wsp, wsn, st)
-    nbytes = 4.0 * T * (d + f + d + (d if res is not None else 0))
-    check(_timed("gt_ffn_fwd", 4.0 * T * d * f, nbytes, call, shape=(T, d, f)), "gt_ffn_fwd")
+    # algorithmic bytes: x, hid, out (+ the residual when it is another tensor than x) + the decision bits
+    own_res = res is not None and res.data_ptr() != x2.data_ptr()
+    nbytes = 4.0 * T * (d + f + d + (d if own_res else 0)) + (bits.numel() if bits is not None else 0)
+    keep = (x2, w1, b1, w2, b2, res, drop_h, drop_o, hid, out, bits)
+    check(_timed("gt_ffn_fwd", 4.0 * T * d * f, nbytes, call, replay=(call, keep), shape=(T, d, f)), "gt_ffn_fwd")
     return bits
 
 
@@ -761,8 +764,9 @@ def ffn_bwd(gm: torch.Tensor, w2: torch.Tensor, w1: torch.Tensor, bits: torch.Te
     st = stream_ptr()
     call = lambda: L.gt_ffn_bwd(gm.data_ptr(), T, d, f, w2.data_ptr(), w1.data_ptr(), bits.data_ptr(), float(hid_scale), ptr(res),
                                 gh.data_ptr(), dx.data_ptr(), ptr(dx_masked), m2, p2, p1, wsp, wsn, st)
-    nbytes = 4.0 * T * (d + f + d + (d if res is not None else 0) + (d if dx_masked is not None else 0))
-    check(_timed("gt_ffn_bwd", 4.0 * T * d * f, nbytes, call, shape=(T, d, f)), "gt_ffn_bwd")
+    nbytes = 4.0 * T * (d + f + d + (d if res is not None else 0) + (d if dx_masked is not None else 0)) + bits.numel()
+    keep = (gm, w2, w1, bits, res, gh, dx, dx_masked, mask2)
+    check(_timed("gt_ffn_bwd", 4.0 * T * d * f, nbytes, call, replay=(call, keep), shape=(T, d, f)), "gt_ffn_bwd")
 
 
 def gemm_kernel_name(A, B, M, N, K, *, layout_a=0, layout_b=0, lda, ldb, ldc, split_k=1, precision=None) -> str:
