@@ -572,6 +572,10 @@ static int make_plan(const gt_gemm_desc* d, Plan* pl) {
         if (!has_epilogue(d) && blocks < 384 && d->K >= 512) {
             split = (int)std::min<int64_t>((target + blocks / 2) / blocks, d->K / (4 * pl->bk));
             if (split < 1) split = 1;
+            // token-contracted products on the split engine hand whole groups of K chunks to the eight XCDs (gemm_x3w_kernel's
+            // chunk-major grid): a multiple of eight chunks keeps every XCD at or under its 64 resident blocks -- 171 chunks x
+            // 3 tiles put 66 on seven of them and the launch paid a second round (178 us against 117)
+            if (pl->x3 && d->layout_a == 1 && d->layout_b == 1 && split >= 16) split &= ~7;
         }
     }
     if (d->cv_c > 0 && d->cv_wgrad)                   // nine taps per chunk: ~3 resident blocks per CU, whole XCD groups
