@@ -1805,7 +1805,7 @@ def test_scaler_chain_silu_with_factor_resize_matches_reference(H, gpu_device, p
     rcat = torch.cat(refs, -1).permute(0, 3, 1, 2)
     ry = F.silu(F.interpolate(rcat, size=(Ho, Ho), mode="bilinear", align_corners=True)).permute(0, 2, 3, 1)
     ry.backward(cot.double())
-    assert rel_l2(y, ry) < 3e-6
+    assert rel_l2(y, ry) < 4e-6                 # (f16x2: 1.9e-6; bf16x3, three chained convolutions: 3.0e-6)
     for i in range(3):
         assert rel_l2(ws[i].grad, wr[i].grad) < 5e-6, i
     assert rel_l2(x0.grad, xr.grad) < 5e-6
