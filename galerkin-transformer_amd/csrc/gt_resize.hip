@@ -810,10 +810,31 @@ __global__ __launch_bounds__(256) void resize_nhwc_fwd_kernel(const ResizeP p) {
     const Axis ax = axis_of(ox, p.sx, p.Wi);
     Axis ay[RN_RPT];
     f32x4 v[RN_RPT][4];
+    // Affine epilogue (gt_bilinear2d_fwd_affine: bias + up to two rank-1 terms, the regressor's fc(cat[x, grid]) commuted in
+    // front of the resize): the bias and the weights of the thread's four channels do not depend on the row -- fetched ONCE,
+    // here, and the rows' coefficients with the rows' taps, so that no load stands between the interpolation and the store
+    // (resize_affine ran a dynamic loop of dependent scalar loads per row: 260 us against 118 us without the epilogue; 155 now).
+    const bool rp2 = p.rp == 1 || p.rp == 2;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, w0 = bv, w1 = bv;
+    float a0[RN_RPT], a1[RN_RPT];
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + c);
+    if (rp2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            w0[t] = p.rp_b[(int64_t)(c + t) * p.rp_ldb];
+            w1[t] = p.rp == 2 ? p.rp_b[(int64_t)(c + t) * p.rp_ldb + 1] : 0.f;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < RN_RPT; ++r) {
         const int oy = min(oy0 + r, p.Ho - 1);
         ay[r] = axis_of(oy, p.sy, p.Hi);
+        a0[r] = a1[r] = 0.f;
+        if (rp2) {
+            const float* ga = p.rp_a + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * p.rp_lda;
+            a0[r] = ga[0];
+            if (p.rp == 2) a1[r] = ga[1];
+        }
         if (p.seg) {          // padded three-segment input: gather the four real channels (block-uniform branch)
             const int CP3 = 3 * p.segp;
             v[r][0] = seg_load4(p, p.x + addr<true>(b, 0, ay[r].i0, ax.i0, CP3, p.Hi, p.Wi), c);
@@ -832,7 +853,18 @@ __global__ __launch_bounds__(256) void resize_nhwc_fwd_kernel(const ResizeP p) {
         const int oy = oy0 + r;
         if (oy < p.Ho) {
             f32x4 o = ay[r].l0 * (ax.l0 * v[r][0] + ax.l1 * v[r][1]) + ay[r].l1 * (ax.l0 * v[r][2] + ax.l1 * v[r][3]);
-            o = resize_affine(p, o, b, c, oy, ox);
+            if (rp2 || !p.rp) {                 // same operations in the same order as resize_affine
+                if (p.bias) o += bv;
+                if (rp2) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        o[t] = fmaf(a0[r], w0[t], o[t]);
+                        if (p.rp == 2) o[t] = fmaf(a1[r], w1[t], o[t]);
+                    }
+                }
+            } else {
+                o = resize_affine(p, o, b, c, oy, ox);
+            }
             if (p.act == GT_ACT_RELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
@@ -859,9 +891,23 @@ __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
     const int CX = p.seg ? 3 * p.segp : p.C;
     const int C4 = CX >> 2;
     const int e = blockIdx.x * 256 + threadIdx.x;
+    const int iy = blockIdx.y, b = blockIdx.z;
+    // The tap tables (first output, count, weights: float divisions and a dozen axis_of evaluations each) are the same for every
+    // channel group of a pixel and -- along y -- for the whole block: worked out ONCE per block by the first threads and read
+    // back from LDS, instead of twice by every thread (they were a large part of the kernel's instructions).
+    constexpr int TXMAX = 66;                        // pixels a block's 256 four-channel groups can touch when C4 >= 4
+    __shared__ Taps s_tx[TXMAX];
+    __shared__ Taps s_ty;
+    const int px0 = (blockIdx.x * 256) / C4;
+    const bool shared_taps = C4 >= 4;
+    if (shared_taps) {
+        const int npx = min((blockIdx.x * 256 + 255) / C4, p.Wi - 1) - px0 + 1;
+        if ((int)threadIdx.x < npx) s_tx[threadIdx.x] = taps_of(px0 + threadIdx.x, p.sx, p.Wi, p.Wo);
+        if (threadIdx.x == 255) s_ty = taps_of(iy, p.sy, p.Hi, p.Ho);
+        __syncthreads();
+    }
     if (e >= p.Wi * C4) return;
     const int ix = e / C4, c = (e - ix * C4) * 4;
-    const int iy = blockIdx.y, b = blockIdx.z;
     int cr[4] = {c, c + 1, c + 2, c + 3};          // real channel of each column, -1: padding
     if (p.seg) {
 #pragma unroll
@@ -871,8 +917,8 @@ __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const ResizeP p) {
             cr[j] = r < width ? sgi * p.seg + r : -1;
         }
     }
-    const Taps ty = taps_of(iy, p.sy, p.Hi, p.Ho);
-    const Taps tx = taps_of(ix, p.sx, p.Wi, p.Wo);
+    const Taps ty = shared_taps ? s_ty : taps_of(iy, p.sy, p.Hi, p.Ho);
+    const Taps tx = shared_taps ? s_tx[ix - px0] : taps_of(ix, p.sx, p.Wi, p.Wo);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int jy = 0; jy < RS_MAXT; ++jy) {
