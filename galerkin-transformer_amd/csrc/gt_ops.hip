@@ -1337,15 +1337,19 @@ __global__ __launch_bounds__(256) void modemix_bwd_kernel(
     int Cin, int Cout, int64_t xbs, int64_t ybs, int Qx, int Qy, int qoff, float* __restrict__ dX,
     float* __restrict__ dW) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sWr = lds;                       // [Cin][Cout]
-    float* sWi = sWr + Cin * Cout;
-    float* sX = sWi + Cin * Cout;           // [MM_BCH][2][Cin]
+    // weight rows padded by one float: the dX loop below reads W[i][o] with the lanes running over i -- at a row pitch of
+    // Cout = 32 floats every lane of a wave hit the same LDS bank (a 32-way conflict on both reads of each of the Cout steps)
+    const int CW = Cout + 1;
+    float* sWr = lds;                       // [Cin][Cout + 1]
+    float* sWi = sWr + Cin * CW;
+    float* sX = sWi + Cin * CW;             // [MM_BCH][2][Cin]
     float* sG = sX + MM_BCH * 2 * Cin;      // [MM_BCH][2][Cout]
     const int q = blockIdx.x;
     for (int e = threadIdx.x; e < Cin * Cout; e += blockDim.x) {
         const float2 w = *reinterpret_cast<const float2*>(W + ((int64_t)e * Q + q) * 2);
-        sWr[e] = w.x;
-        sWi[e] = w.y;
+        const int i = e / Cout, o = e - i * Cout;
+        sWr[i * CW + o] = w.x;
+        sWi[i * CW + o] = w.y;
     }
     // each thread owns up to MAXP (i,o) pairs of dW, accumulated over the whole batch in registers
     float gr[MAXP], gi[MAXP];
@@ -1372,7 +1376,7 @@ __global__ __launch_bounds__(256) void modemix_bwd_kernel(
             const float* g_i = g_r + Cout;
             float xr = 0.f, xi = 0.f;
             for (int o = 0; o < Cout; ++o) {
-                const float wr = sWr[i * Cout + o], wi = sWi[i * Cout + o];
+                const float wr = sWr[i * CW + o], wi = sWi[i * CW + o];
                 xr = fmaf(g_r[o], wr, xr); xr = fmaf(g_i[o], wi, xr);
                 xi = fmaf(g_i[o], wr, xi); xi = fmaf(-g_r[o], wi, xi);
             }
@@ -1764,7 +1768,7 @@ extern "C" int gt_modemix_bwd(const float* X, const float* W, const float* dY, i
     if (((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(dW)) & 7) != 0) return GT_EALIGN;
     if (Cin * Cout > 24 * 256) return GT_ENOTSUP;          // 96 x 48 (ex1 as shipped) = 18 pairs per thread
     const size_t lds =
-        ((size_t)2 * Cin * Cout + (size_t)MM_BCH * 2 * Cin + (size_t)MM_BCH * 2 * Cout) * sizeof(float);
+        ((size_t)2 * Cin * (Cout + 1) + (size_t)MM_BCH * 2 * Cin + (size_t)MM_BCH * 2 * Cout) * sizeof(float);
     const int S = modemix_slices(B, Q);
     const int64_t nW = (int64_t)Cin * Cout * Q * 2;
     float* dWk = dW;                                       // S == 1: the kernel writes dW directly
