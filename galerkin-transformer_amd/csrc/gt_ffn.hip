@@ -296,9 +296,11 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
                     f16_mulsplit_pair(acc[i][j][4 * g], sv, acc[i][j][4 * g + 1], sv, h0, l0);
                     f16_mulsplit_pair(acc[i][j][4 * g + 2], sv, acc[i][j][4 * g + 3], sv, h1, l1);
                     // hidden columns 64 wave + 32 j + 8 g + 4 lh .. + 3 = k-half g & 1 of stage 4 wave + 2 j + g / 2, second half of
-                    // the fragment's eight k for lh = 1:  [plane][stage][row][k-half] x 16 B
+                    // the fragment's eight k for lh = 1:  [plane][stage][k-half][row] x 16 B -- rows in consecutive 16-byte slots:
+                    // the 8-byte stores of a wave cover 512 contiguous bytes and a fragment read is conflict-free (with the
+                    // k-halves of a row side by side, at a row pitch of 32 bytes, both hit every bank group several times)
                     const int st = 4 * wave + 2 * j + (g >> 1);
-                    char* dst = smem + ((st * 64 + row) * 32 + (g & 1) * 16 + lh * 8);
+                    char* dst = smem + (((st * 2 + (g & 1)) * 64 + row) * 16 + lh * 8);
                     *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
                     *reinterpret_cast<uint2*>(dst + 16 * 64 * 32) = uint2{l0, l1};
                 }
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd16_kernel(const FfnP p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if constexpr (PS) {                                // finished fragments: no split, no exponent bookkeeping
-                const char* fr = smem + ((kt2 * 64 + 32 * i + lr) * 32 + lh * 16);
+                const char* fr = smem + (((kt2 * 2 + lh) * 64 + 32 * i + lr) * 16);
                 const f16x8 a0 = *reinterpret_cast<const f16x8*>(fr);
                 const f16x8 a1 = *reinterpret_cast<const f16x8*>(fr + 16 * 64 * 32);
                 acc2[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bn[0][0], a1, acc2[i][0], 0, 0, 0);     // h1 g0

@@ -1724,6 +1724,8 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
     // 8-token units to split and store
     const bool isB = wave >= 2;                        // wave-uniform
     const int st = tid & 127, r4 = st & 31, kg = st >> 5;
+    const int wsw = (r4 >> 1) & 3;                     // plane-store swizzle of rows 4 r4 + c:  ((4 r4 + c) >> 3) & 3
+    const int lrs = lr ^ ((lr >> 3) & 3);              // fragment-read swizzle of row .. + lr (the tile bases are multiples of 32)
     const float* Op = isB ? p.B + n0 + 4 * r4 : p.A + m0 + 4 * r4;
     const int64_t ldo = isB ? p.ldb : p.lda;
     // A whole stage (the usual case, block-uniform test): the address of a load is a wave-uniform row pointer (token k0 + e of
@@ -1818,7 +1820,11 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
             uint32_t q[4][2];
 #pragma unroll
             for (int t = 0; t < 4; ++t) x3h_split_pair(v[2 * t][c], v[2 * t + 1][c], sv, q[t]);
-            const int off = (kg * 128 + 4 * r4 + c) << 4;
+            // slot swizzle: row R sits in slot R ^ ((R >> 3) & 3).  A thread owns the four rows 4 r4 + c (its global loads are
+            // float4 over rows), so without it the eight lanes of a ds_write_b128 pass hit 16-byte slots 64 bytes apart -- two
+            // bank groups, a four-way conflict on every plane store (SQ_LDS_BANK_CONFLICT: 0.59 of the kernel's LDS cycles);
+            // with it those eight slots are distinct modulo 8, and so are the eight consecutive rows of a fragment read
+            const int off = (kg * 128 + 4 * r4 + (c ^ wsw)) << 4;
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
                 *reinterpret_cast<u32x4*>(planes + pl * X3W_PLANE + off) = u32x4{q[0][pl], q[1][pl], q[2][pl], q[3][pl]};
@@ -1835,8 +1841,8 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_x3w_kernel(const Ge
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
                     const int kq = 2 * ks + lh;
-                    am[i][pl] = *reinterpret_cast<const f16x8*>(smem + pl * X3W_PLANE + ((kq * 128 + wm * 64 + 32 * i + lr) << 4));
-                    bn[i][pl] = *reinterpret_cast<const f16x8*>(smem + (2 + pl) * X3W_PLANE + ((kq * 128 + wn * 64 + 32 * i + lr) << 4));
+                    am[i][pl] = *reinterpret_cast<const f16x8*>(smem + pl * X3W_PLANE + ((kq * 128 + wm * 64 + 32 * i + lrs) << 4));
+                    bn[i][pl] = *reinterpret_cast<const f16x8*>(smem + (2 + pl) * X3W_PLANE + ((kq * 128 + wn * 64 + 32 * i + lrs) << 4));
                 }
 #pragma unroll
             for (int s = 1; s >= 0; --s)
