@@ -506,8 +506,15 @@ __device__ __forceinline__ void x3_epilogue_hn(const GemmP& p, const f32x16 (&ac
                     }
                 }
                 float* dst = seg + p.hn_p + dim;
+                if ((p.hn_p & 1) == 0) {                      // two 8-byte stores (the coordinates in front shift the head by
+                    // hn_p floats: no 16-byte alignment).  Thirty-two rows at a pitch that is a multiple of four floats meet in
+                    // eight banks: four scalar stores per group were the kernel's LDS bank conflicts (0.58 - 0.77 of its LDS cycles)
+                    *reinterpret_cast<f32x2*>(dst) = f32x2{y[0], y[1]};
+                    *reinterpret_cast<f32x2*>(dst + 2) = f32x2{y[2], y[3]};
+                } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dst[t] = y[t];
+                    for (int t = 0; t < 4; ++t) dst[t] = y[t];
+                }
             }
             if (lh == 0) {                                    // one lane of the pair: coordinates, padding, statistics
 #pragma unroll
