@@ -1041,14 +1041,19 @@ __global__ __launch_bounds__(256) void galerkin_ktv_lds_kernel(const float* __re
 // ------------------------------------------------------------------------------------------ galerkin finalize
 // One block per (batch, head, group of FIN_RB rows of M): row j of P needs row j of M only.  (Round 5: one block per
 // (batch, head) walked the whole 52 x 52 matrix with n_slabs dependent loads per element -- 178 us at ex4's 16 x 64 slabs.)
-constexpr int FIN_RB = 4;
+// Rows per block: a quarter of the matrix (round 6; four until then).  Every block stages all of W_h (d x DP floats: 18 KB at
+// d = 128, 40 KB at d = 192) for its rows' products -- with four rows per block that staging was most of the kernel's traffic
+// (4 608 blocks x 18 KB at C2, 6 656 x 40 KB at C4).
+static inline int fin_rows_per_block(int DP) { return std::max(4, (DP + 3) / 4); }
 __global__ __launch_bounds__(256) void galerkin_fin_fwd_kernel(
     const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int h, int DP, int Dr, int d,
     float inv_n, const float* __restrict__ mask, DropDev drop, const float* __restrict__ Wfc,
-    float* __restrict__ Mt, float* __restrict__ P, float* __restrict__ Pv, int pdim) {
+    float* __restrict__ Mt, float* __restrict__ P, float* __restrict__ Pv, int pdim, int FIN_RB) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // Both operands of the product loop are read as 16-byte vectors along the contraction (DP % 4 == 0; W_h's rows are padded
+    // to DP columns with zeros): a quarter of the LDS instructions of the scalar loop, which was what the kernel waited for.
     float* sM = lds;                    // [FIN_RB][DP]
-    float* sW = lds + FIN_RB * DP;      // [d][Dr]
+    float* sW = lds + FIN_RB * DP;      // [d][DP]
     const int bh = blockIdx.x, b = bh / h, hh = bh % h;
     const int j0 = blockIdx.y * FIN_RB, nr = min(FIN_RB, DP - j0);
     const uint32_t key = drop_key_dev(drop);
@@ -1072,9 +1077,9 @@ __global__ __launch_bounds__(256) void galerkin_fin_fwd_kernel(
         sM[le] = v;
         Mt[mo + e] = v;
     }
-    for (int e = threadIdx.x; e < d * Dr; e += blockDim.x) {
-        const int c = e / Dr, ee = e % Dr;
-        sW[e] = Wfc[(int64_t)c * (h * Dr) + hh * Dr + ee];
+    for (int e = threadIdx.x; e < d * DP; e += blockDim.x) {
+        const int c = e / DP, ee = e % DP;
+        sW[e] = ee < Dr ? Wfc[(int64_t)c * (h * Dr) + hh * Dr + ee] : 0.f;
     }
     __syncthreads();
     float* Pb = P + ((int64_t)b * h * DP + (int64_t)hh * DP) * d;
@@ -1082,9 +1087,13 @@ __global__ __launch_bounds__(256) void galerkin_fin_fwd_kernel(
         const int jl = le / d, c = le % d, j = j0 + jl;
         float acc = 0.f;
         if (j < Dr) {
-            const float* mr = sM + jl * DP;
-            const float* wr = sW + c * Dr;
-            for (int ee = 0; ee < Dr; ++ee) acc = fmaf(mr[ee], wr[ee], acc);
+            const f32x4* mr = reinterpret_cast<const f32x4*>(sM + jl * DP);
+            const f32x4* wr = reinterpret_cast<const f32x4*>(sW + c * DP);
+            for (int q = 0; q < (DP >> 2); ++q) {           // the scalar loop's order (the zero columns behind Dr add nothing)
+                const f32x4 m4 = mr[q], w4 = wr[q];
+                acc = fmaf(m4[0], w4[0], acc); acc = fmaf(m4[1], w4[1], acc);
+                acc = fmaf(m4[2], w4[2], acc); acc = fmaf(m4[3], w4[3], acc);
+            }
         }
         Pb[(int64_t)j * d + c] = acc;
         // the value rows of P once more, compact [B][h dk][d]: the B operand of the backward's dQ product (it used to be
@@ -1106,11 +1115,13 @@ __global__ __launch_bounds__(256) void galerkin_fin_bwd_kernel(
     const int jr = (DP + parts - 1) / parts, j0 = part * jr, j1 = min(DP, j0 + jr), nj = max(0, j1 - j0);
     const int cr = (d + parts - 1) / parts, c0 = part * cr, c1 = min(d, c0 + cr), nc = max(0, c1 - c0);
     const int dpitch = d + 1, cpitch = cr + 1;
-    float* sdr = lds;                       // [jr][d+1]    dP_h[j0 + j][c]        (rows of this part, every feature)
+    // W_h (rows padded to DP columns with zeros) and M first: both are read as 16-byte vectors along ee (four outputs per
+    // thread: one broadcast scalar + one vector read per four FMAs, where the scalar loops issued two reads per FMA)
+    float* sW = lds;                        // [d][DP]
+    float* sM = sW + d * DP;                // [DP][DP]
+    float* sdr = sM + DP * DP;              // [jr][d+1]    dP_h[j0 + j][c]        (rows of this part, every feature)
     float* sdc = parts == 1 ? sdr : sdr + jr * dpitch;    // [DP][cr+1]   dP_h[j][c0 + c]   (every row, features of this part;
                                                           //  one part: the same image as sdr)
-    float* sW = sdc + DP * cpitch;          // [d][Dr]
-    float* sM = sW + d * Dr;                // [DP][DP]
     const int bh = blockIdx.x, b = bh / h, hh = bh % h;
     const uint32_t key = drop_key_dev(drop);
     const int64_t mo = (int64_t)bh * DP * DP;
@@ -1124,31 +1135,38 @@ __global__ __launch_bounds__(256) void galerkin_fin_bwd_kernel(
             const int c = e / DP, j = e % DP;
             sdc[j * cpitch + c] = src[(int64_t)(c0 + c) * (h * DP) + j];
         }
-    for (int e = threadIdx.x; e < d * Dr; e += blockDim.x) {
-        const int c = e / Dr, ee = e % Dr;
-        sW[e] = Wfc[(int64_t)c * (h * Dr) + hh * Dr + ee];
+    for (int e = threadIdx.x; e < d * DP; e += blockDim.x) {
+        const int c = e / DP, ee = e % DP;
+        sW[e] = ee < Dr ? Wfc[(int64_t)c * (h * Dr) + hh * Dr + ee] : 0.f;
     }
     for (int e = threadIdx.x; e < DP * DP; e += blockDim.x) sM[e] = Mt[mo + e];
     __syncthreads();
-    for (int e = threadIdx.x; e < nj * DP; e += blockDim.x) {
-        const int jl = e / DP, ee = e % DP, j = j0 + jl;
-        float acc = 0.f;
-        if (j < Dr && ee < Dr) {
+    const int Q4 = DP >> 2;
+    for (int e = threadIdx.x; e < nj * Q4; e += blockDim.x) {
+        const int jl = e / Q4, q = e - jl * Q4, j = j0 + jl;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (j < Dr) {
             const float* dp = sdr + jl * dpitch;
-            for (int c = 0; c < d; ++c) acc = fmaf(dp[c], sW[c * Dr + ee], acc);
-            float mul = inv_n;
-            if (mask) mul *= mask[mo + j * DP + ee];
-            else if (drop.thresh) mul *= drop_mul(drop, key, (uint32_t)(mo + j * DP + ee));
-            acc *= mul;
+            for (int c = 0; c < d; ++c) acc += dp[c] * *reinterpret_cast<const f32x4*>(sW + c * DP + 4 * q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ee = 4 * q + t;
+                float mul = inv_n;
+                if (mask) mul *= mask[mo + j * DP + ee];
+                else if (drop.thresh) mul *= drop_mul(drop, key, (uint32_t)(mo + j * DP + ee));
+                acc[t] = ee < Dr ? acc[t] * mul : 0.f;
+            }
         }
-        dM[mo + j * DP + ee] = acc;
+        *reinterpret_cast<f32x4*>(dM + mo + j * DP + 4 * q) = acc;
     }
     float* dst = dWfc_slabs + (int64_t)b * d * (h * Dr) + hh * Dr;
-    for (int e = threadIdx.x; e < nc * Dr; e += blockDim.x) {
-        const int cl = e / Dr, ee = e % Dr;
-        float acc = 0.f;
-        for (int j = 0; j < Dr; ++j) acc = fmaf(sdc[j * cpitch + cl], sM[j * DP + ee], acc);
-        dst[(int64_t)(c0 + cl) * (h * Dr) + ee] = acc;
+    for (int e = threadIdx.x; e < nc * Q4; e += blockDim.x) {
+        const int cl = e / Q4, q = e - cl * Q4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < Dr; ++j) acc += sdc[j * cpitch + cl] * *reinterpret_cast<const f32x4*>(sM + j * DP + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * q + t < Dr) dst[(int64_t)(c0 + cl) * (h * Dr) + 4 * q + t] = acc[t];
     }
 }
 
@@ -1668,11 +1686,14 @@ extern "C" int gt_galerkin_finalize_fwd(const float* slabs, int32_t n_slabs, int
         n_tokens <= 0 || pos_dim < 0 || pos_dim >= Dr)
         return GT_EINVAL;
     if (drop && drop->p > 0.f && !drop->seed) return GT_EINVAL;
-    const size_t lds = ((size_t)FIN_RB * DP + (size_t)d * Dr) * sizeof(float);
+    if (DP & 3) return GT_EINVAL;
+    // (few (batch, head) pairs: four rows per block as before, for the parallelism of the slab sums)
+    const int FIN_RB = B * h >= 256 ? fin_rows_per_block(DP) : 4;
+    const size_t lds = ((size_t)FIN_RB * DP + (size_t)d * DP) * sizeof(float);
     if (int rc = allow_big_lds(galerkin_fin_fwd_kernel, lds)) return rc;
     hipLaunchKernelGGL(galerkin_fin_fwd_kernel, dim3(B * h, (DP + FIN_RB - 1) / FIN_RB), dim3(256), lds, (hipStream_t)stream, slabs,
                        n_slabs, slab_stride, h, DP, Dr, d, 1.f / (float)n_tokens, mask,
-                       make_drop(mask ? nullptr : drop), Wfc, Mt, P, Pv, pos_dim);
+                       make_drop(mask ? nullptr : drop), Wfc, Mt, P, Pv, pos_dim, FIN_RB);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -1689,7 +1710,8 @@ extern "C" int gt_galerkin_finalize_bwd(const float* dPt, const float* Mt, const
     // the full staging would leave one block per CU) always take four
     const int parts = std::max(d >= 160 ? 4 : 1, std::min(4, 1024 / (B * h)));
     const size_t lds = ((size_t)((DP + parts - 1) / parts) * (d + 1) + (parts > 1 ? (size_t)DP * ((d + parts - 1) / parts + 1) : 0) +
-                        (size_t)d * Dr + (size_t)DP * DP) * sizeof(float);
+                        (size_t)d * DP + (size_t)DP * DP) * sizeof(float);
+    if ((DP & 3) || (reinterpret_cast<uintptr_t>(dM) & 15)) return GT_EINVAL;
     if (int rc = allow_big_lds(galerkin_fin_bwd_kernel, lds)) return rc;
     hipLaunchKernelGGL(galerkin_fin_bwd_kernel, dim3(B * h, parts), dim3(256), lds, (hipStream_t)stream, dPt, Mt,
                        mask, make_drop(mask ? nullptr : drop), Wfc, h, DP, Dr, d, 1.f / (float)n_tokens, dM,
