@@ -510,10 +510,13 @@ class Conv3x3NhwcFn(Function):
         if fac is None:
             fac = y.new_empty(0)
         ctx.mark_non_differentiable(fac)
+        ctx.set_materialize_grads(False)         # (autograd filled a zero gradient the size of `fac` per step: 388 MB at C2)
         return y, fac
 
     @staticmethod
     def backward(ctx, gy, _gfac=None):
+        if gy is None:
+            return None, None, None
         xc, weight = ctx.saved_tensors
         B, Hh, Ww, Cin = xc.shape
         Cout = weight.shape[0]
@@ -661,10 +664,13 @@ class ScalerConvChainFn(Function):
             return out
         fac4 = fac.view(B, Hh, Ww, 3 * CP)
         ctx.mark_non_differentiable(fac4)
+        ctx.set_materialize_grads(False)         # (no zero gradient the size of `fac` from autograd)
         return out, fac4
 
     @staticmethod
     def backward(ctx, g, _gfac=None):
+        if g is None:
+            return (None,) * 7
         x0c, w1, w2, w3, cat, fac = ctx.saved_tensors
         p_drop, CP, grad_masked, silu = ctx.cfg
         prec = ctx.prec
